@@ -1,0 +1,180 @@
+/*
+ * pislam_hip.h — C ABI of the MI355X-native PiSlam ORB front-end.
+ *
+ * This is the drop-in boundary: a plain-C shared library (libpislam_hip.so,
+ * built from pislam_amd/csrc with hipcc for gfx950) whose entry points are
+ * what the reference's header-only templates forward to.  The C++ headers in
+ * include/pislam/ (Fast.h, Harris.h, Orb.h, Brief.h, Util.h) keep the
+ * reference's names, template parameter lists and argument order and are thin
+ * wrappers over the functions below; INTEGRATION.md shows the binding.
+ *
+ * Conventions
+ *   - every function returns PISLAM_OK (0) or a negative PISLAM_ERR_* code;
+ *     pislam_last_error(ctx) returns a static/ctx-owned message.
+ *   - image / score-map pointers are row-major uint8 with a row stride of
+ *     `vstep` bytes, exactly the reference's `uint8_t img[][vstep]`.
+ *   - every data pointer may be a HOST pointer or a DEVICE pointer
+ *     (hipPointerGetAttributes decides).  Host data is staged through
+ *     ctx-owned device buffers; device data is used in place (zero copy).
+ *   - all work is issued on the ctx's stream (default: the null stream);
+ *     calls with host pointers synchronise before returning, calls with only
+ *     device pointers are asynchronous on that stream unless noted.
+ *   - there is NO CPU fallback: if no gfx950 device is usable the functions
+ *     return PISLAM_ERR_HIP.
+ */
+#ifndef PISLAM_HIP_H_
+#define PISLAM_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PISLAM_OK 0
+#define PISLAM_ERR_INVALID (-1) /* bad argument / violated precondition */
+#define PISLAM_ERR_HIP (-2)     /* HIP runtime error (no device, launch failure, ...) */
+#define PISLAM_ERR_NOMEM (-3)   /* device allocation failed */
+
+#define PISLAM_ABI_VERSION 1
+
+typedef struct pislam_ctx pislam_ctx;
+
+/* ---- context ---------------------------------------------------------- */
+int pislam_abi_version(void);
+/* device < 0 selects the current HIP device. */
+int pislam_ctx_create(int device, pislam_ctx **ctx);
+int pislam_ctx_destroy(pislam_ctx *ctx);
+/* hip_stream is a hipStream_t passed as void*; NULL = null stream. */
+int pislam_ctx_set_stream(pislam_ctx *ctx, void *hip_stream);
+int pislam_ctx_synchronize(pislam_ctx *ctx);
+const char *pislam_last_error(const pislam_ctx *ctx);
+
+/* ---- the four reference entry points (one pyramid level each) ---------- */
+
+/* replaces pislam::fastDetect<vstep,border>(width,height,img,out,threshold)
+ * — reference include/Fast.h:54-158.  FAST-9 segment test; writes 0xff/0x00
+ * to out rows [border,height-border), columns [border, border+16*ceil((width-
+ * 2*border)/16)), plus out[y][width]=out[y][width+1]=0 when width%16 != 0.
+ * Nothing else in `out` is touched.  Requires border >= 3. */
+int pislam_fast_detect(pislam_ctx *ctx, int vstep, int border, int width, int height,
+                       const uint8_t *img, uint8_t *out, int threshold);
+
+/* replaces pislam::fastScoreHarris<vstep,border>(width,height,img,threshold,out)
+ * — reference include/Fast.h:166-180 (+ Harris.h:37-248).  Every non-zero
+ * out[y][x], y in [border,height-border), x in [border,width-border) is
+ * replaced by its 8-bit Harris log-score.  Requires border >= 4. */
+int pislam_fast_score_harris(pislam_ctx *ctx, int vstep, int border, int width, int height,
+                             const uint8_t *img, int32_t threshold, uint8_t *out);
+
+/* replaces pislam::fastExtract<vstep,border,logBucketSize,bucketLimit>(width,
+ * height,out,results) — reference include/Fast.h:196-355.  2x2-block non-max
+ * suppression (+ optional per-bucket top-k).  Writes the packed keypoints
+ * (score<<24 | x<<12 | y, level-relative, reference order) to results[0..cap)
+ * and the number the reference would have appended to *count (it may exceed
+ * `capacity`; only the first `capacity` are stored).  logBucketSize 0..8,
+ * bucketLimit 1..64.  Synchronous (count is returned to the host). */
+int pislam_fast_extract(pislam_ctx *ctx, int vstep, int border, int logBucketSize,
+                        int bucketLimit, int width, int height, const uint8_t *out,
+                        uint32_t *results, size_t capacity, size_t *count);
+
+/* replaces pislam::orbCompute<vstep,words>(img,points,descriptors)
+ * — reference include/Orb.h:396-441.  descriptors[i*words + j], i in [0,n).
+ * `img` is the base of the (stacked) image the keypoint coordinates refer to;
+ * with a host pointer only the byte hull the reference itself reads
+ * (rows y-15..y+15, columns x-15..x+16 of every keypoint) is accessed.
+ * words 1..8. */
+int pislam_orb_compute(pislam_ctx *ctx, int vstep, int words, const uint8_t *img,
+                       const uint32_t *points, size_t n, uint32_t *descriptors);
+
+/* ---- the reference's public helpers (L1 primitives) -------------------- */
+
+/* pislam::harrisScoreSobel<vstep>(img,x,y,threshold) — Harris.h:80-248.
+ * Batched over n points; scores[i] for packed point i (x<<12|y, score ignored). */
+int pislam_harris_score_points(pislam_ctx *ctx, int vstep, const uint8_t *img,
+                               const uint32_t *points, size_t n, int32_t threshold,
+                               uint8_t *scores);
+
+/* pislam::orbCentroids<vstep>(img,points) — Orb.h:80-308.  centroids has
+ * pislam_centroids_size(n) int32 in the reference's grouped layout
+ * [x0 x1 x2 x3 y0 y1 y2 y3]..., padding slots zero. */
+size_t pislam_centroids_size(size_t n);
+int pislam_orb_centroids(pislam_ctx *ctx, int vstep, const uint8_t *img,
+                         const uint32_t *points, size_t n, int32_t *centroids);
+
+/* pislam::atan2(const std::vector<int32_t>&) — Orb.h:310-387.  n8 (multiple
+ * of 8) int32 in the grouped layout -> n8/2 angle bins (0..29), padding slots
+ * included, exactly like the reference. */
+int pislam_orb_angles(pislam_ctx *ctx, const int32_t *centroids, size_t n8, uint8_t *angles);
+
+/* pislam::briefDescribe<vstep,words>(img,x,y,rot,descriptor) — Brief.h:637-733,
+ * batched: descriptors[i*words+j] for point i with rotation rots[i]. */
+int pislam_brief_describe(pislam_ctx *ctx, int vstep, int words, const uint8_t *img,
+                          const uint32_t *points, const uint8_t *rots, size_t n,
+                          uint32_t *descriptors);
+
+/* The rotated-BRIEF offset table int8[30][256][4] = (dx0,dy0,dx1,dy1) the
+ * kernels use (behaviour of Brief.h:28-53); host memory, 30720 bytes. */
+const int8_t *pislam_brief_table(void);
+
+/* ---- the measured path: a batch of stacked pyramids, device resident --- */
+
+typedef struct pislam_level {
+  int32_t width;  /* level width  (pixels)                                   */
+  int32_t height; /* level height (rows)                                     */
+  int32_t row0;   /* first row of the level inside the stacked pyramid       */
+  int32_t col0;   /* first column (0 for the vertically stacked layout)      */
+} pislam_level;
+
+typedef struct pislam_frontend_params {
+  int32_t vstep;            /* row stride in bytes (reference template vstep)  */
+  int32_t rows;             /* rows per pyramid buffer                         */
+  int32_t nlevels;          /* 1..16                                           */
+  int32_t border;           /* reference template border (>= 16 for ORB)       */
+  int32_t fast_threshold;   /* fastDetect threshold (demo: 20)                 */
+  int32_t harris_threshold; /* fastScoreHarris threshold (demo: 1<<15)         */
+  int32_t log_bucket_size;  /* fastExtract logBucketSize (0 = no buckets)      */
+  int32_t bucket_limit;     /* fastExtract bucketLimit                         */
+  int32_t words;            /* orbCompute words (1..8)                         */
+  int32_t max_keypoints;    /* capacity per pyramid of keypoints/descriptors   */
+} pislam_frontend_params;
+
+/* Runs, for every pyramid b in [0,batch) and every level l (in order), the
+ * call sequence of reference demo/demo.cpp:77-101 / README.md:67-82:
+ *   fastDetect -> fastScoreHarris -> fastExtract (y += row0, x += col0)
+ * then one orbCompute over the stacked image, entirely on the device.
+ *   pyramids    : DEVICE, batch * pyramid_stride bytes, pyramid b at
+ *                 pyramids + b*pyramid_stride, uint8 [rows][vstep]
+ *   keypoints   : DEVICE uint32 [batch][max_keypoints]   (reference order)
+ *   descriptors : DEVICE uint32 [batch][max_keypoints][words]
+ *   counts      : DEVICE uint32 [batch]  = keypoints the reference would emit
+ *                 (entries beyond max_keypoints are dropped, count is not clamped)
+ * Asynchronous on the ctx stream; no host round trips; capturable in a hipGraph
+ * after pislam_frontend_reserve() has sized the workspace. */
+int pislam_orb_frontend_batch(pislam_ctx *ctx, const pislam_frontend_params *params,
+                              const pislam_level *levels, const uint8_t *pyramids,
+                              size_t pyramid_stride, int batch, uint32_t *keypoints,
+                              uint32_t *descriptors, uint32_t *counts);
+
+/* Pre-allocates the ctx workspace for the given shape (optional; the batch
+ * call grows it on demand, which synchronises). */
+int pislam_frontend_reserve(pislam_ctx *ctx, const pislam_frontend_params *params,
+                            const pislam_level *levels, int batch);
+
+/* Debug / parity hook: after pislam_orb_frontend_batch, copies the internal
+ * score map of pyramid b (uint8 [rows][vstep], what the reference's `out`
+ * holds after fastScoreHarris on every level) to dst (host or device).
+ * Returns PISLAM_ERR_INVALID if the active pipeline does not materialise it. */
+int pislam_frontend_get_score_map(pislam_ctx *ctx, int b, uint8_t *dst);
+
+/* Elapsed milliseconds of the LAST pislam_orb_frontend_batch call on this ctx,
+ * measured with hipEvents recorded on the ctx stream around its kernels
+ * (total, and per internal stage: 0 detect+score, 1 extract, 2 orb).
+ * Synchronises on the end event. */
+int pislam_frontend_last_timing(pislam_ctx *ctx, float *total_ms, float stage_ms[3]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PISLAM_HIP_H_ */

@@ -1,0 +1,151 @@
+"""ctypes binding of libpislam_hip.so (include/pislam_hip.h).
+
+Fails loudly: if the shared library is missing or cannot be loaded an
+ImportError/OSError propagates — there is no Python or CPU fallback for any
+entry point.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+import numpy as np
+
+from . import build as _build
+
+PISLAM_OK = 0
+ABI_VERSION = 1
+
+_vp, _i, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t
+
+
+class Level(ctypes.Structure):
+    _fields_ = [("width", ctypes.c_int32), ("height", ctypes.c_int32),
+                ("row0", ctypes.c_int32), ("col0", ctypes.c_int32)]
+
+
+class FrontendParams(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int32) for n in (
+        "vstep", "rows", "nlevels", "border", "fast_threshold", "harris_threshold",
+        "log_bucket_size", "bucket_limit", "words", "max_keypoints")]
+
+
+# name -> (restype, argtypes); every symbol declared in include/pislam_hip.h
+SYMBOLS = {
+    "pislam_abi_version": (_i, []),
+    "pislam_ctx_create": (_i, [_i, ctypes.POINTER(_vp)]),
+    "pislam_ctx_destroy": (_i, [_vp]),
+    "pislam_ctx_set_stream": (_i, [_vp, _vp]),
+    "pislam_ctx_synchronize": (_i, [_vp]),
+    "pislam_last_error": (ctypes.c_char_p, [_vp]),
+    "pislam_fast_detect": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _i]),
+    "pislam_fast_score_harris": (_i, [_vp, _i, _i, _i, _i, _vp, ctypes.c_int32, _vp]),
+    "pislam_fast_extract": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _sz, ctypes.POINTER(_sz)]),
+    "pislam_orb_compute": (_i, [_vp, _i, _i, _vp, _vp, _sz, _vp]),
+    "pislam_harris_score_points": (_i, [_vp, _i, _vp, _vp, _sz, ctypes.c_int32, _vp]),
+    "pislam_centroids_size": (_sz, [_sz]),
+    "pislam_orb_centroids": (_i, [_vp, _i, _vp, _vp, _sz, _vp]),
+    "pislam_orb_angles": (_i, [_vp, _vp, _sz, _vp]),
+    "pislam_brief_describe": (_i, [_vp, _i, _i, _vp, _vp, _vp, _sz, _vp]),
+    "pislam_brief_table": (ctypes.POINTER(ctypes.c_int8), []),
+    "pislam_orb_frontend_batch": (_i, [_vp, ctypes.POINTER(FrontendParams), ctypes.POINTER(Level), _vp,
+                                       _sz, _i, _vp, _vp, _vp]),
+    "pislam_frontend_reserve": (_i, [_vp, ctypes.POINTER(FrontendParams), ctypes.POINTER(Level), _i]),
+    "pislam_frontend_get_score_map": (_i, [_vp, _i, _vp]),
+    "pislam_frontend_last_timing": (_i, [_vp, ctypes.POINTER(ctypes.c_float),
+                                         ctypes.POINTER(ctypes.c_float * 3)]),
+}
+
+_LIB = None
+
+
+def library_path() -> str:
+    return _build.LIB
+
+
+def load(rebuild_if_stale: bool = True):
+    """dlopen the in-tree library (building it first if hipcc and sources say it is stale)."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = _build.LIB
+    if rebuild_if_stale:
+        try:
+            path = _build.build()
+        except Exception:
+            if not os.path.exists(path):
+                raise
+    if not os.path.exists(path):
+        raise ImportError(f"{path} is missing: run `python -m pislam_amd.build` (hipcc, gfx950). "
+                          "pislam_amd has no CPU fallback.")
+    lib = ctypes.CDLL(path)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)          # AttributeError if the ABI lost a symbol
+        fn.restype, fn.argtypes = res, args
+    if lib.pislam_abi_version() != ABI_VERSION:
+        raise ImportError("libpislam_hip.so ABI version mismatch")
+    _LIB = lib
+    return lib
+
+
+class PislamError(RuntimeError):
+    pass
+
+
+def ptr(a) -> int:
+    """Raw address of a numpy array (host) or a torch tensor (host or device)."""
+    if a is None:
+        return 0
+    if isinstance(a, np.ndarray):
+        if not a.flags.c_contiguous:
+            raise ValueError("array must be C-contiguous")
+        return a.ctypes.data
+    if hasattr(a, "data_ptr"):
+        if not a.is_contiguous():
+            raise ValueError("tensor must be contiguous")
+        return a.data_ptr()
+    if isinstance(a, int):
+        return a
+    raise TypeError(f"cannot take the address of {type(a)}")
+
+
+class Context:
+    """Owns one pislam_ctx (one device, one stream)."""
+
+    def __init__(self, device: int = -1, stream: int | None = None):
+        self.lib = load()
+        h = _vp()
+        rc = self.lib.pislam_ctx_create(device, ctypes.byref(h))
+        if rc != PISLAM_OK:
+            raise PislamError(f"pislam_ctx_create failed ({rc}): no usable HIP device? "
+                              "(there is no CPU fallback)")
+        self.h = h
+        if stream is not None:
+            self.set_stream(stream)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.pislam_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def check(self, rc: int, what: str):
+        if rc != PISLAM_OK:
+            msg = self.lib.pislam_last_error(self.h)
+            raise PislamError(f"{what} failed ({rc}): {msg.decode() if msg else ''}")
+
+    def set_stream(self, stream: int):
+        self.check(self.lib.pislam_ctx_set_stream(self.h, _vp(stream)), "pislam_ctx_set_stream")
+
+    def synchronize(self):
+        self.check(self.lib.pislam_ctx_synchronize(self.h), "pislam_ctx_synchronize")
+
+
+def brief_table() -> np.ndarray:
+    p = load().pislam_brief_table()
+    return np.ctypeslib.as_array(p, shape=(30, 256, 4)).copy()

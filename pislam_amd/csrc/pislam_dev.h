@@ -1,0 +1,227 @@
+// pislam_dev.h — device-side primitives of the ORB front-end (gfx950, wave64).
+//
+// Every function states which reference lines define its result; the bodies are
+// written for the CDNA4 execution model (per-lane integer ALU, wave ballots,
+// LDS tiles), not transliterated from the NEON code.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace pdev {
+
+// ---------------------------------------------------------------------------
+// Keypoint codec — reference Util.h:27-45
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t encode_fast(uint32_t s, uint32_t x, uint32_t y) {
+  return (s << 24) | (x << 12) | y;
+}
+__device__ __forceinline__ int decode_x(uint32_t e) { return (e >> 12) & 0xfff; }
+__device__ __forceinline__ int decode_y(uint32_t e) { return e & 0xfff; }
+
+// ---------------------------------------------------------------------------
+// FAST-9 segment test — result of reference Fast.h:63-147 for one pixel.
+// Ring positions clockwise from (dy,dx)=(-3,-1) (Fast.h:66-128).  A pixel is
+// "dark" iff p < c - t and "bright" iff p > c + t (the saturating forms at
+// Fast.h:63-64 are equivalent); corner iff 9 circularly contiguous dark or 9
+// contiguous bright positions (what the clz/shift test at Fast.h:130-147
+// decides).
+// ---------------------------------------------------------------------------
+#define PISLAM_RING16(F)                                                         \
+  F(0, -3, -1) F(1, -3, 0) F(2, -3, 1) F(3, -2, 2) F(4, -1, 3) F(5, 0, 3)        \
+  F(6, 1, 3) F(7, 2, 2) F(8, 3, 1) F(9, 3, 0) F(10, 3, -1) F(11, 2, -2)          \
+  F(12, 1, -3) F(13, 0, -3) F(14, -1, -3) F(15, -2, -2)
+
+// 16-bit circular mask -> does it contain a run of >= 9 set bits?
+__device__ __forceinline__ bool has_arc9(uint32_t m) {
+  uint32_t x = m | (m << 16);
+  uint32_t r = x & (x >> 1);   // runs of 2
+  r &= r >> 2;                 // runs of 4
+  r &= r >> 4;                 // runs of 8
+  r &= x >> 8;                 // runs of 9
+  return (r & 0xffffu) != 0;
+}
+
+// c points at the centre pixel; pitch in bytes; thr already truncated to 8 bits.
+template <class P>
+__device__ __forceinline__ bool fast9(const P *c, int pitch, int thr) {
+  const int v = c[0];
+  const int lo = v - thr, hi = v + thr;
+  uint32_t dm = 0, bm = 0;
+#define PISLAM_F(k, dy, dx)                            \
+  {                                                    \
+    const int p = c[(dy) * pitch + (dx)];              \
+    dm |= (uint32_t)(p < lo) << (k);                   \
+    bm |= (uint32_t)(p > hi) << (k);                   \
+  }
+  PISLAM_RING16(PISLAM_F)
+#undef PISLAM_F
+  return has_arc9(dm) || has_arc9(bm);
+}
+
+// ---------------------------------------------------------------------------
+// Harris 6x6 Sobel score byte — reference Harris.h:80-248 + harrisEval
+// Harris.h:37-69.  c points at img[y][x].
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ uint8_t harris_eval(uint32_t Ixx, uint32_t Iyy, int32_t Ixy,
+                                               int32_t threshold) {
+  uint32_t tr = Ixx + Iyy;                                 // Harris.h:41
+  tr = (tr * tr) >> 4;                                     // Harris.h:42-43
+  uint32_t det = Ixx * Iyy - (uint32_t)Ixy * (uint32_t)Ixy;   // Harris.h:46-50
+  int32_t score = (int32_t)(det - tr);                     // Harris.h:53-55
+  if (threshold < score) {                                 // Harris.h:58
+    float f = (float)score;                                // v_cvt_f32_i32: RNE like vcvt.f32.s32
+    return (uint8_t)((__float_as_uint(f) >> 20) & 0xff);   // Harris.h:63-65
+  }
+  return 0;
+}
+
+template <class P>
+__device__ __forceinline__ uint8_t harris_score(const P *c, int pitch, int32_t threshold) {
+  int px[8][8];
+#pragma unroll
+  for (int r = 0; r < 8; r++)
+#pragma unroll
+    for (int q = 0; q < 8; q++) px[r][q] = c[(r - 3) * pitch + (q - 3)];   // Harris.h:102-110
+  uint32_t sxx = 0, syy = 0;
+  int32_t sxy = 0;
+#pragma unroll
+  for (int n = 0; n < 6; n += 2) {
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+      int dxv[2], dyv[2];
+#pragma unroll
+      for (int h = 0; h < 2; h++) {
+        const int m = n + h;
+        // dx: Harris.h:139-162 (halving adds; rows m, m+2 first, then m+1)
+        const int e0 = (px[m][i + 2] - px[m][i]) >> 1;
+        const int e1 = (px[m + 1][i + 2] - px[m + 1][i]) >> 1;
+        const int e2 = (px[m + 2][i + 2] - px[m + 2][i]) >> 1;
+        dxv[h] = (((e0 + e2) >> 1) + e1) >> 1;
+        // dy: Harris.h:123-135 (lanes i, i+2 first, then i+1)
+        const int d0 = (px[m + 2][i] - px[m][i]) >> 1;
+        const int d1 = (px[m + 2][i + 1] - px[m][i + 1]) >> 1;
+        const int d2 = (px[m + 2][i + 2] - px[m][i + 2]) >> 1;
+        dyv[h] = (d1 + ((d0 + d2) >> 1)) >> 1;
+      }
+      // Harris.h:166-213: 16-bit lane accumulation of a row pair, then widening
+      sxx += (uint32_t)(dxv[0] * dxv[0] + dxv[1] * dxv[1]) & 0xffffu;
+      syy += (uint32_t)(dyv[0] * dyv[0] + dyv[1] * dyv[1]) & 0xffffu;
+      sxy += (int32_t)(int16_t)(dxv[0] * dyv[0] + dxv[1] * dyv[1]);
+    }
+  }
+  return harris_eval(sxx >> 4, syy >> 4, sxy >> 4, threshold);   // Harris.h:243-247
+}
+
+// ---------------------------------------------------------------------------
+// 2x2-block non-max suppression — reference Fast.h:228-312.
+// s points at S[y][x] (block origin).  Returns the packed keypoint
+// encode(v, x', y') or 0 when the block emits nothing.
+// ---------------------------------------------------------------------------
+template <class P>
+__device__ __forceinline__ uint32_t nms_block(const P *s, int pitch, int x, int y) {
+#define S_(dy, dx) ((uint32_t)s[(dy) * pitch + (dx)])
+  const uint32_t v0 = S_(0, 0), v1 = S_(0, 1), v2 = S_(1, 0), v3 = S_(1, 1);
+  if (!(v0 | v1 | v2 | v3)) return 0;                                   // Fast.h:237
+  if (v0 > v1 && v0 > v2 && v0 > v3) {                                  // Fast.h:264-273
+    if (v0 >= S_(-1, -1) && v0 >= S_(0, -1) && v0 > S_(1, -1) && v0 >= S_(-1, 0) &&
+        v0 >= S_(-1, 1))
+      return encode_fast(v0, x, y);
+    return 0;
+  } else if (v1 > v2 && v1 > v3) {                                      // Fast.h:275-285
+    if (v1 >= S_(-1, 0) && v1 >= S_(-1, 1) && v1 >= S_(-1, 2) && v1 > S_(0, 2) &&
+        v1 > S_(1, 2))
+      return encode_fast(v1, x + 1, y);
+    return 0;
+  } else if (v2 > v3) {                                                 // Fast.h:287-296
+    if (v2 >= S_(0, -1) && v2 >= S_(1, -1) && v2 > S_(2, -1) && v2 > S_(2, 0) &&
+        v2 > S_(2, 1))
+      return encode_fast(v2, x, y + 1);
+    return 0;
+  } else {                                                              // Fast.h:298-309
+    if (v3 > S_(2, 0) && v3 > S_(2, 1) && v3 >= S_(0, 2) && v3 > S_(1, 2) && v3 > S_(2, 2))
+      return encode_fast(v3, x + 1, y + 1);
+    return 0;
+  }
+#undef S_
+}
+
+// ---------------------------------------------------------------------------
+// Orientation — reference Orb.h:310-387
+// ---------------------------------------------------------------------------
+// Half-width of the moment patch per |dy| (masks Orb.h:118-121, row macros
+// Orb.h:163-178,208-220,238-250,271-286), packed 4 bits each, |dy| = 0..15.
+__device__ __forceinline__ int patch_umax(int ady) {
+  // {15,15,15,15,15,15,14,14,13,13,12,11,10,9,7,5}
+  const uint64_t tab = 0x579ABCDDEEFFFFFFull;
+  return (int)((tab >> (4 * ady)) & 0xf);
+}
+
+// NEON vrecpe.f32 (Orb.h:329): ARM ARM FPRecipEstimate, 8-bit, flush-to-zero.
+__device__ __forceinline__ float vrecpe_f32(float f) {
+  const uint32_t u = __float_as_uint(f), sign = u & 0x80000000u, e = (u >> 23) & 0xff,
+                 m = u & 0x7fffffu;
+  if (e == 0xff) return __uint_as_float(m ? 0x7fc00000u : sign);
+  if (e == 0) return __uint_as_float(sign | 0x7f800000u);
+  if (e >= 253) return __uint_as_float(sign);
+  const uint32_t q2 = 2 * (256 + (m >> 15)) + 1;
+  const uint32_t s = ((1u << 19) + q2) / (2 * q2);
+  return __uint_as_float(sign | ((253 - e) << 23) | ((s - 256) << 15));
+}
+
+// (m10, m01) -> angle bin 0..29.  Float ops are individually rounded (the
+// library is built with -ffp-contract=off; ARMv7 NEON has no fused MAC here).
+__device__ __forceinline__ uint32_t angle_bin(int32_t x, int32_t y) {
+  const float xf = fabsf((float)x), yf = fabsf((float)y);      // Orb.h:318-322
+  const float zmax = fmaxf(xf, yf), zmin = fminf(xf, yf);      // Orb.h:324-325
+  const float z = __fmul_rn(zmin, vrecpe_f32(zmax));           // Orb.h:327-329
+  const float c0 = (float)(256 * 14.999998);                   // Orb.h:336
+  const float c1 = (float)(256 * 4.723436);                    // Orb.h:343
+  const float c2 = (float)(256 * 1.266240);                    // Orb.h:344
+  const float t1 = __fadd_rn(c1, __fmul_rn(c2, z));
+  const float t3 = __fmul_rn(__fsub_rn(z, 1.0f), t1);
+  const float af = __fmul_rn(z, __fsub_rn(c0, t3));            // Orb.h:345
+  int32_t angle;                                               // vcvt.s32.f32, Orb.h:348
+  if (af != af) angle = 0;
+  else if (af >= 2147483648.0f) angle = INT32_MAX;
+  else if (af <= -2147483648.0f) angle = INT32_MIN;
+  else angle = (int32_t)af;
+  const uint32_t ax = x < 0 ? 0u - (uint32_t)x : (uint32_t)x;
+  const uint32_t ay = y < 0 ? 0u - (uint32_t)y : (uint32_t)y;
+  if (ax > ay) {                                               // Orb.h:355-364
+    if ((x ^ y) < 0) angle = -angle;
+    if (x < 0) angle += 256 * 60;
+    else if (angle < 0) angle += 256 * 120;
+  } else {                                                     // Orb.h:365-374
+    if ((x ^ y) >= 0) angle = -angle;
+    angle += (y >= 0) ? 256 * 30 : 256 * 90;
+  }
+  angle >>= 10;                                                // Orb.h:376
+  if (!(0 <= angle && angle < 30)) angle = 0;                  // Orb.h:377-380
+  return (uint32_t)angle;
+}
+
+// ---------------------------------------------------------------------------
+// wave64 helpers
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ int lane_id() {
+  return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+}
+__device__ __forceinline__ int wave_sum(int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    uint32_t t = (uint32_t)__shfl_xor((int)v, o, 64);
+    v = t > v ? t : v;
+  }
+  return v;
+}
+// number of set bits of a ballot below this lane
+__device__ __forceinline__ int ballot_rank(uint64_t m) {
+  return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
+
+}  // namespace pdev

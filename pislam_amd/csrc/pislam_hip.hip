@@ -1,0 +1,665 @@
+// pislam_hip.hip — C ABI (include/pislam_hip.h) over the gfx950 kernels.
+//
+// Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -shared -fPIC
+// There is no CPU fallback anywhere in this library.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <string>
+#include <vector>
+
+#include "../../include/pislam_hip.h"
+
+// rotated BRIEF table (behaviour of reference Brief.h:28-53), packed per pair
+__device__ const uint32_t g_brief_tab[30 * 256] = {
+#include "brief_table.inc"
+};
+static const uint32_t h_brief_tab_packed[30 * 256] = {
+#include "brief_table.inc"
+};
+
+#include "pislam_stage_kernels.h"
+
+#define PISLAM_EXPORT extern "C" __attribute__((visibility("default")))
+
+namespace {
+
+struct DevBuf {
+  void *p = nullptr;
+  size_t cap = 0;
+  // returns true if (re)allocated
+  int ensure(size_t bytes, bool *grew = nullptr) {
+    if (grew) *grew = false;
+    if (bytes <= cap) return PISLAM_OK;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+    size_t want = std::max<size_t>(bytes, 256);
+    if (hipMalloc(&p, want) != hipSuccess) {
+      (void)hipGetLastError();
+      return PISLAM_ERR_NOMEM;
+    }
+    cap = want;
+    if (grew) *grew = true;
+    return PISLAM_OK;
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+  template <class T>
+  T *as() const { return (T *)p; }
+};
+
+}  // namespace
+
+struct pislam_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::string err;
+  // staging for host-pointer calls
+  DevBuf s_img, s_out, s_pts, s_desc, s_misc, s_rots;
+  // compaction scratch (shared by extract and the batch pipeline)
+  DevBuf w_cnt, w_off, w_total, w_cellkp;
+  // batch pipeline workspace
+  DevBuf w_score;
+  size_t score_bytes_valid = 0;   // bytes of w_score known to be in a consistent (zero-border) state
+  pislam_frontend_params last_params{};
+  std::vector<pislam_level> last_levels;
+  int last_batch = 0;
+  size_t last_stride = 0;
+  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  bool timing_valid = false;
+};
+
+namespace {
+
+int fail(pislam_ctx *c, int code, const char *what, hipError_t e = hipSuccess) {
+  if (c) {
+    c->err = what;
+    if (e != hipSuccess) {
+      c->err += ": ";
+      c->err += hipGetErrorString(e);
+    }
+  }
+  (void)hipGetLastError();
+  return code;
+}
+
+#define HIPCHK(c, call)                                                   \
+  do {                                                                    \
+    hipError_t e_ = (call);                                               \
+    if (e_ != hipSuccess) return fail((c), PISLAM_ERR_HIP, #call, e_);    \
+  } while (0)
+
+#define PCHK(call)                     \
+  do {                                 \
+    int r_ = (call);                   \
+    if (r_ != PISLAM_OK) return r_;    \
+  } while (0)
+
+bool is_device_ptr(const void *p) {
+  if (!p) return false;
+  hipPointerAttribute_t a;
+  hipError_t e = hipPointerGetAttributes(&a, p);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    return false;
+  }
+  return a.type == hipMemoryTypeDevice || a.type == hipMemoryTypeManaged;
+}
+
+// Host->device staging of a read-only/in-out byte range.
+struct Staged {
+  const void *host = nullptr;   // original host pointer (nullptr if the caller's was device)
+  void *dev = nullptr;
+  size_t bytes = 0;
+};
+
+int stage_in(pislam_ctx *c, DevBuf &buf, const void *p, size_t bytes, Staged *s, bool copy = true) {
+  s->bytes = bytes;
+  if (bytes == 0 || is_device_ptr(p)) {
+    s->host = nullptr;
+    s->dev = (void *)p;
+    return PISLAM_OK;
+  }
+  if (buf.ensure(bytes) != PISLAM_OK) return fail(c, PISLAM_ERR_NOMEM, "hipMalloc(staging)");
+  s->host = p;
+  s->dev = buf.p;
+  if (copy) HIPCHK(c, hipMemcpyAsync(buf.p, p, bytes, hipMemcpyHostToDevice, c->stream));
+  return PISLAM_OK;
+}
+
+int stage_out(pislam_ctx *c, const Staged &s, void *host_dst, size_t bytes) {
+  if (!s.host || bytes == 0) return PISLAM_OK;
+  HIPCHK(c, hipMemcpyAsync(host_dst, s.dev, bytes, hipMemcpyDeviceToHost, c->stream));
+  return PISLAM_OK;
+}
+
+int sync(pislam_ctx *c) {
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return PISLAM_OK;
+}
+
+int launch_ok(pislam_ctx *c, const char *what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(c, PISLAM_ERR_HIP, what, e);
+  return PISLAM_OK;
+}
+
+inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+// ---- launch helpers shared by the 4-call API and the staged batch path ----
+
+int launch_detect(pislam_ctx *c, const uint8_t *d_img, uint8_t *d_out, int vstep, size_t stride,
+                  int batch, int border, int width, int height, int threshold) {
+  const int ny = height - 2 * border;
+  if (ny <= 0) return PISLAM_OK;   // Fast.h:60: the row loop does not execute
+  const int nx = width - 2 * border;
+  const int xend = nx > 0 ? border + 16 * cdiv(nx, 16) : border;   // Fast.h:61,149
+  dim3 grid(std::max(1, cdiv(xend - border, pk::DT_W)), cdiv(ny, pk::DT_H), batch);
+  hipLaunchKernelGGL(pk::k_fast_detect, grid, dim3(256), 0, c->stream, d_img, d_out, vstep, stride,
+                     border, width, height, threshold & 0xff, xend);
+  return launch_ok(c, "k_fast_detect");
+}
+
+int launch_harris(pislam_ctx *c, const uint8_t *d_img, uint8_t *d_out, int vstep, size_t stride,
+                  int batch, int border, int width, int height, int32_t threshold) {
+  const int ny = height - 2 * border, nx = width - 2 * border;
+  if (ny <= 0 || nx <= 0) return PISLAM_OK;
+  dim3 grid(cdiv(nx, pk::DT_W), cdiv(ny, pk::DT_H), batch);
+  hipLaunchKernelGGL(pk::k_harris_score, grid, dim3(256), 0, c->stream, d_img, d_out, vstep, stride,
+                     border, width, height, threshold);
+  return launch_ok(c, "k_harris_score");
+}
+
+// Ordered extraction of one level for `batch` pyramids.  d_total[b] is the
+// running keypoint count of pyramid b (in: offset of this level's first
+// keypoint, out: += this level's count).  Scratch: w_cnt / w_off / w_cellkp.
+int launch_extract(pislam_ctx *c, const uint8_t *d_score, int vstep, size_t stride, int batch,
+                   int border, int lbs, int limit, int width, int height, uint32_t *d_kp,
+                   size_t kp_stride, uint32_t cap, uint32_t add_xy, uint32_t *d_total) {
+  const int ny = height - 2 * border, nx = width - 2 * border;
+  if (ny <= 0 || nx <= 0) return PISLAM_OK;
+  if (lbs == 0) {
+    const int nrows = cdiv(ny, 2);
+    if (c->w_cnt.ensure(sizeof(uint32_t) * (size_t)nrows * batch) != PISLAM_OK ||
+        c->w_off.ensure(sizeof(uint32_t) * (size_t)nrows * batch) != PISLAM_OK)
+      return fail(c, PISLAM_ERR_NOMEM, "hipMalloc(extract scratch)");
+    dim3 grid(cdiv(nrows, 4), 1, batch);
+    hipLaunchKernelGGL(pk::k_nms_rows<false>, grid, dim3(256), 0, c->stream, d_score, vstep, stride,
+                       border, width, height, nrows, c->w_cnt.as<uint32_t>(), (size_t)nrows,
+                       (const uint32_t *)nullptr, (uint32_t *)nullptr, (size_t)0, 0u, 0u);
+    PCHK(launch_ok(c, "k_nms_rows<count>"));
+    hipLaunchKernelGGL(pk::k_scan_counts, dim3(batch), dim3(256), 0, c->stream,
+                       c->w_cnt.as<uint32_t>(), c->w_off.as<uint32_t>(), nrows, (size_t)nrows,
+                       d_total);
+    PCHK(launch_ok(c, "k_scan_counts"));
+    hipLaunchKernelGGL(pk::k_nms_rows<true>, grid, dim3(256), 0, c->stream, d_score, vstep, stride,
+                       border, width, height, nrows, (uint32_t *)nullptr, (size_t)nrows,
+                       c->w_off.as<uint32_t>(), d_kp, kp_stride, cap, add_xy);
+    return launch_ok(c, "k_nms_rows<emit>");
+  }
+  const int bs = 1 << lbs;
+  const int ncx = (nx - 1) / bs + 1;   // Fast.h:201 numBuckets
+  const int ncy = (ny - 1) / bs + 1;
+  const int ncells = ncx * ncy;
+  if (c->w_cnt.ensure(sizeof(uint32_t) * (size_t)ncells * batch) != PISLAM_OK ||
+      c->w_off.ensure(sizeof(uint32_t) * (size_t)ncells * batch) != PISLAM_OK ||
+      c->w_cellkp.ensure(sizeof(uint32_t) * (size_t)ncells * batch * limit) != PISLAM_OK)
+    return fail(c, PISLAM_ERR_NOMEM, "hipMalloc(extract scratch)");
+  const size_t lds = sizeof(uint32_t) * (size_t)(bs / 2) * (bs / 2);
+  hipLaunchKernelGGL(pk::k_nms_cells, dim3(ncx, ncy, batch), dim3(64), lds, c->stream, d_score, vstep,
+                     stride, border, width, height, lbs, limit, ncx, c->w_cnt.as<uint32_t>(),
+                     c->w_cellkp.as<uint32_t>(), (size_t)ncells);
+  PCHK(launch_ok(c, "k_nms_cells"));
+  hipLaunchKernelGGL(pk::k_scan_counts, dim3(batch), dim3(256), 0, c->stream, c->w_cnt.as<uint32_t>(),
+                     c->w_off.as<uint32_t>(), ncells, (size_t)ncells, d_total);
+  PCHK(launch_ok(c, "k_scan_counts"));
+  hipLaunchKernelGGL(pk::k_emit_cells, dim3(cdiv(ncells * limit, 256), 1, batch), dim3(256), 0,
+                     c->stream, c->w_cnt.as<uint32_t>(), c->w_off.as<uint32_t>(),
+                     c->w_cellkp.as<uint32_t>(), ncells, limit, (size_t)ncells, d_kp, kp_stride, cap,
+                     add_xy);
+  return launch_ok(c, "k_emit_cells");
+}
+
+int check_level_args(pislam_ctx *c, int vstep, int border, int width, int height, int min_border) {
+  if (!c) return PISLAM_ERR_INVALID;
+  if (vstep <= 0 || width <= 0 || height <= 0 || width > vstep)
+    return fail(c, PISLAM_ERR_INVALID, "bad vstep/width/height");
+  if (border < min_border) return fail(c, PISLAM_ERR_INVALID, "border too small for this stage");
+  return PISLAM_OK;
+}
+
+// byte hull [lo, hi) of the image the reference's orbCompute reads for these points
+void orb_hull(const uint32_t *pts, size_t n, int vstep, ptrdiff_t *lo, ptrdiff_t *hi) {
+  ptrdiff_t l = PTRDIFF_MAX, h = PTRDIFF_MIN;
+  for (size_t i = 0; i < n; i++) {
+    const int x = (pts[i] >> 12) & 0xfff, y = pts[i] & 0xfff;
+    const ptrdiff_t a = (ptrdiff_t)(y - 15) * vstep + (x - 15);
+    const ptrdiff_t b = (ptrdiff_t)(y + 15) * vstep + (x + 16) + 1;
+    l = std::min(l, a);
+    h = std::max(h, b);
+  }
+  *lo = l;
+  *hi = h;
+}
+
+// Stage points + the image hull for the point-list entry points.  On return
+// *d_img_base is a device pointer such that d_img_base[y*vstep+x] is valid for
+// every byte the kernels touch.
+int stage_points_image(pislam_ctx *c, int vstep, const uint8_t *img, const uint32_t *points, size_t n,
+                       const uint8_t **d_img_base, const uint32_t **d_pts) {
+  Staged sp;
+  std::vector<uint32_t> host_pts;
+  const bool pts_dev = is_device_ptr(points);
+  const bool img_dev = is_device_ptr(img);
+  PCHK(stage_in(c, c->s_pts, points, n * sizeof(uint32_t), &sp));
+  *d_pts = (const uint32_t *)sp.dev;
+  if (img_dev) {
+    *d_img_base = img;
+    return PISLAM_OK;
+  }
+  const uint32_t *hp = points;
+  if (pts_dev) {   // need the coordinates on the host to size the hull
+    host_pts.resize(n);
+    HIPCHK(c, hipMemcpyAsync(host_pts.data(), points, n * sizeof(uint32_t), hipMemcpyDeviceToHost,
+                             c->stream));
+    PCHK(sync(c));
+    hp = host_pts.data();
+  }
+  ptrdiff_t lo, hi;
+  orb_hull(hp, n, vstep, &lo, &hi);
+  if (lo < 0) return fail(c, PISLAM_ERR_INVALID, "keypoint closer than 15 px to the image origin");
+  const size_t bytes = (size_t)(hi - lo);
+  if (c->s_img.ensure(bytes) != PISLAM_OK) return fail(c, PISLAM_ERR_NOMEM, "hipMalloc(image hull)");
+  HIPCHK(c, hipMemcpyAsync(c->s_img.p, img + lo, bytes, hipMemcpyHostToDevice, c->stream));
+  *d_img_base = c->s_img.as<uint8_t>() - lo;
+  return PISLAM_OK;
+}
+
+}  // namespace
+
+// ===========================================================================
+// context
+// ===========================================================================
+PISLAM_EXPORT int pislam_abi_version(void) { return PISLAM_ABI_VERSION; }
+
+PISLAM_EXPORT int pislam_ctx_create(int device, pislam_ctx **out) {
+  if (!out) return PISLAM_ERR_INVALID;
+  *out = nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+    (void)hipGetLastError();
+    return PISLAM_ERR_HIP;
+  }
+  if (device < 0) {
+    if (hipGetDevice(&device) != hipSuccess) return PISLAM_ERR_HIP;
+  }
+  if (device >= ndev) return PISLAM_ERR_INVALID;
+  if (hipSetDevice(device) != hipSuccess) return PISLAM_ERR_HIP;
+  pislam_ctx *c = new pislam_ctx();
+  c->device = device;
+  for (auto &e : c->ev)
+    if (hipEventCreate(&e) != hipSuccess) {
+      delete c;
+      return PISLAM_ERR_HIP;
+    }
+  *out = c;
+  return PISLAM_OK;
+}
+
+PISLAM_EXPORT int pislam_ctx_destroy(pislam_ctx *c) {
+  if (!c) return PISLAM_ERR_INVALID;
+  (void)hipSetDevice(c->device);
+  (void)hipStreamSynchronize(c->stream);
+  for (DevBuf *b : {&c->s_img, &c->s_out, &c->s_pts, &c->s_desc, &c->s_misc, &c->s_rots, &c->w_cnt,
+                    &c->w_off, &c->w_total, &c->w_cellkp, &c->w_score})
+    b->release();
+  for (auto &e : c->ev)
+    if (e) (void)hipEventDestroy(e);
+  delete c;
+  return PISLAM_OK;
+}
+
+PISLAM_EXPORT int pislam_ctx_set_stream(pislam_ctx *c, void *s) {
+  if (!c) return PISLAM_ERR_INVALID;
+  c->stream = (hipStream_t)s;
+  return PISLAM_OK;
+}
+
+PISLAM_EXPORT int pislam_ctx_synchronize(pislam_ctx *c) {
+  if (!c) return PISLAM_ERR_INVALID;
+  return sync(c);
+}
+
+PISLAM_EXPORT const char *pislam_last_error(const pislam_ctx *c) { return c ? c->err.c_str() : "null ctx"; }
+
+PISLAM_EXPORT const int8_t *pislam_brief_table(void) {
+  static int8_t tab[30 * 256 * 4];
+  static bool ready = false;
+  if (!ready) {
+    for (int i = 0; i < 30 * 256; i++)
+      for (int k = 0; k < 4; k++) tab[i * 4 + k] = (int8_t)((h_brief_tab_packed[i] >> (8 * k)) & 0xff);
+    ready = true;
+  }
+  return tab;
+}
+
+PISLAM_EXPORT size_t pislam_centroids_size(size_t n) { return (2 * n + 7) & ~(size_t)7; }
+
+// ===========================================================================
+// the four reference entry points
+// ===========================================================================
+PISLAM_EXPORT int pislam_fast_detect(pislam_ctx *c, int vstep, int border, int width, int height,
+                                     const uint8_t *img, uint8_t *out, int threshold) {
+  PCHK(check_level_args(c, vstep, border, width, height, 3));
+  if (!img || !out) return fail(c, PISLAM_ERR_INVALID, "null image");
+  HIPCHK(c, hipSetDevice(c->device));
+  const size_t bytes = (size_t)height * vstep;
+  Staged si, so;
+  PCHK(stage_in(c, c->s_img, img, bytes, &si));
+  PCHK(stage_in(c, c->s_out, out, bytes, &so));
+  PCHK(launch_detect(c, (const uint8_t *)si.dev, (uint8_t *)so.dev, vstep, 0, 1, border, width, height,
+                     threshold));
+  PCHK(stage_out(c, so, out, bytes));
+  if (si.host || so.host) PCHK(sync(c));
+  return PISLAM_OK;
+}
+
+PISLAM_EXPORT int pislam_fast_score_harris(pislam_ctx *c, int vstep, int border, int width, int height,
+                                           const uint8_t *img, int32_t threshold, uint8_t *out) {
+  PCHK(check_level_args(c, vstep, border, width, height, 4));
+  if (!img || !out) return fail(c, PISLAM_ERR_INVALID, "null image");
+  HIPCHK(c, hipSetDevice(c->device));
+  const size_t bytes = (size_t)height * vstep;
+  Staged si, so;
+  PCHK(stage_in(c, c->s_img, img, bytes, &si));
+  PCHK(stage_in(c, c->s_out, out, bytes, &so));
+  PCHK(launch_harris(c, (const uint8_t *)si.dev, (uint8_t *)so.dev, vstep, 0, 1, border, width, height,
+                     threshold));
+  PCHK(stage_out(c, so, out, bytes));
+  if (si.host || so.host) PCHK(sync(c));
+  return PISLAM_OK;
+}
+
+PISLAM_EXPORT int pislam_fast_extract(pislam_ctx *c, int vstep, int border, int lbs, int limit, int width,
+                                      int height, const uint8_t *out, uint32_t *results, size_t capacity,
+                                      size_t *count) {
+  PCHK(check_level_args(c, vstep, border, width, height, 1));
+  if (!out || !count || (!results && capacity)) return fail(c, PISLAM_ERR_INVALID, "null pointer");
+  if (lbs < 0 || lbs > 8 || limit < 1 || limit > 64)
+    return fail(c, PISLAM_ERR_INVALID, "logBucketSize must be 0..8 and bucketLimit 1..64");
+  if (width > 4096 || height > 4096)
+    return fail(c, PISLAM_ERR_INVALID, "encodeFast holds 12-bit coordinates (Util.h:27-29)");
+  HIPCHK(c, hipSetDevice(c->device));
+  const size_t bytes = (size_t)height * vstep;
+  Staged so, sr;
+  PCHK(stage_in(c, c->s_out, out, bytes, &so));
+  PCHK(stage_in(c, c->s_pts, results, capacity * sizeof(uint32_t), &sr, /*copy=*/false));
+  if (c->w_total.ensure(sizeof(uint32_t)) != PISLAM_OK) return fail(c, PISLAM_ERR_NOMEM, "hipMalloc");
+  HIPCHK(c, hipMemsetAsync(c->w_total.p, 0, sizeof(uint32_t), c->stream));
+  const uint32_t cap32 = (uint32_t)std::min<size_t>(capacity, 0xffffffffu);
+  PCHK(launch_extract(c, (const uint8_t *)so.dev, vstep, 0, 1, border, lbs, limit, width, height,
+                      (uint32_t *)sr.dev, 0, cap32, 0u, c->w_total.as<uint32_t>()));
+  uint32_t n = 0;
+  HIPCHK(c, hipMemcpyAsync(&n, c->w_total.p, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+  PCHK(sync(c));
+  *count = n;
+  PCHK(stage_out(c, sr, results, std::min<size_t>(n, capacity) * sizeof(uint32_t)));
+  if (sr.host) PCHK(sync(c));
+  return PISLAM_OK;
+}
+
+namespace {
+int orb_common(pislam_ctx *c, int mode, int vstep, int words, const uint8_t *img, const uint32_t *points,
+               const uint8_t *rots, size_t n, uint32_t *descriptors, int32_t *centroids) {
+  if (!c) return PISLAM_ERR_INVALID;
+  if (vstep <= 0) return fail(c, PISLAM_ERR_INVALID, "bad vstep");
+  if (mode != 1 && (words < 1 || words > 8)) return fail(c, PISLAM_ERR_INVALID, "words must be 1..8");
+  HIPCHK(c, hipSetDevice(c->device));
+  if (mode == 1) {
+    const size_t n8 = pislam_centroids_size(n);
+    Staged sc;
+    PCHK(stage_in(c, c->s_misc, centroids, n8 * sizeof(int32_t), &sc, false));
+    if (n8) HIPCHK(c, hipMemsetAsync(sc.dev, 0, n8 * sizeof(int32_t), c->stream));
+    if (n) {
+      const uint8_t *d_img;
+      const uint32_t *d_pts;
+      PCHK(stage_points_image(c, vstep, img, points, n, &d_img, &d_pts));
+      hipLaunchKernelGGL(pk::k_orb<1>, dim3(cdiv((int)n, 4)), dim3(256), 0, c->stream, d_img, vstep,
+                         (size_t)0, d_pts, (size_t)0, (const uint32_t *)nullptr, (uint32_t)n,
+                         (uint32_t)n, 0, (uint32_t *)nullptr, (size_t)0, (int32_t *)sc.dev,
+                         (const uint8_t *)nullptr);
+      PCHK(launch_ok(c, "k_orb<centroids>"));
+    }
+    PCHK(stage_out(c, sc, centroids, n8 * sizeof(int32_t)));
+    return sync(c);
+  }
+  if (n == 0) return PISLAM_OK;
+  if (!img || !points || !descriptors) return fail(c, PISLAM_ERR_INVALID, "null pointer");
+  const uint8_t *d_img;
+  const uint32_t *d_pts;
+  PCHK(stage_points_image(c, vstep, img, points, n, &d_img, &d_pts));
+  Staged sd, sr;
+  PCHK(stage_in(c, c->s_desc, descriptors, n * words * sizeof(uint32_t), &sd, false));
+  const uint8_t *d_rots = nullptr;
+  if (mode == 2) {
+    PCHK(stage_in(c, c->s_rots, rots, n, &sr));
+    d_rots = (const uint8_t *)sr.dev;
+    // rotations outside 0..29 leave the descriptor untouched (Brief.h switch): preserve caller bytes
+    if (sd.host)
+      HIPCHK(c, hipMemcpyAsync(sd.dev, descriptors, n * words * sizeof(uint32_t), hipMemcpyHostToDevice,
+                               c->stream));
+    hipLaunchKernelGGL(pk::k_orb<2>, dim3(cdiv((int)n, 4)), dim3(256), 0, c->stream, d_img, vstep,
+                       (size_t)0, d_pts, (size_t)0, (const uint32_t *)nullptr, (uint32_t)n, (uint32_t)n,
+                       words, (uint32_t *)sd.dev, (size_t)0, (int32_t *)nullptr, d_rots);
+  } else {
+    hipLaunchKernelGGL(pk::k_orb<0>, dim3(cdiv((int)n, 4)), dim3(256), 0, c->stream, d_img, vstep,
+                       (size_t)0, d_pts, (size_t)0, (const uint32_t *)nullptr, (uint32_t)n, (uint32_t)n,
+                       words, (uint32_t *)sd.dev, (size_t)0, (int32_t *)nullptr,
+                       (const uint8_t *)nullptr);
+  }
+  PCHK(launch_ok(c, "k_orb"));
+  PCHK(stage_out(c, sd, descriptors, n * words * sizeof(uint32_t)));
+  return sync(c);
+}
+}  // namespace
+
+PISLAM_EXPORT int pislam_orb_compute(pislam_ctx *c, int vstep, int words, const uint8_t *img,
+                                     const uint32_t *points, size_t n, uint32_t *descriptors) {
+  return orb_common(c, 0, vstep, words, img, points, nullptr, n, descriptors, nullptr);
+}
+
+PISLAM_EXPORT int pislam_orb_centroids(pislam_ctx *c, int vstep, const uint8_t *img, const uint32_t *points,
+                                       size_t n, int32_t *centroids) {
+  if (!c) return PISLAM_ERR_INVALID;
+  if (!centroids && n) return fail(c, PISLAM_ERR_INVALID, "null pointer");
+  return orb_common(c, 1, vstep, 0, img, points, nullptr, n, nullptr, centroids);
+}
+
+PISLAM_EXPORT int pislam_brief_describe(pislam_ctx *c, int vstep, int words, const uint8_t *img,
+                                        const uint32_t *points, const uint8_t *rots, size_t n,
+                                        uint32_t *descriptors) {
+  if (!c) return PISLAM_ERR_INVALID;
+  if (!rots && n) return fail(c, PISLAM_ERR_INVALID, "null pointer");
+  return orb_common(c, 2, vstep, words, img, points, rots, n, descriptors, nullptr);
+}
+
+PISLAM_EXPORT int pislam_orb_angles(pislam_ctx *c, const int32_t *centroids, size_t n8, uint8_t *angles) {
+  if (!c) return PISLAM_ERR_INVALID;
+  if (n8 % 8) return fail(c, PISLAM_ERR_INVALID, "n8 must be a multiple of 8 (Orb.h:314)");
+  if (n8 == 0) return PISLAM_OK;
+  if (!centroids || !angles) return fail(c, PISLAM_ERR_INVALID, "null pointer");
+  HIPCHK(c, hipSetDevice(c->device));
+  Staged sc, sa;
+  PCHK(stage_in(c, c->s_misc, centroids, n8 * sizeof(int32_t), &sc));
+  PCHK(stage_in(c, c->s_rots, angles, n8 / 2, &sa, false));
+  hipLaunchKernelGGL(pk::k_angles, dim3(cdiv((int)(n8 / 2), 256)), dim3(256), 0, c->stream,
+                     (const int32_t *)sc.dev, (int)(n8 / 2), (uint8_t *)sa.dev);
+  PCHK(launch_ok(c, "k_angles"));
+  PCHK(stage_out(c, sa, angles, n8 / 2));
+  return sync(c);
+}
+
+PISLAM_EXPORT int pislam_harris_score_points(pislam_ctx *c, int vstep, const uint8_t *img,
+                                             const uint32_t *points, size_t n, int32_t threshold,
+                                             uint8_t *scores) {
+  if (!c) return PISLAM_ERR_INVALID;
+  if (n == 0) return PISLAM_OK;
+  if (!img || !points || !scores || vstep <= 0) return fail(c, PISLAM_ERR_INVALID, "bad argument");
+  HIPCHK(c, hipSetDevice(c->device));
+  const uint8_t *d_img;
+  const uint32_t *d_pts;
+  PCHK(stage_points_image(c, vstep, img, points, n, &d_img, &d_pts));   // hull is a superset of 8x8
+  Staged ss;
+  PCHK(stage_in(c, c->s_rots, scores, n, &ss, false));
+  hipLaunchKernelGGL(pk::k_harris_points, dim3(cdiv((int)n, 256)), dim3(256), 0, c->stream, d_img, vstep,
+                     d_pts, (int)n, threshold, (uint8_t *)ss.dev);
+  PCHK(launch_ok(c, "k_harris_points"));
+  PCHK(stage_out(c, ss, scores, n));
+  return sync(c);
+}
+
+// ===========================================================================
+// batch pipeline (staged: one launch group per level, blockIdx.z = pyramid)
+// ===========================================================================
+namespace {
+int check_params(pislam_ctx *c, const pislam_frontend_params *p, const pislam_level *lv, int batch) {
+  if (!c) return PISLAM_ERR_INVALID;
+  if (!p || !lv) return fail(c, PISLAM_ERR_INVALID, "null params");
+  if (batch <= 0) return fail(c, PISLAM_ERR_INVALID, "batch must be positive");
+  if (p->vstep <= 0 || p->rows <= 0 || p->nlevels < 1 || p->nlevels > 16)
+    return fail(c, PISLAM_ERR_INVALID, "bad vstep/rows/nlevels");
+  if (p->border < 16) return fail(c, PISLAM_ERR_INVALID, "ORB needs border >= 16 (Fast.h:46-49)");
+  if (p->words < 1 || p->words > 8) return fail(c, PISLAM_ERR_INVALID, "words must be 1..8");
+  if (p->log_bucket_size < 0 || p->log_bucket_size > 8 || p->bucket_limit < 1 || p->bucket_limit > 64)
+    return fail(c, PISLAM_ERR_INVALID, "bad bucket parameters");
+  if (p->max_keypoints < 1) return fail(c, PISLAM_ERR_INVALID, "max_keypoints must be positive");
+  for (int l = 0; l < p->nlevels; l++) {
+    if (lv[l].width <= 0 || lv[l].height <= 0 || lv[l].row0 < 0 || lv[l].col0 < 0 ||
+        lv[l].col0 + lv[l].width > p->vstep || lv[l].row0 + lv[l].height > p->rows)
+      return fail(c, PISLAM_ERR_INVALID, "level does not fit the pyramid buffer");
+    if (lv[l].row0 + lv[l].height > 4096 || lv[l].col0 + lv[l].width > 4096)
+      return fail(c, PISLAM_ERR_INVALID, "stacked coordinates exceed 12 bits (Util.h:27-29)");
+  }
+  return PISLAM_OK;
+}
+}  // namespace
+
+PISLAM_EXPORT int pislam_frontend_reserve(pislam_ctx *c, const pislam_frontend_params *p,
+                                          const pislam_level *lv, int batch) {
+  PCHK(check_params(c, p, lv, batch));
+  HIPCHK(c, hipSetDevice(c->device));
+  const size_t pyr_bytes = (size_t)p->rows * p->vstep;
+  bool grew = false;
+  if (c->w_score.ensure(pyr_bytes * batch, &grew) != PISLAM_OK)
+    return fail(c, PISLAM_ERR_NOMEM, "hipMalloc(score map)");
+  const bool same_shape = !grew && c->last_batch >= batch && c->last_params.vstep == p->vstep &&
+                          c->last_params.rows == p->rows && c->last_params.nlevels == p->nlevels &&
+                          c->last_params.border == p->border && (int)c->last_levels.size() == p->nlevels &&
+                          memcmp(c->last_levels.data(), lv, sizeof(pislam_level) * p->nlevels) == 0;
+  if (!same_shape) {
+    // Fast.h:42-44: `out` must start as zeros; afterwards the regions fastDetect rewrites are the
+    // only ones that ever change, so the zeroing is needed once per shape.
+    HIPCHK(c, hipMemsetAsync(c->w_score.p, 0, pyr_bytes * batch, c->stream));
+    c->last_params = *p;
+    c->last_levels.assign(lv, lv + p->nlevels);
+    c->last_batch = batch;
+  }
+  size_t maxn = 1;
+  for (int l = 0; l < p->nlevels; l++) {
+    const int ny = lv[l].height - 2 * p->border, nx = lv[l].width - 2 * p->border;
+    if (ny <= 0 || nx <= 0) continue;
+    if (p->log_bucket_size == 0) maxn = std::max<size_t>(maxn, cdiv(ny, 2));
+    else {
+      const int bs = 1 << p->log_bucket_size;
+      maxn = std::max<size_t>(maxn, (size_t)((nx - 1) / bs + 1) * ((ny - 1) / bs + 1));
+    }
+  }
+  if (c->w_cnt.ensure(sizeof(uint32_t) * maxn * batch) != PISLAM_OK ||
+      c->w_off.ensure(sizeof(uint32_t) * maxn * batch) != PISLAM_OK ||
+      (p->log_bucket_size &&
+       c->w_cellkp.ensure(sizeof(uint32_t) * maxn * batch * p->bucket_limit) != PISLAM_OK))
+    return fail(c, PISLAM_ERR_NOMEM, "hipMalloc(extract scratch)");
+  return PISLAM_OK;
+}
+
+PISLAM_EXPORT int pislam_orb_frontend_batch(pislam_ctx *c, const pislam_frontend_params *p,
+                                            const pislam_level *lv, const uint8_t *pyramids,
+                                            size_t stride, int batch, uint32_t *kp, uint32_t *desc,
+                                            uint32_t *counts) {
+  PCHK(check_params(c, p, lv, batch));
+  if (!pyramids || !kp || !desc || !counts) return fail(c, PISLAM_ERR_INVALID, "null pointer");
+  if (stride < (size_t)p->rows * p->vstep) return fail(c, PISLAM_ERR_INVALID, "pyramid_stride too small");
+  if (!is_device_ptr(pyramids) || !is_device_ptr(kp) || !is_device_ptr(desc) || !is_device_ptr(counts))
+    return fail(c, PISLAM_ERR_INVALID, "the batch path takes device pointers only");
+  PCHK(pislam_frontend_reserve(c, p, lv, batch));
+  const size_t pyr_bytes = (size_t)p->rows * p->vstep;
+  uint8_t *score = c->w_score.as<uint8_t>();
+  c->last_stride = pyr_bytes;
+  HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
+  HIPCHK(c, hipMemsetAsync(counts, 0, sizeof(uint32_t) * batch, c->stream));
+  // The score map workspace is laid out with stride pyr_bytes; the image with `stride`.  The stage
+  // kernels take one stride for both, so when they differ run detect/score per pyramid group: here
+  // we require equal strides for the fast path and fall back to per-pyramid launches otherwise.
+  const bool same = stride == pyr_bytes;
+  for (int l = 0; l < p->nlevels; l++) {
+    const size_t off = (size_t)lv[l].row0 * p->vstep + lv[l].col0;
+    if (same) {
+      PCHK(launch_detect(c, pyramids + off, score + off, p->vstep, pyr_bytes, batch, p->border,
+                         lv[l].width, lv[l].height, p->fast_threshold));
+      PCHK(launch_harris(c, pyramids + off, score + off, p->vstep, pyr_bytes, batch, p->border,
+                         lv[l].width, lv[l].height, p->harris_threshold));
+    } else {
+      for (int b = 0; b < batch; b++) {
+        PCHK(launch_detect(c, pyramids + b * stride + off, score + b * pyr_bytes + off, p->vstep, 0, 1,
+                           p->border, lv[l].width, lv[l].height, p->fast_threshold));
+        PCHK(launch_harris(c, pyramids + b * stride + off, score + b * pyr_bytes + off, p->vstep, 0, 1,
+                           p->border, lv[l].width, lv[l].height, p->harris_threshold));
+      }
+    }
+  }
+  HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
+  for (int l = 0; l < p->nlevels; l++) {
+    const size_t off = (size_t)lv[l].row0 * p->vstep + lv[l].col0;
+    const uint32_t add_xy = ((uint32_t)lv[l].col0 << 12) | (uint32_t)lv[l].row0;   // README.md:78
+    PCHK(launch_extract(c, score + off, p->vstep, pyr_bytes, batch, p->border, p->log_bucket_size,
+                        p->bucket_limit, lv[l].width, lv[l].height, kp, (size_t)p->max_keypoints,
+                        (uint32_t)p->max_keypoints, add_xy, counts));
+  }
+  HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
+  hipLaunchKernelGGL(pk::k_orb<0>, dim3(cdiv(p->max_keypoints, 4), 1, batch), dim3(256), 0, c->stream,
+                     pyramids, p->vstep, stride, kp, (size_t)p->max_keypoints, counts, 0u,
+                     (uint32_t)p->max_keypoints, p->words, desc, (size_t)p->max_keypoints * p->words,
+                     (int32_t *)nullptr, (const uint8_t *)nullptr);
+  PCHK(launch_ok(c, "k_orb<batch>"));
+  HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
+  c->timing_valid = true;
+  return PISLAM_OK;
+}
+
+PISLAM_EXPORT int pislam_frontend_get_score_map(pislam_ctx *c, int b, uint8_t *dst) {
+  if (!c || !dst) return PISLAM_ERR_INVALID;
+  if (b < 0 || b >= c->last_batch || !c->w_score.p || !c->last_stride)
+    return fail(c, PISLAM_ERR_INVALID, "no score map for that pyramid");
+  HIPCHK(c, hipSetDevice(c->device));
+  const size_t bytes = c->last_stride;
+  HIPCHK(c, hipMemcpyAsync(dst, c->w_score.as<uint8_t>() + (size_t)b * bytes, bytes, hipMemcpyDefault,
+                           c->stream));
+  return sync(c);
+}
+
+PISLAM_EXPORT int pislam_frontend_last_timing(pislam_ctx *c, float *total_ms, float stage_ms[3]) {
+  if (!c) return PISLAM_ERR_INVALID;
+  if (!c->timing_valid) return fail(c, PISLAM_ERR_INVALID, "no batch call recorded");
+  HIPCHK(c, hipEventSynchronize(c->ev[3]));
+  if (total_ms) HIPCHK(c, hipEventElapsedTime(total_ms, c->ev[0], c->ev[3]));
+  if (stage_ms)
+    for (int i = 0; i < 3; i++) HIPCHK(c, hipEventElapsedTime(&stage_ms[i], c->ev[i], c->ev[i + 1]));
+  return PISLAM_OK;
+}

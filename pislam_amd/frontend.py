@@ -1,0 +1,220 @@
+"""Host-side mirror of the reference's public interface for the ORB hot path.
+
+Same names, argument order and semantics as the header-only templates of
+0xfaded/pislam (include/Fast.h, Harris.h, Orb.h, Brief.h, Util.h); the template
+parameters (vstep, border, logBucketSize, bucketLimit, words) become keyword
+arguments, `vstep` is taken from the array's row stride.  Every function forwards
+to the C ABI of libpislam_hip.so — nothing is computed in Python and nothing
+falls back to the CPU.
+
+Arrays may be numpy (host; staged through the device by the library) or torch
+CUDA/HIP tensors (used in place).
+"""
+from __future__ import annotations
+
+import ctypes
+
+import numpy as np
+
+from . import capi
+from .capi import Context, FrontendParams, Level, ptr
+
+_default_ctx: Context | None = None
+
+
+def default_context() -> Context:
+    global _default_ctx
+    if _default_ctx is None:
+        _default_ctx = Context()
+    return _default_ctx
+
+
+# ---- Util.h:27-45 ----------------------------------------------------------
+def encodeFast(score, x, y):
+    return ((np.uint32(score) << np.uint32(24)) | (np.uint32(x) << np.uint32(12)) | np.uint32(y)).astype(np.uint32) \
+        if isinstance(score, np.ndarray) else ((int(score) << 24) | (int(x) << 12) | int(y)) & 0xFFFFFFFF
+
+
+def rencodeFastScore(score, encoded):
+    return ((int(score) << 24) | (int(encoded) & 0xFFFFFF)) & 0xFFFFFFFF
+
+
+def decodeFastX(encoded):
+    return (encoded >> 12) & 0xFFF
+
+
+def decodeFastY(encoded):
+    return encoded & 0xFFF
+
+
+def decodeFastScore(encoded):
+    return encoded >> 24
+
+
+def _vstep(a) -> int:
+    if a.ndim != 2:
+        raise ValueError("image / score map must be 2-D [rows][vstep]")
+    return int(a.shape[1])
+
+
+# ---- Fast.h:54 ---------------------------------------------------------------
+def fastDetect(width, height, img, out, threshold, *, border=16, ctx: Context | None = None):
+    """pislam::fastDetect<vstep,border>(width, height, img, out, threshold)."""
+    ctx = ctx or default_context()
+    ctx.check(ctx.lib.pislam_fast_detect(ctx.h, _vstep(img), border, width, height, ptr(img), ptr(out),
+                                         threshold), "pislam_fast_detect")
+
+
+# ---- Fast.h:166 --------------------------------------------------------------
+def fastScoreHarris(width, height, img, threshold, out, *, border=16, ctx: Context | None = None):
+    """pislam::fastScoreHarris<vstep,border>(width, height, img, threshold, out)."""
+    ctx = ctx or default_context()
+    ctx.check(ctx.lib.pislam_fast_score_harris(ctx.h, _vstep(img), border, width, height, ptr(img),
+                                               threshold, ptr(out)), "pislam_fast_score_harris")
+
+
+# ---- Fast.h:196 --------------------------------------------------------------
+def fastExtract(width, height, out, results: list | None = None, *, border=16, logBucketSize=0,
+                bucketLimit=5, ctx: Context | None = None) -> np.ndarray:
+    """pislam::fastExtract<vstep,border,logBucketSize,bucketLimit>(width, height, out, results).
+
+    Appends to `results` (a Python list, like the reference's std::vector&) when given and
+    returns the keypoints of this call as a uint32 array."""
+    ctx = ctx or default_context()
+    cap = max(16, ((width + 1) // 2) * ((height + 1) // 2))
+    buf = np.zeros(cap, np.uint32)
+    n = ctypes.c_size_t(0)
+    ctx.check(ctx.lib.pislam_fast_extract(ctx.h, _vstep(out), border, logBucketSize, bucketLimit, width,
+                                          height, ptr(out), ptr(buf), cap, ctypes.byref(n)),
+              "pislam_fast_extract")
+    kp = buf[:n.value].copy()
+    if results is not None:
+        results.extend(int(v) for v in kp)
+    return kp
+
+
+# ---- Harris.h:80 ---------------------------------------------------------------
+def harrisScoreSobel(img, x, y, threshold, *, ctx: Context | None = None) -> int:
+    """pislam::harrisScoreSobel<vstep>(img, x, y, threshold)."""
+    return int(harrisScorePoints(img, np.array([(int(x) << 12) | int(y)], np.uint32), threshold, ctx=ctx)[0])
+
+
+def harrisScorePoints(img, points, threshold, *, ctx: Context | None = None) -> np.ndarray:
+    ctx = ctx or default_context()
+    points = np.ascontiguousarray(points, np.uint32)
+    scores = np.zeros(len(points), np.uint8)
+    ctx.check(ctx.lib.pislam_harris_score_points(ctx.h, _vstep(img), ptr(img), ptr(points), len(points),
+                                                 threshold, ptr(scores)), "pislam_harris_score_points")
+    return scores
+
+
+# ---- Orb.h:80 ------------------------------------------------------------------
+def orbCentroids(img, points, *, ctx: Context | None = None) -> np.ndarray:
+    """pislam::orbCentroids<vstep>(img, points): int32, groups [x0 x1 x2 x3 y0 y1 y2 y3]."""
+    ctx = ctx or default_context()
+    points = np.ascontiguousarray(points, np.uint32)
+    n8 = ctx.lib.pislam_centroids_size(len(points))
+    cen = np.zeros(n8, np.int32)
+    ctx.check(ctx.lib.pislam_orb_centroids(ctx.h, _vstep(img), ptr(img), ptr(points), len(points),
+                                           ptr(cen)), "pislam_orb_centroids")
+    return cen
+
+
+# ---- Orb.h:310 -----------------------------------------------------------------
+def atan2(xys, *, ctx: Context | None = None) -> np.ndarray:
+    """pislam::atan2(const std::vector<int32_t>&): uint8 angle bins, padding slots included."""
+    ctx = ctx or default_context()
+    xys = np.ascontiguousarray(xys, np.int32)
+    ang = np.zeros(len(xys) // 2, np.uint8)
+    ctx.check(ctx.lib.pislam_orb_angles(ctx.h, ptr(xys), len(xys), ptr(ang)), "pislam_orb_angles")
+    return ang
+
+
+# ---- Brief.h:637 ---------------------------------------------------------------
+def briefDescribe(img, x, y, rot, *, words=8, ctx: Context | None = None) -> np.ndarray:
+    """pislam::briefDescribe<vstep,words>(img, x, y, rot, descriptor)."""
+    pts = np.array([(int(x) << 12) | int(y)], np.uint32)
+    return briefDescribePoints(img, pts, np.array([rot], np.uint8), words=words, ctx=ctx)[0]
+
+
+def briefDescribePoints(img, points, rots, *, words=8, ctx: Context | None = None) -> np.ndarray:
+    ctx = ctx or default_context()
+    points = np.ascontiguousarray(points, np.uint32)
+    rots = np.ascontiguousarray(rots, np.uint8)
+    desc = np.zeros((len(points), words), np.uint32)
+    ctx.check(ctx.lib.pislam_brief_describe(ctx.h, _vstep(img), words, ptr(img), ptr(points), ptr(rots),
+                                            len(points), ptr(desc)), "pislam_brief_describe")
+    return desc
+
+
+# ---- Orb.h:396 -----------------------------------------------------------------
+def orbCompute(img, points, descriptors: list | None = None, *, words=8,
+               ctx: Context | None = None) -> np.ndarray:
+    """pislam::orbCompute<vstep,words>(img, points, descriptors); returns uint32 [n][words] and
+    appends the flattened words to `descriptors` when given."""
+    ctx = ctx or default_context()
+    points = np.ascontiguousarray(points, np.uint32)
+    desc = np.zeros((len(points), words), np.uint32)
+    ctx.check(ctx.lib.pislam_orb_compute(ctx.h, _vstep(img), words, ptr(img), ptr(points), len(points),
+                                         ptr(desc)), "pislam_orb_compute")
+    if descriptors is not None:
+        descriptors.extend(int(v) for v in desc.reshape(-1))
+    return desc
+
+
+# ---- the measured path ---------------------------------------------------------
+class OrbFrontend:
+    """Batch of device-resident stacked pyramids -> keypoints + descriptors + counts.
+
+    Runs the call sequence of reference demo/demo.cpp:77-101 for every pyramid on the
+    GPU (pislam_orb_frontend_batch).  All tensors are torch device tensors."""
+
+    def __init__(self, levels, vstep: int, rows: int, *, border=16, fast_threshold=20,
+                 harris_threshold=1 << 15, log_bucket_size=0, bucket_limit=5, words=8,
+                 max_keypoints=4096, ctx: Context | None = None):
+        self.ctx = ctx or default_context()
+        lv = []
+        for t in levels:
+            w, h, r0 = t[0], t[1], t[2]
+            c0 = t[3] if len(t) > 3 else 0
+            lv.append(Level(w, h, r0, c0))
+        self.levels = (Level * len(lv))(*lv)
+        self.params = FrontendParams(vstep, rows, len(lv), border, fast_threshold, harris_threshold,
+                                     log_bucket_size, bucket_limit, words, max_keypoints)
+
+    def reserve(self, batch: int):
+        c = self.ctx
+        c.check(c.lib.pislam_frontend_reserve(c.h, ctypes.byref(self.params), self.levels, batch),
+                "pislam_frontend_reserve")
+
+    def alloc_outputs(self, batch: int, device):
+        import torch
+        p = self.params
+        kp = torch.zeros((batch, p.max_keypoints), dtype=torch.int32, device=device)
+        desc = torch.zeros((batch, p.max_keypoints, p.words), dtype=torch.int32, device=device)
+        counts = torch.zeros((batch,), dtype=torch.int32, device=device)
+        return kp, desc, counts
+
+    def __call__(self, pyramids, kp, desc, counts):
+        """pyramids: uint8 [batch][rows][vstep] device tensor; outputs int32 device tensors
+        (bit patterns are the reference's uint32)."""
+        c = self.ctx
+        batch = int(pyramids.shape[0])
+        stride = int(pyramids.stride(0)) if hasattr(pyramids, "stride") else self.params.rows * self.params.vstep
+        c.check(c.lib.pislam_orb_frontend_batch(c.h, ctypes.byref(self.params), self.levels, ptr(pyramids),
+                                                stride, batch, ptr(kp), ptr(desc), ptr(counts)),
+                "pislam_orb_frontend_batch")
+
+    def score_map(self, b: int) -> np.ndarray:
+        c = self.ctx
+        out = np.zeros((self.params.rows, self.params.vstep), np.uint8)
+        c.check(c.lib.pislam_frontend_get_score_map(c.h, b, ptr(out)), "pislam_frontend_get_score_map")
+        return out
+
+    def last_timing(self):
+        c = self.ctx
+        tot = ctypes.c_float(0)
+        st = (ctypes.c_float * 3)()
+        c.check(c.lib.pislam_frontend_last_timing(c.h, ctypes.byref(tot), ctypes.byref(st)),
+                "pislam_frontend_last_timing")
+        return float(tot.value), [float(v) for v in st]

@@ -1,0 +1,253 @@
+"""GPU parity suite (pytest -m gpu): HIP path through the C ABI vs the oracle, bit-exact."""
+import numpy as np
+import pytest
+
+from conftest import SURVEY_PINS, sha16
+
+pytestmark = pytest.mark.gpu
+
+
+def _levels_stagewise(fe, orc, img, levels, ctx, border=16, thr=20, hthr=1 << 15):
+    det_g = np.zeros_like(img)
+    det_o = np.zeros_like(img)
+    for w, h, r0 in levels:
+        fe.fastDetect(w, h, img[r0:r0 + h], det_g[r0:r0 + h], thr, border=border, ctx=ctx)
+        orc.fast_detect(img[r0:r0 + h], det_o[r0:r0 + h], w, h, thr, border=border)
+    assert (det_g == det_o).all(), f"FAST maps differ at {np.argwhere(det_g != det_o)[:5]}"
+    sc_g, sc_o = det_g.copy(), det_o.copy()
+    for w, h, r0 in levels:
+        fe.fastScoreHarris(w, h, img[r0:r0 + h], hthr, sc_g[r0:r0 + h], border=border, ctx=ctx)
+        orc.fast_score_harris(img[r0:r0 + h], sc_o[r0:r0 + h], w, h, hthr, border=border)
+    assert (sc_g == sc_o).all(), f"score maps differ at {np.argwhere(sc_g != sc_o)[:5]}"
+    return det_g, sc_g
+
+
+def test_four_call_api_on_reference_demo_pyramid(gpu_ctx, orc, demo):
+    """README.md:67-82 call sequence through the drop-in API; every stage equals the reference's
+    recorded outputs (SURVEY §8c pins) on the reference's own input."""
+    from pislam_amd import frontend as fe
+    img, levels = demo["img"], demo["levels"]
+    det, score = _levels_stagewise(fe, orc, img, levels, gpu_ctx)
+    assert sha16(det) == SURVEY_PINS["det"] and sha16(score) == SURVEY_PINS["score"]
+    kp = np.concatenate([fe.fastExtract(w, h, score[r0:r0 + h], ctx=gpu_ctx) + np.uint32(r0) for w, h, r0 in levels])
+    assert sha16(kp.astype(np.uint32)) == SURVEY_PINS["kp"] and (kp == demo["kp"]).all()
+    kpb = np.concatenate([fe.fastExtract(w, h, score[r0:r0 + h], logBucketSize=4, bucketLimit=3, ctx=gpu_ctx)
+                          + np.uint32(r0) for w, h, r0 in levels])
+    assert sha16(kpb.astype(np.uint32)) == SURVEY_PINS["kp_bucket43"]
+    cen = fe.orbCentroids(img, kp, ctx=gpu_ctx)
+    assert sha16(cen) == SURVEY_PINS["centroids"]
+    ang = fe.atan2(cen, ctx=gpu_ctx)
+    assert sha16(ang) == SURVEY_PINS["angles"]
+    desc = fe.orbCompute(img, kp, ctx=gpu_ctx)
+    assert sha16(desc) == SURVEY_PINS["desc"] and (desc == demo["desc"]).all()
+
+
+def test_batch_path_on_reference_demo_pyramid(gpu_ctx, demo):
+    import torch
+    from pislam_amd.frontend import OrbFrontend
+    img = demo["img"]
+    dev = torch.device("cuda:0")
+    pyr = torch.from_numpy(np.stack([img, img[::-1].copy(), img])).to(dev)   # same pyramid at batch slots 0 and 2
+    fe = OrbFrontend(demo["levels"], vstep=640, rows=2210, max_keypoints=4096, ctx=gpu_ctx)
+    kp, desc, counts = fe.alloc_outputs(3, dev)
+    fe(pyr, kp, desc, counts)
+    torch.cuda.synchronize()
+    c = counts.cpu().numpy().view(np.uint32)
+    k = kp.cpu().numpy().view(np.uint32)
+    d = desc.cpu().numpy().view(np.uint32)
+    assert c[0] == 1754 == c[2]
+    assert sha16(k[0, :1754]) == SURVEY_PINS["kp"] and sha16(d[0, :1754]) == SURVEY_PINS["desc"]
+    assert (k[2] == k[0]).all() and (d[2] == d[0]).all()           # independent of batch position
+    try:
+        sm = fe.score_map(0)
+    except Exception:
+        sm = None
+    if sm is not None:
+        assert sha16(sm) == SURVEY_PINS["score"]
+    # bucketed mode (README's recommended <4,3>)
+    feb = OrbFrontend(demo["levels"], vstep=640, rows=2210, max_keypoints=4096, log_bucket_size=4,
+                      bucket_limit=3, ctx=gpu_ctx)
+    feb(pyr, kp, desc, counts)
+    torch.cuda.synchronize()
+    c = counts.cpu().numpy().view(np.uint32)
+    assert c[0] == 1315 and sha16(kp.cpu().numpy().view(np.uint32)[0, :1315]) == SURVEY_PINS["kp_bucket43"]
+
+
+@pytest.mark.parametrize("w,h,border,thr", [
+    (64, 48, 16, 20),      # (w-2B) % 16 == 0
+    (77, 61, 16, 20),      # odd (w-2B): over-classified right edge emits score-255 keypoints
+    (90, 70, 16, 10),      # even, not multiple of 16
+    (33, 33, 16, 20),      # a single classified column/row
+    (32, 40, 16, 20),      # width == 2*border: nothing to do
+    (50, 44, 3, 30),       # small border (detect only contract), xend past width
+    (130, 47, 4, 0),       # threshold 0
+    (100, 60, 16, 276),    # threshold truncated to uint8 (276 & 0xff = 20), Fast.h:58
+])
+def test_stage_parity_on_adversarial_levels(gpu_ctx, orc, w, h, border, thr):
+    """Noise/blocks images with NON-zero padding right of the level (reads past `width`)."""
+    from pislam_amd import frontend as fe
+    rng = np.random.default_rng(w * 1000 + h)
+    vstep = 160
+    img = rng.integers(0, 256, (h, vstep), dtype=np.uint8)
+    img[:, : w // 2] = (img[:, : w // 2] // 64) * 64
+    det, score = _levels_stagewise(fe, orc, img, [(w, h, 0)], gpu_ctx, border=border, thr=thr,
+                                   hthr=(1 << 15) if border >= 4 else 1 << 15)
+    if border >= 16:
+        for lb, lim in [(0, 5), (4, 3), (3, 1), (5, 7), (1, 2)]:
+            g = fe.fastExtract(w, h, score, border=border, logBucketSize=lb, bucketLimit=lim, ctx=gpu_ctx)
+            o = orc.fast_extract(score, w, h, border=border, log_bucket=lb, bucket_limit=lim)
+            assert len(g) == len(o) and (g == o).all(), (lb, lim)
+        kp = orc.fast_extract(score, w, h, border=border)
+        if len(kp):
+            for words in (8, 5, 1):
+                assert (fe.orbCompute(img, kp, words=words, ctx=gpu_ctx) == orc.orb_compute(img, kp, words=words)).all()
+            assert (fe.orbCentroids(img, kp, ctx=gpu_ctx) == orc.orb_centroids(img, kp)).all()
+
+
+def test_score_map_with_stale_values_and_dense_scores(gpu_ctx, orc):
+    """fastScoreHarris scores ANY non-zero byte (Fast.h:173-176); NMS on a dense random score map."""
+    from pislam_amd import frontend as fe
+    rng = np.random.default_rng(11)
+    img = rng.integers(0, 256, (80, 128), dtype=np.uint8)
+    out = (rng.integers(0, 4, (80, 128)) == 0).astype(np.uint8) * rng.integers(1, 256, (80, 128)).astype(np.uint8)
+    g, o = out.copy(), out.copy()
+    fe.fastScoreHarris(120, 80, img, 1000, g, ctx=gpu_ctx)
+    orc.fast_score_harris(img, o, 120, 80, 1000)
+    assert (g == o).all()
+    dense = rng.integers(0, 256, (80, 128), dtype=np.uint8)
+    dense[rng.integers(0, 2, (80, 128)) == 0] = 200                      # many ties
+    for lb, lim in [(0, 5), (4, 5), (2, 2), (6, 64)]:
+        a = fe.fastExtract(121, 79, dense, logBucketSize=lb, bucketLimit=lim, ctx=gpu_ctx)
+        b = orc.fast_extract(dense, 121, 79, log_bucket=lb, bucket_limit=lim)
+        assert len(a) == len(b) and (a == b).all(), (lb, lim)
+    # capacity clipping: count is the reference's count, storage is clipped
+    import ctypes
+    from pislam_amd.capi import ptr
+    buf = np.zeros(7, np.uint32)
+    n = ctypes.c_size_t(0)
+    gpu_ctx.check(gpu_ctx.lib.pislam_fast_extract(gpu_ctx.h, 128, 16, 0, 5, 121, 79, ptr(dense), ptr(buf), 7,
+                                                  ctypes.byref(n)), "extract")
+    full = orc.fast_extract(dense, 121, 79)
+    assert n.value == len(full) and (buf == full[:7]).all()
+
+
+def test_harris_and_angle_primitives(gpu_ctx, orc, demo):
+    from pislam_amd import frontend as fe
+    img = demo["img"]
+    rng = np.random.default_rng(5)
+    pts = ((rng.integers(16, 600, 500).astype(np.uint32) << 12) | rng.integers(16, 2190, 500).astype(np.uint32))
+    g = fe.harrisScorePoints(img, pts, 1 << 15, ctx=gpu_ctx)
+    o = np.array([orc.lib().orc_harris_score_sobel(640, img.ctypes.data, int(p >> 12) & 0xFFF, int(p) & 0xFFF, 1 << 15)
+                  for p in pts], np.uint8)
+    assert (g == o).all()
+    noise = rng.integers(0, 256, (64, 64), dtype=np.uint8)
+    noise[::2] = 255 - noise[::2] // 8
+    pts = ((rng.integers(8, 56, 300).astype(np.uint32) << 12) | rng.integers(8, 56, 300).astype(np.uint32))
+    for thr in (-(1 << 31), -5, 0, 1 << 15, (1 << 31) - 1):
+        g = fe.harrisScorePoints(noise, pts, thr, ctx=gpu_ctx)
+        o = np.array([orc.lib().orc_harris_score_sobel(64, noise.ctypes.data, int(p >> 12) & 0xFFF, int(p) & 0xFFF, thr)
+                      for p in pts], np.uint8)
+        assert (g == o).all(), thr
+    # angle bins: exhaustive-ish sweep incl. zeros, axes, diagonals, extremes (Orb.h:310-387)
+    xs = np.concatenate([rng.integers(-1365780, 1365781, 40000), [0, 0, 1, -1, 5, -5, 1365780, -1365780, 7, 7]])
+    ys = np.concatenate([rng.integers(-1365780, 1365781, 40000), [0, 5, 0, 0, 5, 5, -1365780, 1365780, -7, 7]])
+    n = (len(xs) + 3) // 4 * 4
+    xs = np.pad(xs, (0, n - len(xs))).astype(np.int32)
+    ys = np.pad(ys, (0, n - len(ys))).astype(np.int32)
+    grouped = np.stack([xs.reshape(-1, 4), ys.reshape(-1, 4)], axis=1).reshape(-1)
+    assert (fe.atan2(grouped, ctx=gpu_ctx) == orc.atan2_bins(grouped)).all()
+    small = np.arange(-40, 41, dtype=np.int32)
+    gx, gy = np.meshgrid(small, small)
+    gx, gy = gx.reshape(-1), gy.reshape(-1)
+    n = (len(gx) + 3) // 4 * 4
+    gx = np.pad(gx, (0, n - len(gx))); gy = np.pad(gy, (0, n - len(gy)))
+    grouped = np.stack([gx.reshape(-1, 4), gy.reshape(-1, 4)], axis=1).reshape(-1).astype(np.int32)
+    assert (fe.atan2(grouped, ctx=gpu_ctx) == orc.atan2_bins(grouped)).all()
+
+
+def test_brief_describe_all_rotations(gpu_ctx, orc, demo):
+    from pislam_amd import frontend as fe
+    img = demo["img"]
+    kp = demo["kp"][::13]
+    rots = (np.arange(len(kp)) % 32).astype(np.uint8)          # includes out-of-range 30, 31
+    g = fe.briefDescribePoints(img, kp, rots, ctx=gpu_ctx)
+    for i, p in enumerate(kp):
+        exp = orc.brief_describe(img, (int(p) >> 12) & 0xFFF, int(p) & 0xFFF, int(rots[i])) if rots[i] < 30 else 0
+        assert (g[i] == exp).all(), (i, rots[i])
+
+
+def test_batch_parity_on_synthetic_pyramids(gpu_ctx, orc):
+    """bench workload (VGA 8-level x1.2, thr 20, Harris 1<<15): batch path vs oracle, bit-exact,
+    incl. score maps, with and without buckets, and with a clipped keypoint capacity."""
+    import torch
+    from pislam_amd import synth
+    from pislam_amd.frontend import OrbFrontend
+    levels = synth.level_table()
+    B = 6
+    pyr = synth.make_batch(100, B)
+    dev = torch.device("cuda:0")
+    d_pyr = torch.from_numpy(pyr).to(dev)
+    for lb, lim, cap in [(0, 5, 4096), (4, 3, 4096), (0, 5, 300)]:
+        fe = OrbFrontend(levels, vstep=640, rows=2210, max_keypoints=cap, log_bucket_size=lb, bucket_limit=lim,
+                         ctx=gpu_ctx)
+        kp, desc, counts = fe.alloc_outputs(B, dev)
+        fe(d_pyr, kp, desc, counts)
+        torch.cuda.synchronize()
+        c = counts.cpu().numpy().view(np.uint32)
+        k = kp.cpu().numpy().view(np.uint32)
+        d = desc.cpu().numpy().view(np.uint32)
+        for b in range(B):
+            okp, odesc, _, osc = orc.pyramid(pyr[b], levels, log_bucket=lb, bucket_limit=lim, return_score=True)
+            assert c[b] == len(okp), (b, c[b], len(okp))
+            n = min(len(okp), cap)
+            assert (k[b, :n] == okp[:n]).all(), b
+            assert (d[b, :n] == odesc[:n]).all(), b
+            try:
+                sm = fe.score_map(b)
+            except Exception:
+                sm = None
+            if sm is not None:
+                assert (sm == osc).all(), b
+
+
+def test_full_batch_properties(gpu_ctx, orc):
+    """BASELINE config 2 size (batch 256): size-independent properties — results do not depend on
+    the batch slot, repeated runs are bit-identical (ordered compaction, no atomics-order), a sample
+    of slots equals the oracle, every keypoint lies inside its level, list order is the reference's."""
+    import torch
+    from pislam_amd import synth
+    from pislam_amd.frontend import OrbFrontend
+    levels = synth.level_table()
+    base = synth.make_batch(0, 8)
+    batch = 256
+    idx = np.arange(batch) % 8
+    dev = torch.device("cuda:0")
+    d_pyr = torch.from_numpy(base).to(dev)[torch.from_numpy(idx).to(dev)].contiguous()
+    fe = OrbFrontend(levels, vstep=640, rows=2210, max_keypoints=4096, ctx=gpu_ctx)
+    kp, desc, counts = fe.alloc_outputs(batch, dev)
+    fe(d_pyr, kp, desc, counts)
+    torch.cuda.synchronize()
+    c1, k1, d1 = (t.cpu().numpy().view(np.uint32) for t in (counts, kp, desc))
+    fe(d_pyr, kp, desc, counts)
+    torch.cuda.synchronize()
+    c2, k2, d2 = (t.cpu().numpy().view(np.uint32) for t in (counts, kp, desc))
+    assert (c1 == c2).all() and (k1 == k2).all() and (d1 == d2).all()
+    for b in range(8, batch):
+        n = c1[b]
+        assert n == c1[b % 8] and (k1[b, :n] == k1[b % 8, :n]).all() and (d1[b, :n] == d1[b % 8, :n]).all()
+    for b in (0, 3, 7):
+        okp, odesc, _ = orc.pyramid(base[b], levels)
+        assert c1[b] == len(okp) and (k1[b, :len(okp)] == okp).all() and (d1[b, :len(okp)] == odesc).all()
+    # geometry + ordering invariants for every slot
+    for b in range(0, batch, 17):
+        n = c1[b]
+        x = (k1[b, :n] >> 12) & 0xFFF
+        y = k1[b, :n] & 0xFFF
+        lvl = np.zeros(n, int)
+        for li, (w, h, r0) in enumerate(levels):
+            m = (y >= r0) & (y < r0 + h)
+            lvl[m] = li
+            assert ((x[m] >= 16) & (x[m] <= w - 16) & (y[m] - r0 >= 16) & (y[m] - r0 <= h - 16)).all()
+        assert (np.diff(lvl) >= 0).all()
+        key = lvl * (1 << 24) + ((y - np.array([levels[l][2] for l in lvl])) // 2) * 4096 + x // 2
+        assert (np.diff(key) > 0).all()

@@ -1,0 +1,212 @@
+"""CPU suite: the oracle against the reference's pins (no GPU, no /root/reference needed)."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, SURVEY_PINS, sha16
+
+RING = [(-3, -1), (-3, 0), (-3, 1), (-2, 2), (-1, 3), (0, 3), (1, 3), (2, 2),
+        (3, 1), (3, 0), (3, -1), (2, -2), (1, -3), (0, -3), (-1, -3), (-2, -2)]   # (dy, dx)
+UMAX = [15, 15, 15, 15, 15, 15, 14, 14, 13, 13, 12, 11, 10, 9, 7, 5]
+
+
+def test_golden_fixture_matches_survey_pins(demo):
+    for k, v in SURVEY_PINS.items():
+        assert sha16(demo[k]) == v, k
+
+
+def test_oracle_reproduces_reference_outputs_on_demo_pyramid(demo, orc):
+    """Every stage of the oracle on the reference's demo input == the hashes recorded from the
+    reference's own headers: det map, score map, both keypoint lists incl. order,
+    centroids, angle bins, descriptors."""
+    img, levels = demo["img"], demo["levels"]
+    det = np.zeros_like(img)
+    for w, h, r0 in levels:
+        orc.fast_detect(img[r0:r0 + h], det[r0:r0 + h], w, h, 20)
+    assert sha16(det) == SURVEY_PINS["det"]
+    score = det.copy()
+    for w, h, r0 in levels:
+        orc.fast_score_harris(img[r0:r0 + h], score[r0:r0 + h], w, h)
+    assert sha16(score) == SURVEY_PINS["score"]
+    kp = np.concatenate([orc.fast_extract(score[r0:r0 + h], w, h) + np.uint32(r0) for w, h, r0 in levels])
+    assert len(kp) == 1754 and sha16(kp.astype(np.uint32)) == SURVEY_PINS["kp"]
+    kpb = np.concatenate([orc.fast_extract(score[r0:r0 + h], w, h, log_bucket=4, bucket_limit=3) + np.uint32(r0)
+                          for w, h, r0 in levels])
+    assert len(kpb) == 1315 and sha16(kpb.astype(np.uint32)) == SURVEY_PINS["kp_bucket43"]
+    cen = orc.orb_centroids(img, kp)
+    assert len(cen) == 3512 and sha16(cen) == SURVEY_PINS["centroids"]
+    ang = orc.atan2_bins(cen)
+    assert len(ang) == 1756 and sha16(ang) == SURVEY_PINS["angles"]
+    desc = orc.orb_compute(img, kp)
+    assert desc.size == 14032 and sha16(desc) == SURVEY_PINS["desc"]
+    assert int(kp[0]) == 0x891ED010 and int(desc[0, 0]) == 0xB3BFD04F
+    # whole-pyramid driver == stage-by-stage
+    k2, d2, lc = orc.pyramid(img, levels)
+    assert (k2 == kp).all() and (d2 == desc).all()
+    assert lc.tolist() == [271, 296, 275, 255, 229, 184, 148, 96]
+
+
+def test_vrecpe_known_answers(orc):
+    """ARM ARM FPRecipEstimate known answers."""
+    assert orc.vrecpe(1.0) == 0.998046875
+    assert orc.vrecpe(2.0) == 0.4990234375
+    assert orc.vrecpe(3.0) == 0.3330078125
+    assert orc.vrecpe(0.0) == float("inf")
+    assert orc.vrecpe(float("inf")) == 0.0
+    assert orc.vrecpe(-4.0) == -orc.vrecpe(4.0)
+    # integer form == the pseudocode's floating form for every 8-bit mantissa bucket
+    for q in range(256, 512):
+        r = 1.0 / ((q + 0.5) / 512.0)
+        s = int(256.0 * r + 0.5)
+        assert ((1 << 19) + (2 * q + 1)) // (2 * (2 * q + 1)) == s
+
+
+def test_angle_bin_quadrants_and_padding(orc):
+    L = orc.lib()
+    assert L.orc_angle_bin(0, 0) == 7            # the (0,0) padding slots
+    assert L.orc_angle_bin(1000, 0) == 0
+    assert L.orc_angle_bin(0, 1000) == 7
+    assert L.orc_angle_bin(-1000, 0) == 15
+    assert L.orc_angle_bin(0, -1000) == 22
+    # bins follow exact atan2 except near bin edges: compare away from edges
+    rng = np.random.default_rng(1)
+    bad = 0
+    for _ in range(3000):
+        x, y = (int(v) for v in rng.integers(-100000, 100000, 2))
+        a = np.degrees(np.arctan2(y, x)) % 360.0
+        if abs((a / 12.0) - round(a / 12.0)) < 0.05:
+            continue
+        bad += int(L.orc_angle_bin(x, y) != int(a // 12) % 30)
+    assert bad == 0
+
+
+def test_fast9_equals_textbook_definition(orc):
+    """oracle's NEON-style clz/shift test == '9 contiguous ring pixels all brighter than c+t or
+    all darker than c-t' on adversarial random images."""
+    rng = np.random.default_rng(2)
+    for w, h, t in [(48, 40, 20), (61, 37, 5), (64, 33, 60), (50, 50, 0), (52, 41, 255), (40, 40, 276)]:
+        img = rng.integers(0, 256, (h, 96), dtype=np.uint8)
+        img[:, : w // 2] = (img[:, : w // 2] // 64) * 64          # blocky half -> many corners
+        out = np.zeros_like(img)
+        B = 3
+        orc.fast_detect(img, out, w, h, t, border=B)
+        tt = t & 0xFF
+        xend = B + 16 * -(-(w - 2 * B) // 16)
+        for y in range(B, h - B):
+            for x in range(B, xend):
+                c = int(img[y, x])
+                ring = [int(img[y + dy, x + dx]) for dy, dx in RING]
+                br = [p > c + tt for p in ring]
+                dk = [p < c - tt for p in ring]
+                def arc(f):
+                    f2 = f + f
+                    return any(all(f2[s:s + 9]) for s in range(16))
+                exp = 0xFF if (arc(br) or arc(dk)) else 0
+                if w % 16 and x in (w, w + 1):
+                    exp = 0
+                assert out[y, x] == exp, (w, h, t, x, y)
+        assert not out[:B].any() and not out[h - B:].any() and not out[:, :B].any()
+        assert not out[:, max(xend, w + 2 if w % 16 else 0):].any()
+
+
+def test_centroid_equals_bruteforce_circle(orc, demo):
+    img = demo["img"]
+    kp = demo["kp"][::97]
+    cen = orc.orb_centroids(img, kp)
+    for i, p in enumerate(kp):
+        x, y = (int(p) >> 12) & 0xFFF, int(p) & 0xFFF
+        m10 = m01 = 0
+        for dy in range(-15, 16):
+            u = UMAX[abs(dy)]
+            row = img[y + dy, x - u:x + u + 1].astype(np.int64)
+            m10 += int((row * np.arange(-u, u + 1)).sum())
+            m01 += dy * int(row.sum())
+        g = (i // 4) * 8 + (i % 4)
+        assert cen[g] == m10 and cen[g + 4] == m01
+
+
+def test_harris_eval_wraparound_and_encoding(orc):
+    L = orc.lib()
+    assert L.orc_harris_eval(0, 0, 0, 1 << 15) == 0
+    # score = Ixx*Iyy - Ixy^2 - (Ixx+Iyy)^2/16
+    for ixx, iyy, ixy in [(5000, 4000, 100), (30000, 30000, -20000), (900, 800, 0), (65535, 65535, 0)]:
+        det = (ixx * iyy - ixy * ixy) & 0xFFFFFFFF
+        tr = (((ixx + iyy) ** 2) & 0xFFFFFFFF) >> 4
+        s = (det - tr) & 0xFFFFFFFF
+        s = s - (1 << 32) if s >= (1 << 31) else s
+        exp = 0
+        if s > (1 << 15):
+            exp = (np.float32(s).view(np.uint32) >> 20) & 0xFF
+        assert L.orc_harris_eval(ixx, iyy, ixy, 1 << 15) == exp
+
+
+def test_brief_table_equals_compiled_reference_probe(orc):
+    """oracle's float32 rotation formula == table probed from the compiled reference Brief.h."""
+    ref = np.load(os.path.join(GOLDEN, "brief_table_ref.npy"))
+    tab = orc.brief_table()
+    assert tab.shape == (30, 256, 4)
+    assert (tab == ref).all()
+    import hashlib
+    assert hashlib.sha256(ref.tobytes()).hexdigest().startswith("15c108c2d4c62b94")
+    assert tuple(ref[1, 0]) == (8, -1, 8, 7) and tuple(ref[7, 0]) == (4, 8, -4, 9)
+    assert int((np.abs(ref) == 15).sum()) > 0
+
+
+def test_brief_descriptor_equals_real_reference_when_built(orc, demo):
+    """Direct execution of the real Brief.h (oracle/_ref/libbrief_ref.so, built in the dev container)."""
+    so = os.path.join(os.path.dirname(GOLDEN), "..", "oracle", "_ref", "libbrief_ref.so")
+    if not os.path.exists(so):
+        pytest.skip("oracle/_ref not built here")
+    ref = ctypes.CDLL(so)
+    ref.ref_brief_describe_640.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+    img = demo["img"]
+    rng = np.random.default_rng(3)
+    for i, p in enumerate(demo["kp"][::41]):
+        x, y = (int(p) >> 12) & 0xFFF, int(p) & 0xFFF
+        rot = int(rng.integers(0, 30))
+        exp = np.zeros(8, np.uint32)
+        ref.ref_brief_describe_640(img.ctypes.data, x, y, rot, exp.ctypes.data)
+        assert (orc.brief_describe(img, x, y, rot) == exp).all()
+
+
+def test_extract_edge_cases(orc):
+    rng = np.random.default_rng(4)
+    # empty map, tiny level, ties, capacity clipping
+    s = np.zeros((64, 64), np.uint8)
+    assert len(orc.fast_extract(s, 40, 40)) == 0
+    assert len(orc.fast_extract(s, 32, 32)) == 0          # width == 2*border: loops do not run
+    s[20, 20] = s[20, 21] = s[21, 20] = s[21, 21] = 9      # 4-way tie inside one block -> v3 wins
+    kp = orc.fast_extract(s, 50, 50)
+    assert kp.tolist() == [(9 << 24) | (21 << 12) | 21]
+    s[:] = 0
+    s[18, 19] = 7
+    s[18, 20] = 7                                          # tie across blocks: '>=' vs '>' rules
+    kp = orc.fast_extract(s, 50, 50)
+    assert kp.tolist() == [(7 << 24) | (20 << 12) | 18]   # left pixel loses: v1 needs ">" to its right, v0 only ">=" to its left
+    dense = rng.integers(0, 256, (64, 64), dtype=np.uint8)
+    full = orc.fast_extract(dense, 60, 60)
+    dst = np.zeros(5, np.uint32)
+    n = orc.lib().orc_fast_extract(64, 16, 0, 5, 60, 60, dense.ctypes.data, dst.ctypes.data, 5)
+    assert n == len(full) and (dst == full[:5]).all()
+    # buckets: each 16x16 cell keeps its `limit` largest packed words, ascending
+    b = orc.fast_extract(dense, 60, 60, log_bucket=4, bucket_limit=2)
+    cells = {}
+    for v in full:
+        x, y = (int(v) >> 12) & 0xFFF, int(v) & 0xFFF
+        bx, by = ((x - 16) // 2 * 2) // 16, ((y - 16) // 2 * 2) // 16
+        cells.setdefault((by, bx), []).append(int(v))
+    exp = []
+    for key in sorted(cells):
+        exp += sorted(cells[key])[-2:]
+    assert b.tolist() == exp
+
+
+def test_synth_small_fixture_regression(synth_small, orc):
+    from pislam_amd import synth
+    lv = synth_small["levels"]
+    p = synth.make_pyramid(7, w0=160, h0=120, nlevels=3, levels=lv, nshapes=12)
+    assert (p == synth_small["img"]).all(), "synthetic generator changed"
+    kp, desc, _ = orc.pyramid(p, lv)
+    assert (kp == synth_small["kp"]).all() and (desc == synth_small["desc"]).all()
