@@ -1,0 +1,164 @@
+#!/usr/bin/env python3
+"""bench.py — ORB keypoints+descriptors/sec on synthetic 640x480 8-level x1.2 pyramids.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+A "step" is one pass of the whole hot path (fastDetect -> fastScoreHarris -> fastExtract ->
+orbCompute on every level of every pyramid) over one device-resident batch of 256 synthetic
+pyramids per GPU (BASELINE.json configs[1]); for N>1 each rank owns its own 256 pyramids (weak
+scaling) and the step ends with the RCCL all-gather of the per-pyramid keypoint counts.
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+HBM_PEAK_GBPS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def cpu_baseline(pyr_host, levels, budget_s=12.0):
+    """The oracle (bit-exact plain-C restatement of the reference path, oracle/pislam_oracle.c) timed
+    on ONE host thread — the reference itself is single-threaded — on a bounded sample of the same
+    workload."""
+    from oracle import orc
+    orc.lib()
+    orc.pyramid(pyr_host[0], levels)                      # warm caches / lazy table
+    n_kp, n_pyr, t0 = 0, 0, time.perf_counter()
+    for b in range(len(pyr_host)):
+        kp, _, _ = orc.pyramid(pyr_host[b], levels)
+        n_kp += len(kp)
+        n_pyr += 1
+        if time.perf_counter() - t0 > budget_s:
+            break
+    dt = time.perf_counter() - t0
+    return {"value": n_kp / dt, "unit": "kp+desc/s", "cores": 1, "kind": "port",
+            "sample": f"{n_pyr} of the batch's pyramids ({n_kp} keypoints) in {dt:.2f} s, 1 thread, "
+                      f"oracle/pislam_oracle.c -O3 on {os.cpu_count()} visible host cores"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=256, help="pyramids per GPU")
+    ap.add_argument("--distinct", type=int, default=0,
+                    help="distinct synthetic pyramids generated per GPU (0 = all of the batch)")
+    ap.add_argument("--max-keypoints", type=int, default=4096)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    from pislam_amd import dist as pdist, synth
+    from pislam_amd.frontend import OrbFrontend
+    from pislam_amd.capi import Context
+
+    rank, local_rank, world = pdist.init()
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU fallback)"
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    levels = synth.level_table()                           # demo.cpp:38-47 table, 2210 stacked rows
+    rows = synth.pyramid_rows(levels)
+    B = args.batch
+    distinct = args.distinct or B
+    first = rank * B
+    host = synth.make_batch(first, min(distinct, B))
+    d_pyr = torch.from_numpy(host).to(dev)
+    if distinct < B:
+        d_pyr = d_pyr[torch.arange(B, device=dev) % distinct].contiguous()
+
+    stream = torch.cuda.current_stream(dev)
+    ctx = Context(device=local_rank, stream=stream.cuda_stream)
+    fe = OrbFrontend(levels, vstep=640, rows=rows, max_keypoints=args.max_keypoints, ctx=ctx)
+    fe.reserve(B)
+    kp, desc, counts = fe.alloc_outputs(B, dev)
+
+    def step():
+        fe(d_pyr, kp, desc, counts)
+        return pdist.gather_counts(counts, world)
+
+    for _ in range(args.warmup):
+        allc = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    gpu_ms = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        allc = step()
+        gpu_ms.append(None)
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # device time of the library's launches for the last step (hipEvents on the launch stream)
+    ev_total_ms, ev_stage_ms = fe.last_timing()
+    # a few more event-timed steps for an average kernel-side duration
+    ev = []
+    for _ in range(min(5, args.steps)):
+        fe(d_pyr, kp, desc, counts)
+        ev.append(fe.last_timing())
+    ev_total_ms = float(np.mean([e[0] for e in ev]))
+    ev_stage_ms = [float(np.mean([e[1][i] for e in ev])) for i in range(3)]
+
+    total_kp_step = int(allc.to(torch.int64).sum().item())          # all ranks, one step
+    local_kp = int(counts.to(torch.int64).sum().item())
+    value = total_kp_step * args.steps / dt
+
+    if rank == 0:
+        valid_px = sum(w * h for w, h, _ in levels)
+        # algorithmic bytes: every valid pixel once + 36 B per keypoint + 4 B count
+        b_alg_launch = B * (valid_px + 4) + 36 * local_kp
+        achieved = b_alg_launch / (ev_total_ms * 1e-3) / 1e9
+        out = {
+            "metric": "ORB keypoints+descriptors/sec, 640x480 8-level pyramid",
+            "value": value, "unit": "kp+desc/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {
+                "workload": "batch=256 synthetic 640x480 pyramids per GPU, 8 levels x1.2 stacked (vstep=640, "
+                            "2210 rows), border=16, FAST threshold=20, Harris threshold=1<<15, no buckets, "
+                            "256-bit descriptors (BASELINE.json configs[1])",
+                "batch_per_gpu": B, "global_batch": B * world, "distinct_pyramids_per_gpu": min(distinct, B),
+                "keypoints_per_pyramid": total_kp_step / (B * world),
+                "pyramids_per_s": B * world * args.steps / dt,
+                "parallelism": f"pyramid-shard x{world}, RCCL all-gather of counts" if world > 1 else "single GPU",
+                "pipeline": "staged",
+            },
+            "roofline": {
+                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                "kernel": "whole pipeline step (all launches, hipEvents on the launch stream)",
+                "algorithmic_bytes_per_launch": b_alg_launch, "launch_ms": ev_total_ms,
+                "stage_ms": {"detect+score": ev_stage_ms[0], "extract": ev_stage_ms[1], "orb": ev_stage_ms[2]},
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(host, levels)
+        print(json.dumps(out))
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

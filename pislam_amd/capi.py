@@ -68,6 +68,14 @@ def load(rebuild_if_stale: bool = True):
     global _LIB
     if _LIB is not None:
         return _LIB
+    # One HIP runtime per process: torch bundles its own libamdhip64 (soname libamdhip64.so.7) and
+    # asks for it as "libamdhip64.so", so it must be loaded BEFORE this library (which then binds to
+    # the already-loaded runtime and can use torch's device pointers in place).  Loading us first
+    # would bring in /opt/rocm's copy as a second runtime.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     path = _build.LIB
     if rebuild_if_stale:
         try:

@@ -236,12 +236,13 @@ int check_level_args(pislam_ctx *c, int vstep, int border, int width, int height
 }
 
 // byte hull [lo, hi) of the image the reference's orbCompute reads for these points
-void orb_hull(const uint32_t *pts, size_t n, int vstep, ptrdiff_t *lo, ptrdiff_t *hi) {
+void orb_hull(const uint32_t *pts, size_t n, int vstep, int before, int after, ptrdiff_t *lo,
+              ptrdiff_t *hi) {
   ptrdiff_t l = PTRDIFF_MAX, h = PTRDIFF_MIN;
   for (size_t i = 0; i < n; i++) {
     const int x = (pts[i] >> 12) & 0xfff, y = pts[i] & 0xfff;
-    const ptrdiff_t a = (ptrdiff_t)(y - 15) * vstep + (x - 15);
-    const ptrdiff_t b = (ptrdiff_t)(y + 15) * vstep + (x + 16) + 1;
+    const ptrdiff_t a = (ptrdiff_t)(y - before) * vstep + (x - before);
+    const ptrdiff_t b = (ptrdiff_t)(y + after) * vstep + (x + after) + 1;
     l = std::min(l, a);
     h = std::max(h, b);
   }
@@ -252,8 +253,11 @@ void orb_hull(const uint32_t *pts, size_t n, int vstep, ptrdiff_t *lo, ptrdiff_t
 // Stage points + the image hull for the point-list entry points.  On return
 // *d_img_base is a device pointer such that d_img_base[y*vstep+x] is valid for
 // every byte the kernels touch.
+// `before`/`after`: how many rows/columns before/after a point the consumer reads
+// (ORB: 15 / 16 incl. the masked column x+16 of Orb.h:200-203; Harris 8x8: 3 / 4).
 int stage_points_image(pislam_ctx *c, int vstep, const uint8_t *img, const uint32_t *points, size_t n,
-                       const uint8_t **d_img_base, const uint32_t **d_pts) {
+                       const uint8_t **d_img_base, const uint32_t **d_pts, int before = 15,
+                       int after = 16) {
   Staged sp;
   std::vector<uint32_t> host_pts;
   const bool pts_dev = is_device_ptr(points);
@@ -273,8 +277,8 @@ int stage_points_image(pislam_ctx *c, int vstep, const uint8_t *img, const uint3
     hp = host_pts.data();
   }
   ptrdiff_t lo, hi;
-  orb_hull(hp, n, vstep, &lo, &hi);
-  if (lo < 0) return fail(c, PISLAM_ERR_INVALID, "keypoint closer than 15 px to the image origin");
+  orb_hull(hp, n, vstep, before, after, &lo, &hi);
+  if (lo < 0) return fail(c, PISLAM_ERR_INVALID, "point too close to the image origin for its patch");
   const size_t bytes = (size_t)(hi - lo);
   if (c->s_img.ensure(bytes) != PISLAM_OK) return fail(c, PISLAM_ERR_NOMEM, "hipMalloc(image hull)");
   HIPCHK(c, hipMemcpyAsync(c->s_img.p, img + lo, bytes, hipMemcpyHostToDevice, c->stream));
@@ -292,23 +296,37 @@ PISLAM_EXPORT int pislam_abi_version(void) { return PISLAM_ABI_VERSION; }
 PISLAM_EXPORT int pislam_ctx_create(int device, pislam_ctx **out) {
   if (!out) return PISLAM_ERR_INVALID;
   *out = nullptr;
+  // creation failures have no ctx to carry a message: say why on stderr (they are fatal for the
+  // caller anyway — there is no CPU fallback)
+#define CREATE_CHK(call)                                                                    \
+  do {                                                                                      \
+    hipError_t e_ = (call);                                                                 \
+    if (e_ != hipSuccess) {                                                                 \
+      fprintf(stderr, "pislam_ctx_create: %s -> %s\n", #call, hipGetErrorString(e_));       \
+      (void)hipGetLastError();                                                              \
+      return PISLAM_ERR_HIP;                                                                \
+    }                                                                                       \
+  } while (0)
   int ndev = 0;
-  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
-    (void)hipGetLastError();
+  CREATE_CHK(hipGetDeviceCount(&ndev));
+  if (ndev <= 0) {
+    fprintf(stderr, "pislam_ctx_create: no HIP device\n");
     return PISLAM_ERR_HIP;
   }
-  if (device < 0) {
-    if (hipGetDevice(&device) != hipSuccess) return PISLAM_ERR_HIP;
-  }
+  if (device < 0) CREATE_CHK(hipGetDevice(&device));
   if (device >= ndev) return PISLAM_ERR_INVALID;
-  if (hipSetDevice(device) != hipSuccess) return PISLAM_ERR_HIP;
+  CREATE_CHK(hipSetDevice(device));
   pislam_ctx *c = new pislam_ctx();
   c->device = device;
-  for (auto &e : c->ev)
-    if (hipEventCreate(&e) != hipSuccess) {
+  for (auto &e : c->ev) {
+    hipError_t r = hipEventCreate(&e);
+    if (r != hipSuccess) {
+      fprintf(stderr, "pislam_ctx_create: hipEventCreate -> %s\n", hipGetErrorString(r));
       delete c;
       return PISLAM_ERR_HIP;
     }
+  }
+#undef CREATE_CHK
   *out = c;
   return PISLAM_OK;
 }
@@ -515,7 +533,7 @@ PISLAM_EXPORT int pislam_harris_score_points(pislam_ctx *c, int vstep, const uin
   HIPCHK(c, hipSetDevice(c->device));
   const uint8_t *d_img;
   const uint32_t *d_pts;
-  PCHK(stage_points_image(c, vstep, img, points, n, &d_img, &d_pts));   // hull is a superset of 8x8
+  PCHK(stage_points_image(c, vstep, img, points, n, &d_img, &d_pts, 3, 4));   // Harris.h:102-110
   Staged ss;
   PCHK(stage_in(c, c->s_rots, scores, n, &ss, false));
   hipLaunchKernelGGL(pk::k_harris_points, dim3(cdiv((int)n, 256)), dim3(256), 0, c->stream, d_img, vstep,
