@@ -48,6 +48,10 @@ int pislam_ctx_create(int device, pislam_ctx **ctx);
 int pislam_ctx_destroy(pislam_ctx *ctx);
 /* hip_stream is a hipStream_t passed as void*; NULL = null stream. */
 int pislam_ctx_set_stream(pislam_ctx *ctx, void *hip_stream);
+/* Tuning / test hooks.  Keys: "pipeline" (0 auto, 1 staged = one launch group per level with an
+ * HBM score map, 2 fused strips), "dump_score" (fused pipeline also materialises the score map so
+ * that pislam_frontend_get_score_map works), "strip_rows" (fused strip height, 0 = heuristic). */
+int pislam_ctx_set_option(pislam_ctx *ctx, const char *key, int value);
 int pislam_ctx_synchronize(pislam_ctx *ctx);
 const char *pislam_last_error(const pislam_ctx *ctx);
 

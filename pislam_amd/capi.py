@@ -36,6 +36,7 @@ SYMBOLS = {
     "pislam_ctx_create": (_i, [_i, ctypes.POINTER(_vp)]),
     "pislam_ctx_destroy": (_i, [_vp]),
     "pislam_ctx_set_stream": (_i, [_vp, _vp]),
+    "pislam_ctx_set_option": (_i, [_vp, ctypes.c_char_p, _i]),
     "pislam_ctx_synchronize": (_i, [_vp]),
     "pislam_last_error": (ctypes.c_char_p, [_vp]),
     "pislam_fast_detect": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _i]),
@@ -149,6 +150,9 @@ class Context:
 
     def set_stream(self, stream: int):
         self.check(self.lib.pislam_ctx_set_stream(self.h, _vp(stream)), "pislam_ctx_set_stream")
+
+    def set_option(self, key: str, value: int):
+        self.check(self.lib.pislam_ctx_set_option(self.h, key.encode(), int(value)), f"set_option({key})")
 
     def synchronize(self):
         self.check(self.lib.pislam_ctx_synchronize(self.h), "pislam_ctx_synchronize")

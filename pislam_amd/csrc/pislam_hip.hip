@@ -22,6 +22,7 @@ static const uint32_t h_brief_tab_packed[30 * 256] = {
 };
 
 #include "pislam_stage_kernels.h"
+#include "pislam_fused_kernels.h"
 
 #define PISLAM_EXPORT extern "C" __attribute__((visibility("default")))
 
@@ -66,7 +67,11 @@ struct pislam_ctx {
   // compaction scratch (shared by extract and the batch pipeline)
   DevBuf w_cnt, w_off, w_total, w_cellkp;
   // batch pipeline workspace
-  DevBuf w_score;
+  DevBuf w_score, w_stage, w_stripcnt;
+  int opt_pipeline = 0;      // 0 auto, 1 staged (one launch group per level), 2 fused strips
+  int opt_dump_score = 0;    // fused pipeline: also materialise the score map (parity hook)
+  int opt_strip_rows = 0;    // fused pipeline: strip height override (0 = heuristic)
+  int last_pipeline = 0;
   size_t score_bytes_valid = 0;   // bytes of w_score known to be in a consistent (zero-border) state
   pislam_frontend_params last_params{};
   std::vector<pislam_level> last_levels;
@@ -336,7 +341,7 @@ PISLAM_EXPORT int pislam_ctx_destroy(pislam_ctx *c) {
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
   for (DevBuf *b : {&c->s_img, &c->s_out, &c->s_pts, &c->s_desc, &c->s_misc, &c->s_rots, &c->w_cnt,
-                    &c->w_off, &c->w_total, &c->w_cellkp, &c->w_score})
+                    &c->w_off, &c->w_total, &c->w_cellkp, &c->w_score, &c->w_stage, &c->w_stripcnt})
     b->release();
   for (auto &e : c->ev)
     if (e) (void)hipEventDestroy(e);
@@ -347,6 +352,22 @@ PISLAM_EXPORT int pislam_ctx_destroy(pislam_ctx *c) {
 PISLAM_EXPORT int pislam_ctx_set_stream(pislam_ctx *c, void *s) {
   if (!c) return PISLAM_ERR_INVALID;
   c->stream = (hipStream_t)s;
+  return PISLAM_OK;
+}
+
+PISLAM_EXPORT int pislam_ctx_set_option(pislam_ctx *c, const char *key, int value) {
+  if (!c || !key) return PISLAM_ERR_INVALID;
+  if (!strcmp(key, "pipeline")) {
+    if (value < 0 || value > 2) return fail(c, PISLAM_ERR_INVALID, "pipeline must be 0 (auto), 1 (staged) or 2 (fused)");
+    c->opt_pipeline = value;
+  } else if (!strcmp(key, "dump_score")) {
+    c->opt_dump_score = value != 0;
+  } else if (!strcmp(key, "strip_rows")) {
+    if (value < 0 || value > 64 || (value & 1)) return fail(c, PISLAM_ERR_INVALID, "strip_rows must be even, 0..64");
+    c->opt_strip_rows = value;
+  } else {
+    return fail(c, PISLAM_ERR_INVALID, "unknown option");
+  }
   return PISLAM_OK;
 }
 
@@ -569,6 +590,91 @@ int check_params(pislam_ctx *c, const pislam_frontend_params *p, const pislam_le
 }
 }  // namespace
 
+
+namespace {
+
+// Strip plan of the fused pipeline.  Strip height per level: aim at ~8k pixels per workgroup,
+// even, 16..32 rows (override: option "strip_rows").
+bool build_fused_plan(const pislam_ctx *c, const pislam_frontend_params *p, const pislam_level *lv,
+                      int batch, pf::FusedParams *F, size_t *lds_bytes) {
+  if (p->nlevels > pf::MAX_LEVELS) return false;
+  memset(F, 0, sizeof(*F));
+  F->nlevels = p->nlevels;
+  F->vstep = p->vstep;
+  F->rows = p->rows;
+  F->border = p->border;
+  F->thr = p->fast_threshold & 0xff;
+  F->hthr = p->harris_threshold;
+  F->batch = batch;
+  F->dump_score = c->opt_dump_score;
+  int strips = 0, slots = 0;
+  size_t lds = 0;
+  for (int l = 0; l < p->nlevels; l++) {
+    pf::FusedLevel &L = F->lv[l];
+    L.w = lv[l].width;
+    L.h = lv[l].height;
+    L.row0 = lv[l].row0;
+    L.col0 = lv[l].col0;
+    const int nx = L.w - 2 * p->border, ny = L.h - 2 * p->border;
+    L.strip0 = strips;
+    L.slot0 = slots;
+    if (nx <= 0 || ny <= 0) {   // nothing to extract on this level (Fast.h loops do not run)
+      L.R = 16;
+      L.nstrips = 0;
+      L.nbx = 0;
+      L.xend = p->border;
+      L.pitch = 16;
+      continue;
+    }
+    int R = c->opt_strip_rows;
+    if (R == 0) {
+      R = (8192 / L.w) & ~1;
+      R = std::min(32, std::max(16, R));
+    }
+    L.R = R;
+    L.nstrips = cdiv(ny, R);
+    L.nbx = (nx + 1) / 2;
+    L.xend = p->border + 16 * cdiv(nx, 16);
+    L.pitch = (L.xend + 4 + 15) & ~15;
+    strips += L.nstrips;
+    slots += L.nstrips * (R / 2) * L.nbx;
+    lds = std::max(lds, (size_t)(2 * R + 13) * L.pitch + pf::WAVES * 2 * pf::QCAP * sizeof(uint32_t));
+  }
+  F->strips_per_pyr = strips;
+  F->slots_per_pyr = slots;
+  *lds_bytes = lds;
+  return strips > 0 && lds <= 150 * 1024;
+}
+
+int run_fused(pislam_ctx *c, const pislam_frontend_params *p, const pf::FusedParams &F, size_t lds,
+              const uint8_t *pyramids, size_t stride, int batch, uint32_t *kp, uint32_t *counts) {
+  if (c->w_stage.ensure(sizeof(uint32_t) * (size_t)F.slots_per_pyr * batch) != PISLAM_OK ||
+      c->w_stripcnt.ensure(sizeof(uint32_t) * (size_t)F.strips_per_pyr * batch) != PISLAM_OK)
+    return fail(c, PISLAM_ERR_NOMEM, "hipMalloc(fused staging)");
+  // 16-byte loads need 16-byte aligned rows
+  bool vec = ((uintptr_t)pyramids % 16 == 0) && (stride % 16 == 0) && (p->vstep % 16 == 0);
+  for (int l = 0; l < F.nlevels; l++) vec = vec && (F.lv[l].col0 % 16 == 0);
+  const int groups = cdiv(batch, 8);
+  const dim3 grid((unsigned)(groups * F.strips_per_pyr * 8));
+  uint8_t *dump = F.dump_score ? c->w_score.as<uint8_t>() : nullptr;
+  const size_t dump_stride = (size_t)p->rows * p->vstep;
+  auto kern = vec ? pf::k_fused_strips<true> : pf::k_fused_strips<false>;
+  if (lds > 64 * 1024)
+    HIPCHK(c, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(kern, grid, dim3(256), lds, c->stream, F, pyramids, stride, c->w_stage.as<uint32_t>(),
+                     c->w_stripcnt.as<uint32_t>(), dump, dump_stride);
+  PCHK(launch_ok(c, "k_fused_strips"));
+  HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
+  hipLaunchKernelGGL(pf::k_gather, dim3(batch), dim3(256), sizeof(uint32_t) * (F.strips_per_pyr + 1), c->stream,
+                     F, c->w_stage.as<uint32_t>(), c->w_stripcnt.as<uint32_t>(), kp, (size_t)p->max_keypoints,
+                     (uint32_t)p->max_keypoints, counts);
+  PCHK(launch_ok(c, "k_gather"));
+  HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
+  return PISLAM_OK;
+}
+
+}  // namespace
+
 PISLAM_EXPORT int pislam_frontend_reserve(pislam_ctx *c, const pislam_frontend_params *p,
                                           const pislam_level *lv, int batch) {
   PCHK(check_params(c, p, lv, batch));
@@ -620,11 +726,19 @@ PISLAM_EXPORT int pislam_orb_frontend_batch(pislam_ctx *c, const pislam_frontend
   const size_t pyr_bytes = (size_t)p->rows * p->vstep;
   uint8_t *score = c->w_score.as<uint8_t>();
   c->last_stride = pyr_bytes;
+  pf::FusedParams F;
+  size_t lds = 0;
+  bool fused = c->opt_pipeline != 1 && p->log_bucket_size == 0 && build_fused_plan(c, p, lv, batch, &F, &lds);
+  if (c->opt_pipeline == 2 && !fused)
+    return fail(c, PISLAM_ERR_INVALID, "fused pipeline unavailable for these parameters (buckets / LDS size)");
+  c->last_pipeline = fused ? 2 : 1;
   HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
+  if (fused) {
+    PCHK(run_fused(c, p, F, lds, pyramids, stride, batch, kp, counts));
+  } else {
   HIPCHK(c, hipMemsetAsync(counts, 0, sizeof(uint32_t) * batch, c->stream));
   // The score map workspace is laid out with stride pyr_bytes; the image with `stride`.  The stage
-  // kernels take one stride for both, so when they differ run detect/score per pyramid group: here
-  // we require equal strides for the fast path and fall back to per-pyramid launches otherwise.
+  // kernels take one stride for both, so when they differ fall back to per-pyramid launches.
   const bool same = stride == pyr_bytes;
   for (int l = 0; l < p->nlevels; l++) {
     const size_t off = (size_t)lv[l].row0 * p->vstep + lv[l].col0;
@@ -651,6 +765,7 @@ PISLAM_EXPORT int pislam_orb_frontend_batch(pislam_ctx *c, const pislam_frontend
                         (uint32_t)p->max_keypoints, add_xy, counts));
   }
   HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
+  }
   hipLaunchKernelGGL(pk::k_orb<0>, dim3(cdiv(p->max_keypoints, 4), 1, batch), dim3(256), 0, c->stream,
                      pyramids, p->vstep, stride, kp, (size_t)p->max_keypoints, counts, 0u,
                      (uint32_t)p->max_keypoints, p->words, desc, (size_t)p->max_keypoints * p->words,
@@ -665,6 +780,8 @@ PISLAM_EXPORT int pislam_frontend_get_score_map(pislam_ctx *c, int b, uint8_t *d
   if (!c || !dst) return PISLAM_ERR_INVALID;
   if (b < 0 || b >= c->last_batch || !c->w_score.p || !c->last_stride)
     return fail(c, PISLAM_ERR_INVALID, "no score map for that pyramid");
+  if (c->last_pipeline == 2 && !c->opt_dump_score)
+    return fail(c, PISLAM_ERR_INVALID, "the fused pipeline keeps the score map in LDS (set option dump_score)");
   HIPCHK(c, hipSetDevice(c->device));
   const size_t bytes = c->last_stride;
   HIPCHK(c, hipMemcpyAsync(dst, c->w_score.as<uint8_t>() + (size_t)b * bytes, bytes, hipMemcpyDefault,

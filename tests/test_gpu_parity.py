@@ -47,7 +47,18 @@ def test_four_call_api_on_reference_demo_pyramid(gpu_ctx, orc, demo):
     assert sha16(desc) == SURVEY_PINS["desc"] and (desc == demo["desc"]).all()
 
 
-def test_batch_path_on_reference_demo_pyramid(gpu_ctx, demo):
+@pytest.fixture(params=[1, 2], ids=["staged", "fused"])
+def pipeline(request, gpu_ctx):
+    """Run the batch tests on both pipelines; the fused one also dumps its LDS score tiles."""
+    gpu_ctx.set_option("pipeline", request.param)
+    gpu_ctx.set_option("dump_score", 1)
+    yield request.param
+    gpu_ctx.set_option("pipeline", 0)
+    gpu_ctx.set_option("dump_score", 0)
+    gpu_ctx.set_option("strip_rows", 0)
+
+
+def test_batch_path_on_reference_demo_pyramid(gpu_ctx, demo, pipeline):
     import torch
     from pislam_amd.frontend import OrbFrontend
     img = demo["img"]
@@ -69,7 +80,8 @@ def test_batch_path_on_reference_demo_pyramid(gpu_ctx, demo):
         sm = None
     if sm is not None:
         assert sha16(sm) == SURVEY_PINS["score"]
-    # bucketed mode (README's recommended <4,3>)
+    # bucketed mode (README's recommended <4,3>): auto mode picks the staged pipeline for it
+    gpu_ctx.set_option("pipeline", 0)
     feb = OrbFrontend(demo["levels"], vstep=640, rows=2210, max_keypoints=4096, log_bucket_size=4,
                       bucket_limit=3, ctx=gpu_ctx)
     feb(pyr, kp, desc, counts)
@@ -180,7 +192,80 @@ def test_brief_describe_all_rotations(gpu_ctx, orc, demo):
         assert (g[i] == exp).all(), (i, rots[i])
 
 
-def test_batch_parity_on_synthetic_pyramids(gpu_ctx, orc):
+@pytest.mark.parametrize("strip_rows", [0, 16, 32, 2, 64])
+def test_fused_strip_heights(gpu_ctx, orc, strip_rows):
+    """The fused pipeline's result must not depend on how levels are cut into strips."""
+    import torch
+    from pislam_amd import synth
+    from pislam_amd.frontend import OrbFrontend
+    levels = synth.level_table()
+    pyr = synth.make_batch(300, 3)
+    dev = torch.device("cuda:0")
+    gpu_ctx.set_option("pipeline", 2)
+    gpu_ctx.set_option("dump_score", 1)
+    gpu_ctx.set_option("strip_rows", strip_rows)
+    try:
+        fe = OrbFrontend(levels, vstep=640, rows=2210, max_keypoints=4096, ctx=gpu_ctx)
+        kp, desc, counts = fe.alloc_outputs(3, dev)
+        fe(torch.from_numpy(pyr).to(dev), kp, desc, counts)
+        torch.cuda.synchronize()
+        c = counts.cpu().numpy().view(np.uint32)
+        k = kp.cpu().numpy().view(np.uint32)
+        d = desc.cpu().numpy().view(np.uint32)
+        for b in range(3):
+            okp, odesc, _, osc = orc.pyramid(pyr[b], levels, return_score=True)
+            assert c[b] == len(okp)
+            assert (k[b, :c[b]] == okp).all() and (d[b, :c[b]] == odesc).all()
+            assert (fe.score_map(b) == osc).all()
+    finally:
+        gpu_ctx.set_option("pipeline", 0)
+        gpu_ctx.set_option("dump_score", 0)
+        gpu_ctx.set_option("strip_rows", 0)
+
+
+def test_fused_odd_shapes_and_unaligned_layouts(gpu_ctx, orc):
+    """Packed side-by-side layout (col0 != 0, not 16-aligned -> scalar staging path), ragged level
+    sizes, odd (w-2B), levels too small to hold a keypoint, batch not a multiple of 8."""
+    import torch
+    from pislam_amd.frontend import OrbFrontend
+    rng = np.random.default_rng(77)
+    vstep, rows = 400, 260
+    levels = [(200, 150, 0, 0), (131, 97, 0, 205), (77, 61, 150, 7), (40, 33, 150, 100), (33, 40, 150, 150),
+              (32, 32, 150, 200), (150, 49, 211, 16)]
+    B = 11
+    pyr = rng.integers(0, 256, (B, rows, vstep), dtype=np.uint8)
+    pyr[:, :, ::3] = (pyr[:, :, ::3] // 96) * 96
+    dev = torch.device("cuda:0")
+    d_pyr = torch.from_numpy(pyr).to(dev)
+    res = {}
+    for pl in (1, 2):
+        gpu_ctx.set_option("pipeline", pl)
+        try:
+            fe = OrbFrontend(levels, vstep=vstep, rows=rows, max_keypoints=8192, ctx=gpu_ctx)
+            kp, desc, counts = fe.alloc_outputs(B, dev)
+            fe(d_pyr, kp, desc, counts)
+            torch.cuda.synchronize()
+            res[pl] = tuple(t.cpu().numpy().view(np.uint32) for t in (counts, kp, desc))
+        finally:
+            gpu_ctx.set_option("pipeline", 0)
+    for a, b in zip(res[1], res[2]):
+        assert (a == b).all()
+    # and against the oracle, level by level (col0 != 0 -> offset views)
+    c, k, d = res[2]
+    for b in (0, 5, 10):
+        exp = []
+        for (w, h, r0, c0) in levels:
+            view = np.ascontiguousarray(pyr[b, r0:r0 + h].reshape(-1)[c0:])
+            pad = (-len(view)) % vstep
+            view = np.concatenate([view, np.zeros(pad, np.uint8)]).reshape(-1, vstep)
+            lkp, _, _ = orc.pyramid(view, [(w, h, 0)])
+            exp.append(lkp + np.uint32((c0 << 12) | r0))
+        exp = np.concatenate(exp)
+        assert c[b] == len(exp) and (k[b, :len(exp)] == exp).all()
+        assert (d[b, :len(exp)] == orc.orb_compute(pyr[b], exp)).all()
+
+
+def test_batch_parity_on_synthetic_pyramids(gpu_ctx, orc, pipeline):
     """bench workload (VGA 8-level x1.2, thr 20, Harris 1<<15): batch path vs oracle, bit-exact,
     incl. score maps, with and without buckets, and with a clipped keypoint capacity."""
     import torch
@@ -192,6 +277,8 @@ def test_batch_parity_on_synthetic_pyramids(gpu_ctx, orc):
     dev = torch.device("cuda:0")
     d_pyr = torch.from_numpy(pyr).to(dev)
     for lb, lim, cap in [(0, 5, 4096), (4, 3, 4096), (0, 5, 300)]:
+        if lb and pipeline == 2:
+            continue            # buckets run on the staged pipeline (auto mode falls back)
         fe = OrbFrontend(levels, vstep=640, rows=2210, max_keypoints=cap, log_bucket_size=lb, bucket_limit=lim,
                          ctx=gpu_ctx)
         kp, desc, counts = fe.alloc_outputs(B, dev)
@@ -214,7 +301,7 @@ def test_batch_parity_on_synthetic_pyramids(gpu_ctx, orc):
                 assert (sm == osc).all(), b
 
 
-def test_full_batch_properties(gpu_ctx, orc):
+def test_full_batch_properties(gpu_ctx, orc, pipeline):
     """BASELINE config 2 size (batch 256): size-independent properties — results do not depend on
     the batch slot, repeated runs are bit-identical (ordered compaction, no atomics-order), a sample
     of slots equals the oracle, every keypoint lies inside its level, list order is the reference's."""
