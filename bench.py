@@ -58,6 +58,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--pipeline", type=int, default=0, help="0 auto (fused), 1 staged, 2 fused")
     ap.add_argument("--strip-rows", type=int, default=0)
+    ap.add_argument("--ablate", type=int, default=0, help="profiling only (results invalid): fused-kernel phase mask")
     args = ap.parse_args()
 
     from pislam_amd import dist as pdist, synth
@@ -85,6 +86,7 @@ def main():
     ctx = Context(device=local_rank, stream=stream.cuda_stream)
     ctx.set_option("pipeline", args.pipeline)
     ctx.set_option("strip_rows", args.strip_rows)
+    ctx.set_option("ablate", args.ablate)
     fe = OrbFrontend(levels, vstep=640, rows=rows, max_keypoints=args.max_keypoints, ctx=ctx)
     fe.reserve(B)
     kp, desc, counts = fe.alloc_outputs(B, dev)

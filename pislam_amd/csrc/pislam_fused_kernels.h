@@ -28,7 +28,7 @@ using namespace pdev;
 
 constexpr int MAX_LEVELS = 16;
 constexpr int WAVES = 4;               // 256 threads
-constexpr int QCAP = 128;              // per-wave queue capacity (entries < 64 before a <=64 push)
+constexpr int QCAP = 320;              // per-wave queue capacity (entries < 64 before a <= 256 push)
 
 struct FusedLevel {
   int w, h;          // level size
@@ -40,6 +40,7 @@ struct FusedLevel {
   int nbx;           // 2x2 blocks per block-row
   int xend;          // one past the last classified column (Fast.h:61,149)
   int pitch;         // LDS tile pitch in bytes (multiple of 16)
+  uint32_t vpr_recip; // ceil(2^32 / (pitch/16)): row = umulhi(i, vpr_recip) for i < 2^16
 };
 
 struct FusedParams {
@@ -48,6 +49,7 @@ struct FusedParams {
   int32_t hthr;
   int batch;
   int dump_score;    // debug: also write the score tile to the HBM score map
+  int ablate;        // profiling only: bit0 stop after staging, bit1 pretest only, bit2 no Harris, bit3 no NMS
   FusedLevel lv[MAX_LEVELS];
 };
 
@@ -64,6 +66,23 @@ __device__ __forceinline__ bool fast_pretest(const uint8_t *c, int pitch, int th
   const int mx = min(max(p1, p9), max(p5, p13));
   const int mn = max(min(p1, p9), min(p5, p13));
   return (mx > v + thr) | (mn < v - thr);
+}
+
+// The same test for 4 horizontally adjacent pixels held in one dword, evaluated on packed
+// unsigned 16-bit pairs (v_pk_min/max/add/sub_u16): `ce/co` are the even/odd centre pixels
+// zero-extended to 16 bit, etc.  Returns a word whose bit 15 / bit 31 is set when the pixel in
+// the low / high half passes.
+typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ us2 as_us2(uint32_t v) { return __builtin_bit_cast(us2, v); }
+__device__ __forceinline__ uint32_t as_u32(us2 v) { return __builtin_bit_cast(uint32_t, v); }
+__device__ __forceinline__ uint32_t pretest_pk(uint32_t c, uint32_t u, uint32_t d, uint32_t l, uint32_t r,
+                                               uint32_t t2) {
+  const us2 C = as_us2(c), U = as_us2(u), D = as_us2(d), Lf = as_us2(l), Rt = as_us2(r), T = as_us2(t2);
+  const us2 a = __builtin_elementwise_min(__builtin_elementwise_max(U, D), __builtin_elementwise_max(Lf, Rt));
+  const us2 b = __builtin_elementwise_max(__builtin_elementwise_min(U, D), __builtin_elementwise_min(Lf, Rt));
+  const us2 hi = C + T, lo = C - T;            // lo may wrap negative: compared as signed 16 bit below
+  // bright: a > hi <=> (hi - a) < 0 ;  dark: b < lo <=> (b - lo) < 0   (all magnitudes < 2^10)
+  return as_u32(hi - a) | as_u32(b - lo);
 }
 
 template <bool VEC16>
@@ -104,7 +123,7 @@ __global__ __launch_bounds__(256) void k_fused_strips(
       // when col0 + pitch > vstep: flat addressing like the reference, but never past the buffer)
       const ptrdiff_t lim = (ptrdiff_t)P.rows * P.vstep - ((ptrdiff_t)L.row0 * P.vstep + L.col0);
       for (int i = tid; i < nrows * vpr; i += 256) {
-        const int r = i / vpr, v = i - r * vpr;
+        const int r = (int)__umulhi((uint32_t)i, L.vpr_recip), v = i - r * vpr;
         const ptrdiff_t off = (ptrdiff_t)(y_lo + r) * P.vstep + 16 * v;
         uint4 d;
         if (off + 16 <= lim) {
@@ -129,8 +148,9 @@ __global__ __launch_bounds__(256) void k_fused_strips(
   }
   __syncthreads();
 
+  if (P.ablate & 1) return;
   const int lane = lane_id();
-  const int wave = tid >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform (keeps loops scalar)
   uint32_t *qf = queues + wave * (2 * QCAP);        // FAST candidates
   uint32_t *qh = qf + QCAP;                         // corners awaiting their Harris score
   int nf = 0, nh = 0;                               // wave-uniform queue fills
@@ -157,27 +177,62 @@ __global__ __launch_bounds__(256) void k_fused_strips(
       nh += __popcll(m);
       if (nh >= 64) {
         nh -= 64;
-        harris_batch(true, qh[nh + lane]);
+        if (!(P.ablate & 4)) harris_batch(true, qh[nh + lane]);
       }
     }
   };
 
   const int r_lo = (ys - 1 < B) ? 1 : 0;                          // rows above B are never classified
   const int r_hi = min(ye + 2, L.h - B) - (ys - 1);               // exclusive
+  const uint32_t t2 = (uint32_t)thr * 0x00010001u;
+  const int xs = B & ~3;                                           // dword-aligned start column
+  const bool aligned4 = ((B | L.xend) & 3) == 0;
   for (int r = r_lo + wave; r < r_hi; r += WAVES) {
     const uint8_t *trow = tile + (r + 3) * pitch;
-    for (int cx = B; cx < L.xend; cx += 64) {
-      const int x = cx + lane;
-      bool cand = false;
-      if (x < L.xend && !(wmod && (x == L.w || x == L.w + 1))) cand = fast_pretest(trow + x, pitch, thr);
-      const uint64_t m = __ballot(cand);
-      if (m) {
-        if (cand) qf[nf + ballot_rank(m)] = pack_xy(x, r);
-        nf += __popcll(m);
-        if (nf >= 64) {
-          nf -= 64;
-          fast_batch(true, qf[nf + lane]);
-        }
+    for (int cx = xs; cx < L.xend; cx += 256) {
+      const int x0 = cx + 4 * lane;
+      // aligned dword reads; lanes past the row end read harmless bytes of the next tile row
+      const uint32_t wc = *(const uint32_t *)(trow + x0);
+      const uint32_t wl = *(const uint32_t *)(trow + x0 - 4);
+      const uint32_t wr = *(const uint32_t *)(trow + x0 + 4);
+      const uint32_t wu = *(const uint32_t *)(trow + x0 - 3 * pitch);
+      const uint32_t wd = *(const uint32_t *)(trow + x0 + 3 * pitch);
+      // even pixels (x0, x0+2) and odd pixels (x0+1, x0+3), zero-extended to 16 bit by v_perm_b32
+      const uint32_t re = pretest_pk(__builtin_amdgcn_perm(0, wc, 0x0c020c00u), __builtin_amdgcn_perm(0, wu, 0x0c020c00u),
+                                     __builtin_amdgcn_perm(0, wd, 0x0c020c00u),
+                                     __builtin_amdgcn_perm(wc, wl, 0x0c030c01u),      // x-3: l.b1, l.b3
+                                     __builtin_amdgcn_perm(wr, wc, 0x0c050c03u), t2); // x+3: c.b3, r.b1
+      const uint32_t ro = pretest_pk(__builtin_amdgcn_perm(0, wc, 0x0c030c01u), __builtin_amdgcn_perm(0, wu, 0x0c030c01u),
+                                     __builtin_amdgcn_perm(0, wd, 0x0c030c01u),
+                                     __builtin_amdgcn_perm(wc, wl, 0x0c040c02u),      // x-3: l.b2, c.b0
+                                     __builtin_amdgcn_perm(wr, wc, 0x0c060c04u), t2); // x+3: r.b0, r.b2
+      uint32_t fe = re & 0x80008000u, fo = ro & 0x80008000u;
+      if (aligned4) {                      // B and xend multiples of 4: a lane is all-in or all-out
+        if (x0 >= L.xend) fe = fo = 0;
+      } else {                             // generic border: mask the pixels outside [B, xend)
+        if (x0 + 0 < B || x0 + 0 >= L.xend) fe &= ~0x00008000u;
+        if (x0 + 1 < B || x0 + 1 >= L.xend) fo &= ~0x00008000u;
+        if (x0 + 2 < B || x0 + 2 >= L.xend) fe &= ~0x80000000u;
+        if (x0 + 3 < B || x0 + 3 >= L.xend) fo &= ~0x80000000u;
+      }
+      if (__ballot((fe | fo) != 0) == 0) continue;
+      const uint32_t key = pack_xy(x0, r);
+      {
+        const uint64_t m0 = __ballot((fe & 0x8000u) != 0), m1 = __ballot((fo & 0x8000u) != 0);
+        const uint64_t m2 = __ballot((int32_t)fe < 0), m3 = __ballot((int32_t)fo < 0);
+        uint32_t *q = qf + nf;
+        if (fe & 0x8000u) q[ballot_rank(m0)] = key;
+        q += __popcll(m0);
+        if (fo & 0x8000u) q[ballot_rank(m1)] = key + 1;
+        q += __popcll(m1);
+        if ((int32_t)fe < 0) q[ballot_rank(m2)] = key + 2;
+        q += __popcll(m2);
+        if ((int32_t)fo < 0) q[ballot_rank(m3)] = key + 3;
+        nf += __popcll(m0) + __popcll(m1) + __popcll(m2) + __popcll(m3);
+      }
+      while (nf >= 64) {
+        nf -= 64;
+        if (!(P.ablate & 2)) fast_batch(true, qf[nf + lane]);
       }
     }
   }
@@ -193,17 +248,38 @@ __global__ __launch_bounds__(256) void k_fused_strips(
     }
   }
 
+  if (P.ablate & 8) return;
   // ---- phase D: NMS, block-raster order.  Pass 0 counts per block-row, pass 1 scatters. ----
   __shared__ uint32_t rowcnt[64];
   const int nbr = (ye - ys + 1) >> 1;               // block rows in this strip
+  const int xlim = L.w - B;                         // block origins are x = B, B+2, ... < xlim
+  // One lane looks at 4 score columns x 2 rows = two horizontally adjacent 2x2 blocks with two
+  // aligned dword reads; an all-zero pair (the overwhelmingly common case) is done (Fast.h:237).
+  auto nms_pair = [&](const uint8_t *srow, int x0, int y, uint32_t &ra, uint32_t &rb) {
+    ra = rb = 0;
+    const uint32_t m = *(const uint32_t *)(srow + x0) | *(const uint32_t *)(srow + pitch + x0);
+    if (m != 0) {
+      if ((m & 0xffffu) && x0 < xlim) ra = nms_block(srow + x0, pitch, x0, y);
+      if ((m >> 16) && x0 + 2 < xlim) rb = nms_block(srow + x0 + 2, pitch, x0 + 2, y);
+    }
+  };
+  const bool pairs = (B & 3) == 0;                  // block origins dword-aligned in pairs
   for (int br = wave; br < nbr; br += WAVES) {
     const uint8_t *srow = sc + (2 * br + 1) * pitch;
     uint32_t cnt = 0;
-    for (int bx0 = 0; bx0 < L.nbx; bx0 += 64) {
-      const int bx = bx0 + lane;
-      uint32_t res = 0;
-      if (bx < L.nbx) res = nms_block(srow + B + 2 * bx, pitch, B + 2 * bx, ys + 2 * br);
-      cnt += __popcll(__ballot(res != 0));
+    if (pairs) {
+      for (int x0 = B + 4 * lane; x0 - 4 * lane < xlim; x0 += 256) {
+        uint32_t ra, rb;
+        nms_pair(srow, x0, ys + 2 * br, ra, rb);
+        cnt += __popcll(__ballot(ra != 0)) + __popcll(__ballot(rb != 0));
+      }
+    } else {
+      for (int bx0 = 0; bx0 < L.nbx; bx0 += 64) {
+        const int bx = bx0 + lane;
+        uint32_t res = 0;
+        if (bx < L.nbx) res = nms_block(srow + B + 2 * bx, pitch, B + 2 * bx, ys + 2 * br);
+        cnt += __popcll(__ballot(res != 0));
+      }
     }
     if (lane == 0) rowcnt[br] = cnt;
   }
@@ -211,17 +287,32 @@ __global__ __launch_bounds__(256) void k_fused_strips(
   const size_t strip_slot = (size_t)pyr * P.slots_per_pyr + L.slot0 + (size_t)s * (L.R >> 1) * L.nbx;
   const uint32_t add_xy = ((uint32_t)L.col0 << 12) | (uint32_t)L.row0;      // README.md:78
   for (int br = wave; br < nbr; br += WAVES) {
+    if (rowcnt[br] == 0) continue;
     uint32_t off = 0;
     for (int k = 0; k < br; k++) off += rowcnt[k];
-    if (rowcnt[br] == 0) continue;
     const uint8_t *srow = sc + (2 * br + 1) * pitch;
-    for (int bx0 = 0; bx0 < L.nbx; bx0 += 64) {
-      const int bx = bx0 + lane;
-      uint32_t res = 0;
-      if (bx < L.nbx) res = nms_block(srow + B + 2 * bx, pitch, B + 2 * bx, ys + 2 * br);
-      const uint64_t m = __ballot(res != 0);
-      if (res) stage_kp[strip_slot + off + ballot_rank(m)] = res + add_xy;
-      off += __popcll(m);
+    uint32_t *dst = stage_kp + strip_slot;
+    if (pairs) {
+      for (int x0 = B + 4 * lane; x0 - 4 * lane < xlim; x0 += 256) {
+        uint32_t ra, rb;
+        nms_pair(srow, x0, ys + 2 * br, ra, rb);
+        const uint64_t ma = __ballot(ra != 0), mb = __ballot(rb != 0);
+        if ((ma | mb) == 0) continue;
+        // raster order inside the row: lane-major, then the left block before the right one
+        const uint32_t pos = off + ballot_rank(ma) + ballot_rank(mb);
+        if (ra) dst[pos] = ra + add_xy;
+        if (rb) dst[pos + (ra != 0)] = rb + add_xy;
+        off += __popcll(ma) + __popcll(mb);
+      }
+    } else {
+      for (int bx0 = 0; bx0 < L.nbx; bx0 += 64) {
+        const int bx = bx0 + lane;
+        uint32_t res = 0;
+        if (bx < L.nbx) res = nms_block(srow + B + 2 * bx, pitch, B + 2 * bx, ys + 2 * br);
+        const uint64_t m = __ballot(res != 0);
+        if (res) dst[off + ballot_rank(m)] = res + add_xy;
+        off += __popcll(m);
+      }
     }
   }
   if (tid == 0) {
@@ -282,6 +373,175 @@ __global__ __launch_bounds__(256) void k_gather(const FusedParams P,
       const uint32_t pos = soff[st] + k;
       if (pos < cap) kp[(size_t)pyr * kp_stride + pos] = stage_kp[slot + k];
     }
+  }
+}
+
+
+// ===========================================================================
+// k_gather_orb — strip offsets -> final keypoint order, then orbCompute on them.
+//
+// grid (NCH, batch): workgroup (ch, pyr) owns keypoints [ch*per, (ch+1)*per) of pyramid pyr.
+// Every workgroup redoes the (tiny) exclusive scan of the pyramid's strip counts, pulls its
+// range of keypoints out of the strip staging buffer into LDS (and writes them to the final
+// keypoint array), then describes them, TWO keypoints per wave iteration (one per half-wave):
+//   lane r of a half owns patch row dy = r-15: 9 dword loads + v_alignbyte funnel shift give the
+//   32 bytes x-15..x+16 dword-aligned; the circle mask (Orb.h:118-121,163-286) is a per-lane
+//   constant; the moments are v_dot4_u32_u8 dot products with the |dx| weights (Orb.h:123-126);
+//   the rows are summed across the 32 lanes; every lane evaluates the angle bin (Orb.h:310-387);
+//   the aligned rows are parked in LDS and the 256 BRIEF tests (Brief.h:52) read them back,
+//   32 pairs per half-wave per round, one ballot = one descriptor word for each keypoint.
+// ===========================================================================
+constexpr int ORB_PATCH_BYTES = 32 * 32;            // 31 rows x 32 B, padded to 32 rows
+
+template <bool VEC_UNUSED = false>
+__device__ __forceinline__ int half_sum(int v) {
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);   // stays inside each 32-lane half
+  return v;
+}
+
+__global__ __launch_bounds__(256) void k_gather_orb(
+    const FusedParams P, const uint8_t *__restrict__ pyramids, size_t pyr_stride,
+    const uint32_t *__restrict__ stage_kp, const uint32_t *__restrict__ strip_count,
+    uint32_t *__restrict__ kp, size_t kp_stride, uint32_t cap, uint32_t *__restrict__ counts,
+    uint32_t *__restrict__ desc, size_t desc_stride, int words) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t osm[];
+  __shared__ uint32_t wsum[4];
+  __shared__ uint32_t carry;
+  const int pyr = blockIdx.y, ch = blockIdx.x, nch = gridDim.x;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int S = P.strips_per_pyr;
+  // LDS carve: patches (4 waves x 2 x 1 KiB) | strip offsets (S+1) | this chunk's keypoints
+  uint8_t *patches = osm;
+  uint32_t *soff = (uint32_t *)(osm + WAVES * 2 * ORB_PATCH_BYTES);
+  uint32_t *kpl = soff + ((S + 1 + 3) & ~3);
+
+  // ---- exclusive scan of the strip counts (strip order = reference push_back order) ----
+  const uint32_t *cnt = strip_count + (size_t)pyr * S;
+  if (tid == 0) carry = 0;
+  __syncthreads();
+  for (int base = 0; base < S; base += 256) {
+    const int i = base + tid;
+    const uint32_t v = i < S ? cnt[i] : 0;
+    uint32_t incl = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint32_t t = (uint32_t)__shfl_up((int)incl, d, 64);
+      if (lane >= d) incl += t;
+    }
+    if (lane == 63) wsum[wv] = incl;
+    __syncthreads();
+    uint32_t pre = carry;
+    for (int w = 0; w < wv; w++) pre += wsum[w];
+    if (i < S) soff[i] = pre + incl - v;
+    __syncthreads();
+    if (tid == 255) carry = pre + incl;
+    __syncthreads();
+  }
+  const uint32_t total = carry;
+  if (tid == 0) {
+    soff[S] = total;
+    if (ch == 0) counts[pyr] = total;
+  }
+  __syncthreads();
+  const uint32_t nkp = min(total, cap);
+  const uint32_t per = (nkp + nch - 1) / nch;        // <= ceil(cap / nch): the size kpl was carved for
+  const uint32_t lo = min((uint32_t)ch * per, nkp), hi = min(lo + per, nkp);
+  if (lo >= hi) return;
+
+  // ---- pull this chunk's keypoints out of the staging buffer ----
+  for (int st = wv; st < S; st += WAVES) {
+    const uint32_t s0 = soff[st], s1 = soff[st + 1];
+    if (s1 <= lo || s0 >= hi || s1 == s0) continue;
+    int li = 0;
+    while (li + 1 < P.nlevels && st >= P.lv[li + 1].strip0) li++;
+    const FusedLevel &L = P.lv[li];
+    const size_t slot = (size_t)pyr * P.slots_per_pyr + L.slot0 + (size_t)(st - L.strip0) * (L.R >> 1) * L.nbx;
+    for (uint32_t k = lane; k < s1 - s0; k += 64) {
+      const uint32_t pos = s0 + k;
+      if (pos >= lo && pos < hi) {
+        const uint32_t v = stage_kp[slot + k];
+        kpl[pos - lo] = v;
+        kp[(size_t)pyr * kp_stride + pos] = v;
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- describe: two keypoints per wave iteration ----
+  const uint8_t *im = pyramids + (size_t)pyr * pyr_stride;
+  const ptrdiff_t img_bytes = (ptrdiff_t)P.rows * P.vstep;
+  const int half = lane >> 5, r = lane & 31;          // r = patch row index, dy = r - 15 (r = 31 idle)
+  const int dy = r - 15;
+  // per-lane circle mask for its row: byte j of the 32 covers dx = j - 15
+  uint32_t cmask[8];
+  {
+    const int u = (r < 31) ? patch_umax(dy < 0 ? -dy : dy) : -1;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      uint32_t m = 0;
+#pragma unroll
+      for (int b = 0; b < 4; b++) {
+        const int dx = 4 * k + b - 15, adx = dx < 0 ? -dx : dx;
+        if (adx <= u) m |= 0xffu << (8 * b);
+      }
+      cmask[k] = m;
+    }
+  }
+  uint8_t *patch = patches + (wv * 2 + half) * ORB_PATCH_BYTES;
+  uint32_t *dsc = desc + (size_t)pyr * desc_stride;
+  const uint32_t npairs = (hi - lo + 1) >> 1;
+  for (uint32_t it = wv; it < npairs; it += WAVES) {
+    const uint32_t idx = lo + 2 * it + half;                       // this half-wave's keypoint
+    const bool valid = idx < hi;
+    const uint32_t p = kpl[valid ? idx - lo : 0];
+    const int x = decode_x(p), y = decode_y(p);
+    // row start (x-15) of row y+dy, dword aligned + funnel shift
+    const ptrdiff_t start = (ptrdiff_t)(y + dy) * P.vstep + (x - 15);
+    const ptrdiff_t a0 = start & ~(ptrdiff_t)3;
+    const uint32_t sh = (uint32_t)(start & 3);
+    uint32_t in[9];
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+      const ptrdiff_t a = a0 + 4 * k;
+      in[k] = (valid && r < 31 && a >= 0 && a + 4 <= img_bytes) ? *(const uint32_t *)(im + a) : 0u;
+    }
+    uint32_t row[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) row[k] = __builtin_amdgcn_alignbyte(in[k + 1], in[k], sh);
+    // park the aligned row for the BRIEF gathers
+    *(uint4 *)(patch + r * 32) = make_uint4(row[0], row[1], row[2], row[3]);
+    *(uint4 *)(patch + r * 32 + 16) = make_uint4(row[4], row[5], row[6], row[7]);
+    // moments of this row: sum v and sum |dx| v, left (dx<0) and right (dx>0) separately
+    uint32_t sv = 0, left = 0, right = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      const uint32_t v = row[k] & cmask[k];
+      sv = __builtin_amdgcn_udot4(v, 0x01010101u, sv, false);
+    }
+    left = __builtin_amdgcn_udot4(row[0] & cmask[0], 0x0c0d0e0fu, left, false);    // dx -15..-12
+    left = __builtin_amdgcn_udot4(row[1] & cmask[1], 0x08090a0bu, left, false);    // dx -11..-8
+    left = __builtin_amdgcn_udot4(row[2] & cmask[2], 0x04050607u, left, false);    // dx  -7..-4
+    left = __builtin_amdgcn_udot4(row[3] & cmask[3], 0x00010203u, left, false);    // dx  -3..0
+    right = __builtin_amdgcn_udot4(row[4] & cmask[4], 0x04030201u, right, false);  // dx   1..4
+    right = __builtin_amdgcn_udot4(row[5] & cmask[5], 0x08070605u, right, false);  // dx   5..8
+    right = __builtin_amdgcn_udot4(row[6] & cmask[6], 0x0c0b0a09u, right, false);  // dx   9..12
+    right = __builtin_amdgcn_udot4(row[7] & cmask[7], 0x000f0e0du, right, false);  // dx  13..15 (16 masked)
+    const int m10 = half_sum((int)right - (int)left);
+    const int m01 = half_sum(dy * (int)sv);
+    const uint32_t rot = angle_bin(m10, m01);
+    // BRIEF: pair k = 32*round + r of this half's keypoint -> bit r of word `round`
+    const uint32_t *tab = ::g_brief_ofs.v + rot * 256 + r;   // defined by the including TU
+    uint32_t myword = 0;
+    for (int round = 0; round < words; round++) {
+      const uint32_t e = tab[32 * round];
+      const uint32_t a = patch[e & 0xffffu], b = patch[e >> 16];
+      const uint64_t m = __ballot(a < b);                           // Brief.h:52
+      const uint32_t w = half ? (uint32_t)(m >> 32) : (uint32_t)m;
+      if (r == round) myword = w;
+    }
+    if (valid && r < words) dsc[(size_t)idx * words + r] = myword;
   }
 }
 

@@ -17,9 +17,25 @@
 __device__ const uint32_t g_brief_tab[30 * 256] = {
 #include "brief_table.inc"
 };
-static const uint32_t h_brief_tab_packed[30 * 256] = {
+static constexpr uint32_t h_brief_tab_packed[30 * 256] = {
 #include "brief_table.inc"
 };
+// The same table as byte offsets into a 32-byte-pitch LDS patch whose row 15 / column 15 is the
+// keypoint: ofs = (dy+15)*32 + (dx+15); low half = first sample point, high half = second.
+struct BriefOfsTab {
+  uint32_t v[30 * 256];
+};
+static constexpr BriefOfsTab make_brief_ofs() {
+  BriefOfsTab t{};
+  for (int i = 0; i < 30 * 256; i++) {
+    const uint32_t e = h_brief_tab_packed[i];
+    const int dx0 = (int8_t)(e & 0xff), dy0 = (int8_t)((e >> 8) & 0xff);
+    const int dx1 = (int8_t)((e >> 16) & 0xff), dy1 = (int8_t)(e >> 24);
+    t.v[i] = (uint32_t)((dy0 + 15) * 32 + dx0 + 15) | ((uint32_t)((dy1 + 15) * 32 + dx1 + 15) << 16);
+  }
+  return t;
+}
+__device__ const BriefOfsTab g_brief_ofs = make_brief_ofs();
 
 #include "pislam_stage_kernels.h"
 #include "pislam_fused_kernels.h"
@@ -71,6 +87,8 @@ struct pislam_ctx {
   int opt_pipeline = 0;      // 0 auto, 1 staged (one launch group per level), 2 fused strips
   int opt_dump_score = 0;    // fused pipeline: also materialise the score map (parity hook)
   int opt_strip_rows = 0;    // fused pipeline: strip height override (0 = heuristic)
+  int opt_ablate = 0;        // profiling only: skip phases of the fused kernel (results invalid)
+  int opt_orb_chunks = 0;    // fused pipeline: workgroups per pyramid in k_gather_orb (0 = heuristic)
   int last_pipeline = 0;
   size_t score_bytes_valid = 0;   // bytes of w_score known to be in a consistent (zero-border) state
   pislam_frontend_params last_params{};
@@ -362,6 +380,11 @@ PISLAM_EXPORT int pislam_ctx_set_option(pislam_ctx *c, const char *key, int valu
     c->opt_pipeline = value;
   } else if (!strcmp(key, "dump_score")) {
     c->opt_dump_score = value != 0;
+  } else if (!strcmp(key, "orb_chunks")) {
+    if (value < 0 || value > 1024) return fail(c, PISLAM_ERR_INVALID, "orb_chunks must be 0..1024");
+    c->opt_orb_chunks = value;
+  } else if (!strcmp(key, "ablate")) {
+    c->opt_ablate = value;
   } else if (!strcmp(key, "strip_rows")) {
     if (value < 0 || value > 64 || (value & 1)) return fail(c, PISLAM_ERR_INVALID, "strip_rows must be even, 0..64");
     c->opt_strip_rows = value;
@@ -607,6 +630,7 @@ bool build_fused_plan(const pislam_ctx *c, const pislam_frontend_params *p, cons
   F->hthr = p->harris_threshold;
   F->batch = batch;
   F->dump_score = c->opt_dump_score;
+  F->ablate = c->opt_ablate;
   int strips = 0, slots = 0;
   size_t lds = 0;
   for (int l = 0; l < p->nlevels; l++) {
@@ -636,6 +660,7 @@ bool build_fused_plan(const pislam_ctx *c, const pislam_frontend_params *p, cons
     L.nbx = (nx + 1) / 2;
     L.xend = p->border + 16 * cdiv(nx, 16);
     L.pitch = (L.xend + 4 + 15) & ~15;
+    L.vpr_recip = (uint32_t)(((1ull << 32) + (L.pitch / 16) - 1) / (L.pitch / 16));
     strips += L.nstrips;
     slots += L.nstrips * (R / 2) * L.nbx;
     lds = std::max(lds, (size_t)(2 * R + 13) * L.pitch + pf::WAVES * 2 * pf::QCAP * sizeof(uint32_t));
@@ -647,7 +672,7 @@ bool build_fused_plan(const pislam_ctx *c, const pislam_frontend_params *p, cons
 }
 
 int run_fused(pislam_ctx *c, const pislam_frontend_params *p, const pf::FusedParams &F, size_t lds,
-              const uint8_t *pyramids, size_t stride, int batch, uint32_t *kp, uint32_t *counts) {
+              const uint8_t *pyramids, size_t stride, int batch, uint32_t *kp, uint32_t *desc, uint32_t *counts) {
   if (c->w_stage.ensure(sizeof(uint32_t) * (size_t)F.slots_per_pyr * batch) != PISLAM_OK ||
       c->w_stripcnt.ensure(sizeof(uint32_t) * (size_t)F.strips_per_pyr * batch) != PISLAM_OK)
     return fail(c, PISLAM_ERR_NOMEM, "hipMalloc(fused staging)");
@@ -665,11 +690,19 @@ int run_fused(pislam_ctx *c, const pislam_frontend_params *p, const pf::FusedPar
                      c->w_stripcnt.as<uint32_t>(), dump, dump_stride);
   PCHK(launch_ok(c, "k_fused_strips"));
   HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
-  hipLaunchKernelGGL(pf::k_gather, dim3(batch), dim3(256), sizeof(uint32_t) * (F.strips_per_pyr + 1), c->stream,
-                     F, c->w_stage.as<uint32_t>(), c->w_stripcnt.as<uint32_t>(), kp, (size_t)p->max_keypoints,
-                     (uint32_t)p->max_keypoints, counts);
-  PCHK(launch_ok(c, "k_gather"));
   HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
+  // gather + orbCompute in one launch: (chunks, batch) workgroups
+  int nch = c->opt_orb_chunks > 0 ? c->opt_orb_chunks : std::min(64, std::max(8, 2048 / batch));
+  const size_t per_max = ((size_t)p->max_keypoints + nch - 1) / nch;
+  size_t olds = (size_t)pf::WAVES * 2 * pf::ORB_PATCH_BYTES + sizeof(uint32_t) * (((size_t)F.strips_per_pyr + 1 + 3) & ~(size_t)3) +
+                sizeof(uint32_t) * per_max;
+  if (olds > 150 * 1024) return fail(c, PISLAM_ERR_INVALID, "max_keypoints too large for the fused ORB kernel");
+  if (olds > 64 * 1024)
+    HIPCHK(c, hipFuncSetAttribute((const void *)pf::k_gather_orb, hipFuncAttributeMaxDynamicSharedMemorySize, (int)olds));
+  hipLaunchKernelGGL(pf::k_gather_orb, dim3(nch, batch), dim3(256), olds, c->stream, F, pyramids, stride,
+                     c->w_stage.as<uint32_t>(), c->w_stripcnt.as<uint32_t>(), kp, (size_t)p->max_keypoints,
+                     (uint32_t)p->max_keypoints, counts, desc, (size_t)p->max_keypoints * p->words, p->words);
+  PCHK(launch_ok(c, "k_gather_orb"));
   return PISLAM_OK;
 }
 
@@ -734,7 +767,7 @@ PISLAM_EXPORT int pislam_orb_frontend_batch(pislam_ctx *c, const pislam_frontend
   c->last_pipeline = fused ? 2 : 1;
   HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
   if (fused) {
-    PCHK(run_fused(c, p, F, lds, pyramids, stride, batch, kp, counts));
+    PCHK(run_fused(c, p, F, lds, pyramids, stride, batch, kp, desc, counts));
   } else {
   HIPCHK(c, hipMemsetAsync(counts, 0, sizeof(uint32_t) * batch, c->stream));
   // The score map workspace is laid out with stride pyr_bytes; the image with `stride`.  The stage
@@ -766,11 +799,13 @@ PISLAM_EXPORT int pislam_orb_frontend_batch(pislam_ctx *c, const pislam_frontend
   }
   HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
   }
-  hipLaunchKernelGGL(pk::k_orb<0>, dim3(cdiv(p->max_keypoints, 4), 1, batch), dim3(256), 0, c->stream,
-                     pyramids, p->vstep, stride, kp, (size_t)p->max_keypoints, counts, 0u,
-                     (uint32_t)p->max_keypoints, p->words, desc, (size_t)p->max_keypoints * p->words,
-                     (int32_t *)nullptr, (const uint8_t *)nullptr);
-  PCHK(launch_ok(c, "k_orb<batch>"));
+  if (!fused) {
+    hipLaunchKernelGGL(pk::k_orb<0>, dim3(cdiv(p->max_keypoints, 4), 1, batch), dim3(256), 0, c->stream,
+                       pyramids, p->vstep, stride, kp, (size_t)p->max_keypoints, counts, 0u,
+                       (uint32_t)p->max_keypoints, p->words, desc, (size_t)p->max_keypoints * p->words,
+                       (int32_t *)nullptr, (const uint8_t *)nullptr);
+    PCHK(launch_ok(c, "k_orb<batch>"));
+  }
   HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
   c->timing_valid = true;
   return PISLAM_OK;
