@@ -26,9 +26,22 @@ namespace pf {
 
 using namespace pdev;
 
+// Explicit LDS (address space 3) pointer types: with queues, lambdas and selects in play the
+// compiler's address-space inference gives up and falls back to FLAT loads, which are several
+// times slower than ds_read.  Typed pointers keep every tile / queue access a DS instruction.
+typedef __attribute__((address_space(3))) uint8_t lds_u8;
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));   // plain clang vector (uint4 is a class)
+typedef __attribute__((address_space(3))) u32x4 lds_u4;
+
 constexpr int MAX_LEVELS = 16;
 constexpr int WAVES = 4;               // 256 threads
-constexpr int QCAP = 320;              // per-wave queue capacity (entries < 64 before a <= 256 push)
+constexpr int QCAP_G = 128;            // 4-pixel groups that passed the SAD prefilter (< 64 before a <= 64 push)
+constexpr int QCAP_F = 320;            // FAST candidates (< 64 before a <= 256 push)
+constexpr int QCAP = QCAP_G + QCAP_F;  // dwords of private queue space per wave
+constexpr int QH_SHARED = 512;         // workgroup-shared queue of corners awaiting their Harris score
+constexpr int QFL_SHARED = 256;        // workgroup-shared queue of the waves' left-over FAST candidates
+constexpr int SHARED_Q = QH_SHARED + QFL_SHARED;
 
 struct FusedLevel {
   int w, h;          // level size
@@ -85,6 +98,16 @@ __device__ __forceinline__ uint32_t pretest_pk(uint32_t c, uint32_t u, uint32_t 
   return as_u32(hi - a) | as_u32(b - lo);
 }
 
+// Rare path (shared corner queue full): score the flagged lanes right away.  Kept out of line so
+// that the hot loops of the kernel do not carry a second inlined copy of the Harris arithmetic.
+__device__ __attribute__((noinline)) void harris_overflow(lds_u8 *tile, lds_u8 *sc, int pitch, int32_t hthr,
+                                                          bool valid, uint32_t e) {
+  if (valid) {
+    const int x = e & 0xffff, r = e >> 16;
+    sc[r * pitch + x] = harris_score(tile + (r + 3) * pitch + x, pitch, hthr);
+  }
+}
+
 template <bool VEC16>
 __global__ __launch_bounds__(256) void k_fused_strips(
     const FusedParams P, const uint8_t *__restrict__ pyramids, size_t pyr_stride,
@@ -106,12 +129,18 @@ __global__ __launch_bounds__(256) void k_fused_strips(
   const int ye = min(ys + L.R, L.h - B);            // one past the last row owned
   const int pitch = L.pitch;
   const int trows = L.R + 10;                       // image tile rows  [ys-4, ys+R+6)
-  uint8_t *tile = smem;
-  uint8_t *sc = smem + trows * pitch;               // score tile rows  [ys-1, ys+R+2)
-  uint32_t *queues = (uint32_t *)(sc + (L.R + 3) * pitch);
+  lds_u8 *tile = (lds_u8 *)smem;
+  lds_u8 *sc = tile + trows * pitch;                // score tile rows  [ys-1, ys+R+2)
+  lds_u32 *queues = (lds_u32 *)(sc + (L.R + 3) * pitch);
 
   const uint8_t *im = pyramids + (size_t)pyr * pyr_stride + (size_t)L.row0 * P.vstep + L.col0;
   const int tid = threadIdx.x;
+  __shared__ uint32_t sh_ctr[4];                    // [0] corners queued, [1] first overflowed slot, [2] left-over candidates
+  if (tid == 0) {
+    sh_ctr[0] = 0;
+    sh_ctr[1] = QH_SHARED;
+    sh_ctr[2] = 0;
+  }
 
   // ---- stage the image rows [ys-4, min(ye+6, h)) and clear the score tile ---------------
   {
@@ -125,15 +154,17 @@ __global__ __launch_bounds__(256) void k_fused_strips(
       for (int i = tid; i < nrows * vpr; i += 256) {
         const int r = (int)__umulhi((uint32_t)i, L.vpr_recip), v = i - r * vpr;
         const ptrdiff_t off = (ptrdiff_t)(y_lo + r) * P.vstep + 16 * v;
-        uint4 d;
+        u32x4 d;
         if (off + 16 <= lim) {
-          d = *(const uint4 *)(im + off);
+          d = *(const u32x4 *)(im + off);
         } else {
-          uint8_t t[16];
-          for (int k = 0; k < 16; k++) t[k] = off + k < lim ? im[off + k] : (uint8_t)0;
-          d = *(const uint4 *)t;
+          uint32_t w4[4] = {0, 0, 0, 0};          // tail of the buffer: byte-wise, zero beyond the end
+#pragma unroll
+          for (int k = 0; k < 16; k++)
+            if (off + k < lim) w4[k >> 2] |= (uint32_t)im[off + k] << (8 * (k & 3));
+          d = (u32x4){w4[0], w4[1], w4[2], w4[3]};
         }
-        *(uint4 *)(tile + r * pitch + 16 * v) = d;
+        *(lds_u4 *)(tile + r * pitch + 16 * v) = d;
       }
     } else {
       const ptrdiff_t lim = (ptrdiff_t)P.rows * P.vstep - ((ptrdiff_t)L.row0 * P.vstep + L.col0);
@@ -144,24 +175,35 @@ __global__ __launch_bounds__(256) void k_fused_strips(
       }
     }
     const int nz = ((L.R + 3) * pitch) >> 4;
-    for (int i = tid; i < nz; i += 256) ((uint4 *)sc)[i] = make_uint4(0, 0, 0, 0);
+    for (int i = tid; i < nz; i += 256) ((lds_u4 *)sc)[i] = (u32x4)(0u);
   }
   __syncthreads();
 
   if (P.ablate & 1) return;
   const int lane = lane_id();
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform (keeps loops scalar)
-  uint32_t *qf = queues + wave * (2 * QCAP);        // FAST candidates
-  uint32_t *qh = qf + QCAP;                         // corners awaiting their Harris score
-  int nf = 0, nh = 0;                               // wave-uniform queue fills
+  lds_u32 *qg = queues + wave * QCAP;              // 4-pixel groups for the exact pretest
+  lds_u32 *qf = qg + QCAP_G;                       // FAST candidates
+  // Corners are rare (~1 % of the pixels): a private queue per wave would end in a mostly empty
+  // 64-lane Harris batch per wave, so corners go to ONE queue per workgroup (LDS atomic append)
+  // and are scored by all waves together once FAST is finished.  The waves' left-over FAST
+  // candidates (< 64 each) are merged the same way.
+  lds_u32 *shq_h = queues + WAVES * QCAP;
+  lds_u32 *shq_fl = shq_h + QH_SHARED;
+  int ng = 0, nf = 0;                               // wave-uniform queue fills
+  // NOTE: the lambdas below capture by reference; they must only touch LOCAL copies of kernel
+  // arguments — capturing `P` itself makes the compiler spill the whole 800-byte struct to scratch.
   const int thr = P.thr;
-  const bool wmod = (L.w & 15) != 0;
+  const int32_t hthr = P.hthr;
+  const int ablate = P.ablate;
+  const int Lw = L.w, Lxend = L.xend, Lh = L.h;
+  const bool wmod = (Lw & 15) != 0;
 
   // score rows r = 0 .. R+2  <->  level rows ys-1+r ; image tile row of level row y is y-(ys-4)
   auto harris_batch = [&](bool valid, uint32_t e) {
     if (valid) {
       const int x = e & 0xffff, r = e >> 16;
-      sc[r * pitch + x] = harris_score(tile + (r + 3) * pitch + x, pitch, P.hthr);
+      sc[r * pitch + x] = (ablate & 32) ? (uint8_t)200 : harris_score(tile + (r + 3) * pitch + x, pitch, hthr);
     }
   };
   auto fast_batch = [&](bool valid, uint32_t e) {
@@ -169,95 +211,139 @@ __global__ __launch_bounds__(256) void k_fused_strips(
     const int x = e & 0xffff, r = e >> 16;
     if (valid) corner = fast9(tile + (r + 3) * pitch + x, pitch, thr);
     // Fast.h:172: only x < w-B is scored; over-classified columns keep 0xff
-    const bool toh = corner && x < L.w - B;
+    const bool toh = corner && x < Lw - B;
     if (corner && !toh) sc[r * pitch + x] = 0xff;
     const uint64_t m = __ballot(toh);
     if (m) {
-      if (toh) qh[nh + ballot_rank(m)] = e;
-      nh += __popcll(m);
-      if (nh >= 64) {
-        nh -= 64;
-        if (!(P.ablate & 4)) harris_batch(true, qh[nh + lane]);
+      const int cnt = __popcll(m);
+      int base = 0;
+      if (lane == 0) base = (int)atomicAdd(&sh_ctr[0], (uint32_t)cnt);
+      base = __builtin_amdgcn_readfirstlane(base);
+      if (base + cnt <= QH_SHARED) {
+        if (toh) shq_h[base + ballot_rank(m)] = e;
+      } else {                                     // queue full: score these right away
+        if (lane == 0) atomicMin(&sh_ctr[1], (uint32_t)base);
+        harris_overflow(tile, sc, pitch, hthr, toh, e);
       }
     }
   };
 
   const int r_lo = (ys - 1 < B) ? 1 : 0;                          // rows above B are never classified
-  const int r_hi = min(ye + 2, L.h - B) - (ys - 1);               // exclusive
+  const int r_hi = min(ye + 2, Lh - B) - (ys - 1);               // exclusive
   const uint32_t t2 = (uint32_t)thr * 0x00010001u;
   const int xs = B & ~3;                                           // dword-aligned start column
-  const bool aligned4 = ((B | L.xend) & 3) == 0;
+  const bool aligned4 = ((B | Lxend) & 3) == 0;
+
+  // exact compass pretest of the 4 pixels of one group (x0 % 4 == 0), survivors -> qf
+  auto pretest_batch = [&](bool valid, uint32_t key) {
+    const int x0 = key & 0xffff, r = key >> 16;
+    const lds_u8 *trow = tile + (r + 3) * pitch;
+    const uint32_t wc = *(const lds_u32 *)(trow + x0);
+    const uint32_t wl = *(const lds_u32 *)(trow + x0 - 4);
+    const uint32_t wr = *(const lds_u32 *)(trow + x0 + 4);
+    const uint32_t wu = *(const lds_u32 *)(trow + x0 - 3 * pitch);
+    const uint32_t wd = *(const lds_u32 *)(trow + x0 + 3 * pitch);
+    // even pixels (x0, x0+2) and odd pixels (x0+1, x0+3), zero-extended to 16 bit by v_perm_b32
+    const uint32_t re = pretest_pk(__builtin_amdgcn_perm(0, wc, 0x0c020c00u), __builtin_amdgcn_perm(0, wu, 0x0c020c00u),
+                                   __builtin_amdgcn_perm(0, wd, 0x0c020c00u),
+                                   __builtin_amdgcn_perm(wc, wl, 0x0c030c01u),      // x-3: l.b1, l.b3
+                                   __builtin_amdgcn_perm(wr, wc, 0x0c050c03u), t2); // x+3: c.b3, r.b1
+    const uint32_t ro = pretest_pk(__builtin_amdgcn_perm(0, wc, 0x0c030c01u), __builtin_amdgcn_perm(0, wu, 0x0c030c01u),
+                                   __builtin_amdgcn_perm(0, wd, 0x0c030c01u),
+                                   __builtin_amdgcn_perm(wc, wl, 0x0c040c02u),      // x-3: l.b2, c.b0
+                                   __builtin_amdgcn_perm(wr, wc, 0x0c060c04u), t2); // x+3: r.b0, r.b2
+    uint32_t fe = valid ? re & 0x80008000u : 0u, fo = valid ? ro & 0x80008000u : 0u;
+    if (!aligned4) {                     // generic border: mask the pixels outside [B, xend)
+      if (x0 + 0 < B || x0 + 0 >= Lxend) fe &= ~0x00008000u;
+      if (x0 + 1 < B || x0 + 1 >= Lxend) fo &= ~0x00008000u;
+      if (x0 + 2 < B || x0 + 2 >= Lxend) fe &= ~0x80000000u;
+      if (x0 + 3 < B || x0 + 3 >= Lxend) fo &= ~0x80000000u;
+    }
+    if (__ballot((fe | fo) != 0) == 0) return;
+    const uint64_t m0 = __ballot((fe & 0x8000u) != 0), m1 = __ballot((fo & 0x8000u) != 0);
+    const uint64_t m2 = __ballot((int32_t)fe < 0), m3 = __ballot((int32_t)fo < 0);
+    lds_u32 *q = qf + nf;
+    if (fe & 0x8000u) q[ballot_rank(m0)] = key;
+    q += __popcll(m0);
+    if (fo & 0x8000u) q[ballot_rank(m1)] = key + 1;
+    q += __popcll(m1);
+    if ((int32_t)fe < 0) q[ballot_rank(m2)] = key + 2;
+    q += __popcll(m2);
+    if ((int32_t)fo < 0) q[ballot_rank(m3)] = key + 3;
+    nf += __popcll(m0) + __popcll(m1) + __popcll(m2) + __popcll(m3);
+    while (nf >= 64) {
+      nf -= 64;
+      if (!(ablate & 2)) fast_batch(true, qf[nf + lane]);
+    }
+  };
+
+  // Group prefilter on every 4-pixel group: a pixel can only pass the compass test if one of its
+  // vertical compass points AND one of its horizontal ones differ from it by more than t, so the
+  // byte-wise SADs of the group against the rows 3 above/below and the columns 3 left/right must
+  // exceed t on both axes (v_sad_u8 sums |a-b| over the 4 bytes, an upper bound of each term).
   for (int r = r_lo + wave; r < r_hi; r += WAVES) {
-    const uint8_t *trow = tile + (r + 3) * pitch;
-    for (int cx = xs; cx < L.xend; cx += 256) {
+    const lds_u8 *trow = tile + (r + 3) * pitch;
+    for (int cx = xs; cx < Lxend; cx += 256) {
       const int x0 = cx + 4 * lane;
       // aligned dword reads; lanes past the row end read harmless bytes of the next tile row
-      const uint32_t wc = *(const uint32_t *)(trow + x0);
-      const uint32_t wl = *(const uint32_t *)(trow + x0 - 4);
-      const uint32_t wr = *(const uint32_t *)(trow + x0 + 4);
-      const uint32_t wu = *(const uint32_t *)(trow + x0 - 3 * pitch);
-      const uint32_t wd = *(const uint32_t *)(trow + x0 + 3 * pitch);
-      // even pixels (x0, x0+2) and odd pixels (x0+1, x0+3), zero-extended to 16 bit by v_perm_b32
-      const uint32_t re = pretest_pk(__builtin_amdgcn_perm(0, wc, 0x0c020c00u), __builtin_amdgcn_perm(0, wu, 0x0c020c00u),
-                                     __builtin_amdgcn_perm(0, wd, 0x0c020c00u),
-                                     __builtin_amdgcn_perm(wc, wl, 0x0c030c01u),      // x-3: l.b1, l.b3
-                                     __builtin_amdgcn_perm(wr, wc, 0x0c050c03u), t2); // x+3: c.b3, r.b1
-      const uint32_t ro = pretest_pk(__builtin_amdgcn_perm(0, wc, 0x0c030c01u), __builtin_amdgcn_perm(0, wu, 0x0c030c01u),
-                                     __builtin_amdgcn_perm(0, wd, 0x0c030c01u),
-                                     __builtin_amdgcn_perm(wc, wl, 0x0c040c02u),      // x-3: l.b2, c.b0
-                                     __builtin_amdgcn_perm(wr, wc, 0x0c060c04u), t2); // x+3: r.b0, r.b2
-      uint32_t fe = re & 0x80008000u, fo = ro & 0x80008000u;
-      if (aligned4) {                      // B and xend multiples of 4: a lane is all-in or all-out
-        if (x0 >= L.xend) fe = fo = 0;
-      } else {                             // generic border: mask the pixels outside [B, xend)
-        if (x0 + 0 < B || x0 + 0 >= L.xend) fe &= ~0x00008000u;
-        if (x0 + 1 < B || x0 + 1 >= L.xend) fo &= ~0x00008000u;
-        if (x0 + 2 < B || x0 + 2 >= L.xend) fe &= ~0x80000000u;
-        if (x0 + 3 < B || x0 + 3 >= L.xend) fo &= ~0x80000000u;
-      }
-      if (__ballot((fe | fo) != 0) == 0) continue;
-      const uint32_t key = pack_xy(x0, r);
-      {
-        const uint64_t m0 = __ballot((fe & 0x8000u) != 0), m1 = __ballot((fo & 0x8000u) != 0);
-        const uint64_t m2 = __ballot((int32_t)fe < 0), m3 = __ballot((int32_t)fo < 0);
-        uint32_t *q = qf + nf;
-        if (fe & 0x8000u) q[ballot_rank(m0)] = key;
-        q += __popcll(m0);
-        if (fo & 0x8000u) q[ballot_rank(m1)] = key + 1;
-        q += __popcll(m1);
-        if ((int32_t)fe < 0) q[ballot_rank(m2)] = key + 2;
-        q += __popcll(m2);
-        if ((int32_t)fo < 0) q[ballot_rank(m3)] = key + 3;
-        nf += __popcll(m0) + __popcll(m1) + __popcll(m2) + __popcll(m3);
-      }
-      while (nf >= 64) {
-        nf -= 64;
-        if (!(P.ablate & 2)) fast_batch(true, qf[nf + lane]);
+      const uint32_t wc = *(const lds_u32 *)(trow + x0);
+      const uint32_t wl = *(const lds_u32 *)(trow + x0 - 4);
+      const uint32_t wr = *(const lds_u32 *)(trow + x0 + 4);
+      const uint32_t wu = *(const lds_u32 *)(trow + x0 - 3 * pitch);
+      const uint32_t wd = *(const lds_u32 *)(trow + x0 + 3 * pitch);
+      const uint32_t sv = max(__builtin_amdgcn_sad_u8(wu, wc, 0u), __builtin_amdgcn_sad_u8(wd, wc, 0u));
+      const uint32_t sh = max(__builtin_amdgcn_sad_u8(__builtin_amdgcn_alignbyte(wc, wl, 1), wc, 0u),
+                              __builtin_amdgcn_sad_u8(__builtin_amdgcn_alignbyte(wr, wc, 3), wc, 0u));
+      const bool g = (min(sv, sh) > (uint32_t)thr) && (x0 < Lxend);
+      const uint64_t m = __ballot(g);
+      if (m == 0) continue;
+      if (g) qg[ng + ballot_rank(m)] = pack_xy(x0, r);
+      ng += __popcll(m);
+      if (ng >= 64) {
+        ng -= 64;
+        if (!(ablate & 16)) pretest_batch(true, qg[ng + lane]);
       }
     }
   }
-  if (nf > 0) fast_batch(lane < nf, lane < nf ? qf[lane] : 0u);
-  if (nh > 0) harris_batch(lane < nh, lane < nh ? qh[lane] : 0u);
+  if (ng > 0 && !(ablate & 16)) pretest_batch(lane < ng, lane < ng ? qg[lane] : pack_xy(xs, r_lo));
+  if (nf > 0) {                                     // merge the waves' left-over candidates
+    int base = 0;
+    if (lane == 0) base = (int)atomicAdd(&sh_ctr[2], (uint32_t)nf);
+    base = __builtin_amdgcn_readfirstlane(base);
+    if (lane < nf) shq_fl[base + lane] = qf[lane];
+  }
+  __syncthreads();
+  {
+    const int tf = (int)sh_ctr[2];
+    if (!(ablate & 2))
+      for (int c0 = wave * 64; c0 < tf; c0 += WAVES * 64) fast_batch(c0 + lane < tf, shq_fl[min(c0 + lane, tf - 1)]);
+  }
+  __syncthreads();
+  {
+    const int th = (int)min(sh_ctr[0], sh_ctr[1]);
+    if (!(ablate & 4))
+      for (int c0 = wave * 64; c0 < th; c0 += WAVES * 64) harris_batch(c0 + lane < th, shq_h[min(c0 + lane, th - 1)]);
+  }
   __syncthreads();
 
   if (P.dump_score) {   // debug / parity hook: rows this strip owns, [ys, ye)
     uint8_t *dst = score_dump + (size_t)pyr * score_stride + (size_t)L.row0 * P.vstep + L.col0;
     for (int i = tid; i < (ye - ys) * pitch; i += 256) {
       const int r = i / pitch, x = i - r * pitch;
-      if (x >= B && x < max(L.xend, wmod ? L.w + 2 : 0)) dst[(ptrdiff_t)(ys + r) * P.vstep + x] = sc[(r + 1) * pitch + x];
+      if (x >= B && x < max(Lxend, wmod ? Lw + 2 : 0)) dst[(ptrdiff_t)(ys + r) * P.vstep + x] = sc[(r + 1) * pitch + x];
     }
   }
 
-  if (P.ablate & 8) return;
+  if (ablate & 8) return;
   // ---- phase D: NMS, block-raster order.  Pass 0 counts per block-row, pass 1 scatters. ----
   __shared__ uint32_t rowcnt[64];
   const int nbr = (ye - ys + 1) >> 1;               // block rows in this strip
-  const int xlim = L.w - B;                         // block origins are x = B, B+2, ... < xlim
+  const int xlim = Lw - B;                         // block origins are x = B, B+2, ... < xlim
   // One lane looks at 4 score columns x 2 rows = two horizontally adjacent 2x2 blocks with two
   // aligned dword reads; an all-zero pair (the overwhelmingly common case) is done (Fast.h:237).
-  auto nms_pair = [&](const uint8_t *srow, int x0, int y, uint32_t &ra, uint32_t &rb) {
+  auto nms_pair = [&](const lds_u8 *srow, int x0, int y, uint32_t &ra, uint32_t &rb) {
     ra = rb = 0;
-    const uint32_t m = *(const uint32_t *)(srow + x0) | *(const uint32_t *)(srow + pitch + x0);
+    const uint32_t m = *(const lds_u32 *)(srow + x0) | *(const lds_u32 *)(srow + pitch + x0);
     if (m != 0) {
       if ((m & 0xffffu) && x0 < xlim) ra = nms_block(srow + x0, pitch, x0, y);
       if ((m >> 16) && x0 + 2 < xlim) rb = nms_block(srow + x0 + 2, pitch, x0 + 2, y);
@@ -265,7 +351,7 @@ __global__ __launch_bounds__(256) void k_fused_strips(
   };
   const bool pairs = (B & 3) == 0;                  // block origins dword-aligned in pairs
   for (int br = wave; br < nbr; br += WAVES) {
-    const uint8_t *srow = sc + (2 * br + 1) * pitch;
+    const lds_u8 *srow = sc + (2 * br + 1) * pitch;
     uint32_t cnt = 0;
     if (pairs) {
       for (int x0 = B + 4 * lane; x0 - 4 * lane < xlim; x0 += 256) {
@@ -290,7 +376,7 @@ __global__ __launch_bounds__(256) void k_fused_strips(
     if (rowcnt[br] == 0) continue;
     uint32_t off = 0;
     for (int k = 0; k < br; k++) off += rowcnt[k];
-    const uint8_t *srow = sc + (2 * br + 1) * pitch;
+    const lds_u8 *srow = sc + (2 * br + 1) * pitch;
     uint32_t *dst = stage_kp + strip_slot;
     if (pairs) {
       for (int x0 = B + 4 * lane; x0 - 4 * lane < xlim; x0 += 256) {
@@ -391,13 +477,20 @@ __global__ __launch_bounds__(256) void k_gather(const FusedParams P,
 //   the aligned rows are parked in LDS and the 256 BRIEF tests (Brief.h:52) read them back,
 //   32 pairs per half-wave per round, one ballot = one descriptor word for each keypoint.
 // ===========================================================================
-constexpr int ORB_PATCH_BYTES = 32 * 32;            // 31 rows x 32 B, padded to 32 rows
+constexpr int ORB_PITCH = 48;                       // one 48-byte (3 x 16 B) window per patch row
+constexpr int ORB_PATCH_BYTES = 32 * ORB_PITCH + 16;   // 31 rows (+1 idle) + slack for the byte shift
 
-template <bool VEC_UNUSED = false>
-__device__ __forceinline__ int half_sum(int v) {
-#pragma unroll
-  for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);   // stays inside each 32-lane half
-  return v;
+// Sum over each 32-lane half of the wave, result in every lane of that half.  DPP row shifts
+// (zero fill) leave each 16-lane row's sum in its last lane, row_bcast:15 folds row 0 into row 1 and
+// row 2 into row 3, two v_readlane pick the totals up.
+__device__ __forceinline__ int half_sum(int v, int half) {
+  v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);   // row_shr:1
+  v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);   // row_shr:2
+  v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);   // row_shr:4
+  v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);   // row_shr:8
+  v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);  // row_bcast:15 into rows 1 and 3
+  const int s0 = __builtin_amdgcn_readlane(v, 31), s1 = __builtin_amdgcn_readlane(v, 63);
+  return half ? s1 : s0;
 }
 
 __global__ __launch_bounds__(256) void k_gather_orb(
@@ -497,22 +590,25 @@ __global__ __launch_bounds__(256) void k_gather_orb(
     const bool valid = idx < hi;
     const uint32_t p = kpl[valid ? idx - lo : 0];
     const int x = decode_x(p), y = decode_y(p);
-    // row start (x-15) of row y+dy, dword aligned + funnel shift
+    // 48-byte window [a16, a16+48) of row y+dy covering the 32 patch bytes x-15..x+16: three
+    // 16-byte loads per lane instead of nine dwords (the loads are row-divergent, so the number of
+    // load instructions is what the L1 pays for); vstep % 16 == 0 makes the shift row-independent.
     const ptrdiff_t start = (ptrdiff_t)(y + dy) * P.vstep + (x - 15);
-    const ptrdiff_t a0 = start & ~(ptrdiff_t)3;
-    const uint32_t sh = (uint32_t)(start & 3);
-    uint32_t in[9];
+    const ptrdiff_t a16 = start & ~(ptrdiff_t)15;
+    const uint32_t sh = (uint32_t)(start & 15);
+    uint4 win[3];
 #pragma unroll
-    for (int k = 0; k < 9; k++) {
-      const ptrdiff_t a = a0 + 4 * k;
-      in[k] = (valid && r < 31 && a >= 0 && a + 4 <= img_bytes) ? *(const uint32_t *)(im + a) : 0u;
+    for (int k = 0; k < 3; k++) {
+      const ptrdiff_t a = a16 + 16 * k;
+      win[k] = (valid && r < 31 && a >= 0 && a + 16 <= img_bytes) ? *(const uint4 *)(im + a) : make_uint4(0, 0, 0, 0);
     }
+    uint8_t *prow = patch + r * ORB_PITCH;
+#pragma unroll
+    for (int k = 0; k < 3; k++) *(uint4 *)(prow + 16 * k) = win[k];
+    // read the row back dword-aligned to the PATCH (byte-unaligned LDS reads are fine on gfx950)
     uint32_t row[8];
 #pragma unroll
-    for (int k = 0; k < 8; k++) row[k] = __builtin_amdgcn_alignbyte(in[k + 1], in[k], sh);
-    // park the aligned row for the BRIEF gathers
-    *(uint4 *)(patch + r * 32) = make_uint4(row[0], row[1], row[2], row[3]);
-    *(uint4 *)(patch + r * 32 + 16) = make_uint4(row[4], row[5], row[6], row[7]);
+    for (int k = 0; k < 8; k++) row[k] = *(const uint32_t *)(prow + sh + 4 * k);
     // moments of this row: sum v and sum |dx| v, left (dx<0) and right (dx>0) separately
     uint32_t sv = 0, left = 0, right = 0;
 #pragma unroll
@@ -528,15 +624,17 @@ __global__ __launch_bounds__(256) void k_gather_orb(
     right = __builtin_amdgcn_udot4(row[5] & cmask[5], 0x08070605u, right, false);  // dx   5..8
     right = __builtin_amdgcn_udot4(row[6] & cmask[6], 0x0c0b0a09u, right, false);  // dx   9..12
     right = __builtin_amdgcn_udot4(row[7] & cmask[7], 0x000f0e0du, right, false);  // dx  13..15 (16 masked)
-    const int m10 = half_sum((int)right - (int)left);
-    const int m01 = half_sum(dy * (int)sv);
+    const int m10 = half_sum((int)right - (int)left, half);
+    const int m01 = half_sum(dy * (int)sv, half);
     const uint32_t rot = angle_bin(m10, m01);
     // BRIEF: pair k = 32*round + r of this half's keypoint -> bit r of word `round`
     const uint32_t *tab = ::g_brief_ofs.v + rot * 256 + r;   // defined by the including TU
+    // the patch's byte (dy,dx) sits at (dy+15)*48 + sh + dx+15; sh is the same for every row
+    const uint32_t sh0 = (uint32_t)(((ptrdiff_t)y * P.vstep + (x - 15)) & 15);
     uint32_t myword = 0;
     for (int round = 0; round < words; round++) {
       const uint32_t e = tab[32 * round];
-      const uint32_t a = patch[e & 0xffffu], b = patch[e >> 16];
+      const uint32_t a = patch[(e & 0xffffu) + sh0], b = patch[(e >> 16) + sh0];
       const uint64_t m = __ballot(a < b);                           // Brief.h:52
       const uint32_t w = half ? (uint32_t)(m >> 32) : (uint32_t)m;
       if (r == round) myword = w;

@@ -20,8 +20,8 @@ __device__ const uint32_t g_brief_tab[30 * 256] = {
 static constexpr uint32_t h_brief_tab_packed[30 * 256] = {
 #include "brief_table.inc"
 };
-// The same table as byte offsets into a 32-byte-pitch LDS patch whose row 15 / column 15 is the
-// keypoint: ofs = (dy+15)*32 + (dx+15); low half = first sample point, high half = second.
+// The same table as byte offsets into a 48-byte-pitch LDS patch whose row 15 / column 15 is the
+// keypoint: ofs = (dy+15)*48 + (dx+15); low half = first sample point, high half = second.
 struct BriefOfsTab {
   uint32_t v[30 * 256];
 };
@@ -31,7 +31,7 @@ static constexpr BriefOfsTab make_brief_ofs() {
     const uint32_t e = h_brief_tab_packed[i];
     const int dx0 = (int8_t)(e & 0xff), dy0 = (int8_t)((e >> 8) & 0xff);
     const int dx1 = (int8_t)((e >> 16) & 0xff), dy1 = (int8_t)(e >> 24);
-    t.v[i] = (uint32_t)((dy0 + 15) * 32 + dx0 + 15) | ((uint32_t)((dy1 + 15) * 32 + dx1 + 15) << 16);
+    t.v[i] = (uint32_t)((dy0 + 15) * 48 + dx0 + 15) | ((uint32_t)((dy1 + 15) * 48 + dx1 + 15) << 16);
   }
   return t;
 }
@@ -663,7 +663,7 @@ bool build_fused_plan(const pislam_ctx *c, const pislam_frontend_params *p, cons
     L.vpr_recip = (uint32_t)(((1ull << 32) + (L.pitch / 16) - 1) / (L.pitch / 16));
     strips += L.nstrips;
     slots += L.nstrips * (R / 2) * L.nbx;
-    lds = std::max(lds, (size_t)(2 * R + 13) * L.pitch + pf::WAVES * 2 * pf::QCAP * sizeof(uint32_t));
+    lds = std::max(lds, (size_t)(2 * R + 13) * L.pitch + (pf::WAVES * pf::QCAP + pf::SHARED_Q) * sizeof(uint32_t));
   }
   F->strips_per_pyr = strips;
   F->slots_per_pyr = slots;
@@ -691,6 +691,19 @@ int run_fused(pislam_ctx *c, const pislam_frontend_params *p, const pf::FusedPar
   PCHK(launch_ok(c, "k_fused_strips"));
   HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
   HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
+  if (p->vstep % 16 != 0) {
+    // k_gather_orb's 48-byte row windows assume a row-independent byte shift (vstep % 16 == 0);
+    // other strides take the generic gather + per-keypoint ORB kernels.
+    hipLaunchKernelGGL(pf::k_gather, dim3(batch), dim3(256), sizeof(uint32_t) * (F.strips_per_pyr + 1), c->stream,
+                       F, c->w_stage.as<uint32_t>(), c->w_stripcnt.as<uint32_t>(), kp, (size_t)p->max_keypoints,
+                       (uint32_t)p->max_keypoints, counts);
+    PCHK(launch_ok(c, "k_gather"));
+    hipLaunchKernelGGL(pk::k_orb<0>, dim3(cdiv(p->max_keypoints, 4), 1, batch), dim3(256), 0, c->stream,
+                       pyramids, p->vstep, stride, kp, (size_t)p->max_keypoints, counts, 0u,
+                       (uint32_t)p->max_keypoints, p->words, desc, (size_t)p->max_keypoints * p->words,
+                       (int32_t *)nullptr, (const uint8_t *)nullptr);
+    return launch_ok(c, "k_orb<batch>");
+  }
   // gather + orbCompute in one launch: (chunks, batch) workgroups
   int nch = c->opt_orb_chunks > 0 ? c->opt_orb_chunks : std::min(64, std::max(8, 2048 / batch));
   const size_t per_max = ((size_t)p->max_keypoints + nch - 1) / nch;
