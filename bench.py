@@ -139,6 +139,13 @@ def main():
         # pipeline there is no single dominant launch, so the whole step is priced instead
         launch_ms = ev_stage_ms[0] if fused else ev_total_ms
         achieved = b_alg_launch / (launch_ms * 1e-3) / 1e9
+        traffic = None                                  # HBM bytes per launch from the committed PMC passes
+        tpath = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
+        if fused and B == 256 and os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath))["kernels"]["k_fused_strips"]["hbm_bytes_per_launch"]
+            except Exception:
+                traffic = None
         out = {
             "metric": "ORB keypoints+descriptors/sec, 640x480 8-level pyramid",
             "value": value, "unit": "kp+desc/s", "n_gpus": world, "steps": args.steps,
@@ -156,7 +163,7 @@ def main():
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                 "kernel": "pf::k_fused_strips (hipEvents around the launch, on the launch stream)" if fused
                           else "whole staged step (all launches)",
                 "algorithmic_bytes_per_launch": b_alg_launch, "launch_ms": launch_ms,
