@@ -40,8 +40,7 @@ constexpr int QCAP_G = 128;            // 4-pixel groups that passed the SAD pre
 constexpr int QCAP_F = 320;            // FAST candidates (< 64 before a <= 256 push)
 constexpr int QCAP = QCAP_G + QCAP_F;  // dwords of private queue space per wave
 constexpr int QH_SHARED = 512;         // workgroup-shared queue of corners awaiting their Harris score
-constexpr int QFL_SHARED = 256;        // workgroup-shared queue of the waves' left-over FAST candidates
-constexpr int SHARED_Q = QH_SHARED + QFL_SHARED;
+constexpr int SHARED_Q = QH_SHARED;
 
 struct FusedLevel {
   int w, h;          // level size
@@ -189,7 +188,6 @@ __global__ __launch_bounds__(256) void k_fused_strips(
   // and are scored by all waves together once FAST is finished.  The waves' left-over FAST
   // candidates (< 64 each) are merged the same way.
   lds_u32 *shq_h = queues + WAVES * QCAP;
-  lds_u32 *shq_fl = shq_h + QH_SHARED;
   int ng = 0, nf = 0;                               // wave-uniform queue fills
   // NOTE: the lambdas below capture by reference; they must only touch LOCAL copies of kernel
   // arguments — capturing `P` itself makes the compiler spill the whole 800-byte struct to scratch.
@@ -306,18 +304,8 @@ __global__ __launch_bounds__(256) void k_fused_strips(
     }
   }
   if (ng > 0 && !(ablate & 16)) pretest_batch(lane < ng, lane < ng ? qg[lane] : pack_xy(xs, r_lo));
-  if (nf > 0) {                                     // merge the waves' left-over candidates
-    int base = 0;
-    if (lane == 0) base = (int)atomicAdd(&sh_ctr[2], (uint32_t)nf);
-    base = __builtin_amdgcn_readfirstlane(base);
-    if (lane < nf) shq_fl[base + lane] = qf[lane];
-  }
-  __syncthreads();
-  {
-    const int tf = (int)sh_ctr[2];
-    if (!(ablate & 2))
-      for (int c0 = wave * 64; c0 < tf; c0 += WAVES * 64) fast_batch(c0 + lane < tf, shq_fl[min(c0 + lane, tf - 1)]);
-  }
+  // left-over candidates (< 64): one partial batch per wave — cheaper than a barrier to merge them
+  if (nf > 0 && !(ablate & 2)) fast_batch(lane < nf, qf[min(lane, nf - 1)]);
   __syncthreads();
   {
     const int th = (int)min(sh_ctr[0], sh_ctr[1]);
@@ -335,10 +323,14 @@ __global__ __launch_bounds__(256) void k_fused_strips(
   }
 
   if (ablate & 8) return;
-  // ---- phase D: NMS, block-raster order.  Pass 0 counts per block-row, pass 1 scatters. ----
+  // ---- phase D: NMS in ONE pass.  The image tile is dead after the Harris phase, so its LDS is
+  // reused as per-block-row survivor buffers: a wave appends its row's survivors in raster order,
+  // then (after a barrier) the rows are copied out back to back = block-raster order of the strip.
   __shared__ uint32_t rowcnt[64];
   const int nbr = (ye - ys + 1) >> 1;               // block rows in this strip
   const int xlim = Lw - B;                         // block origins are x = B, B+2, ... < xlim
+  const int nbx = L.nbx;
+  lds_u32 *rowbuf = (lds_u32 *)tile;                // nbr x nbx dwords <= R/2 * w/2 * 4 B < the tile
   // One lane looks at 4 score columns x 2 rows = two horizontally adjacent 2x2 blocks with two
   // aligned dword reads; an all-zero pair (the overwhelmingly common case) is done (Fast.h:237).
   auto nms_pair = [&](const lds_u8 *srow, int x0, int y, uint32_t &ra, uint32_t &rb) {
@@ -352,32 +344,8 @@ __global__ __launch_bounds__(256) void k_fused_strips(
   const bool pairs = (B & 3) == 0;                  // block origins dword-aligned in pairs
   for (int br = wave; br < nbr; br += WAVES) {
     const lds_u8 *srow = sc + (2 * br + 1) * pitch;
+    lds_u32 *rb_out = rowbuf + br * nbx;
     uint32_t cnt = 0;
-    if (pairs) {
-      for (int x0 = B + 4 * lane; x0 - 4 * lane < xlim; x0 += 256) {
-        uint32_t ra, rb;
-        nms_pair(srow, x0, ys + 2 * br, ra, rb);
-        cnt += __popcll(__ballot(ra != 0)) + __popcll(__ballot(rb != 0));
-      }
-    } else {
-      for (int bx0 = 0; bx0 < L.nbx; bx0 += 64) {
-        const int bx = bx0 + lane;
-        uint32_t res = 0;
-        if (bx < L.nbx) res = nms_block(srow + B + 2 * bx, pitch, B + 2 * bx, ys + 2 * br);
-        cnt += __popcll(__ballot(res != 0));
-      }
-    }
-    if (lane == 0) rowcnt[br] = cnt;
-  }
-  __syncthreads();
-  const size_t strip_slot = (size_t)pyr * P.slots_per_pyr + L.slot0 + (size_t)s * (L.R >> 1) * L.nbx;
-  const uint32_t add_xy = ((uint32_t)L.col0 << 12) | (uint32_t)L.row0;      // README.md:78
-  for (int br = wave; br < nbr; br += WAVES) {
-    if (rowcnt[br] == 0) continue;
-    uint32_t off = 0;
-    for (int k = 0; k < br; k++) off += rowcnt[k];
-    const lds_u8 *srow = sc + (2 * br + 1) * pitch;
-    uint32_t *dst = stage_kp + strip_slot;
     if (pairs) {
       for (int x0 = B + 4 * lane; x0 - 4 * lane < xlim; x0 += 256) {
         uint32_t ra, rb;
@@ -385,21 +353,32 @@ __global__ __launch_bounds__(256) void k_fused_strips(
         const uint64_t ma = __ballot(ra != 0), mb = __ballot(rb != 0);
         if ((ma | mb) == 0) continue;
         // raster order inside the row: lane-major, then the left block before the right one
-        const uint32_t pos = off + ballot_rank(ma) + ballot_rank(mb);
-        if (ra) dst[pos] = ra + add_xy;
-        if (rb) dst[pos + (ra != 0)] = rb + add_xy;
-        off += __popcll(ma) + __popcll(mb);
+        const uint32_t pos = cnt + ballot_rank(ma) + ballot_rank(mb);
+        if (ra) rb_out[pos] = ra;
+        if (rb) rb_out[pos + (ra != 0)] = rb;
+        cnt += __popcll(ma) + __popcll(mb);
       }
     } else {
-      for (int bx0 = 0; bx0 < L.nbx; bx0 += 64) {
+      for (int bx0 = 0; bx0 < nbx; bx0 += 64) {
         const int bx = bx0 + lane;
         uint32_t res = 0;
-        if (bx < L.nbx) res = nms_block(srow + B + 2 * bx, pitch, B + 2 * bx, ys + 2 * br);
+        if (bx < nbx) res = nms_block(srow + B + 2 * bx, pitch, B + 2 * bx, ys + 2 * br);
         const uint64_t m = __ballot(res != 0);
-        if (res) dst[off + ballot_rank(m)] = res + add_xy;
-        off += __popcll(m);
+        if (res) rb_out[cnt + ballot_rank(m)] = res;
+        cnt += __popcll(m);
       }
     }
+    if (lane == 0) rowcnt[br] = cnt;
+  }
+  __syncthreads();
+  const size_t strip_slot = (size_t)pyr * P.slots_per_pyr + L.slot0 + (size_t)s * (L.R >> 1) * nbx;
+  const uint32_t add_xy = ((uint32_t)L.col0 << 12) | (uint32_t)L.row0;      // README.md:78
+  for (int br = wave; br < nbr; br += WAVES) {
+    const uint32_t n = rowcnt[br];
+    if (n == 0) continue;
+    uint32_t off = 0;
+    for (int k = 0; k < br; k++) off += rowcnt[k];
+    for (uint32_t k = lane; k < n; k += 64) stage_kp[strip_slot + off + k] = rowbuf[br * nbx + k] + add_xy;
   }
   if (tid == 0) {
     uint32_t tot = 0;
