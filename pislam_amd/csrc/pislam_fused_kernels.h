@@ -35,7 +35,8 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));   // plain clang vec
 typedef __attribute__((address_space(3))) u32x4 lds_u4;
 
 constexpr int MAX_LEVELS = 16;
-constexpr int WAVES = 4;               // 256 threads
+constexpr int WAVES = 4;               // waves per strip workgroup
+constexpr int NT = WAVES * 64;         // threads per strip workgroup
 constexpr int QCAP_G = 128;            // 4-pixel groups that passed the SAD prefilter (< 64 before a <= 64 push)
 constexpr int QCAP_F = 320;            // FAST candidates (< 64 before a <= 256 push)
 constexpr int QCAP = QCAP_G + QCAP_F;  // dwords of private queue space per wave
@@ -108,7 +109,7 @@ __device__ __attribute__((noinline)) void harris_overflow(lds_u8 *tile, lds_u8 *
 }
 
 template <bool VEC16>
-__global__ __launch_bounds__(256) void k_fused_strips(
+__global__ __launch_bounds__(NT) void k_fused_strips(
     const FusedParams P, const uint8_t *__restrict__ pyramids, size_t pyr_stride,
     uint32_t *__restrict__ stage_kp, uint32_t *__restrict__ strip_count,
     uint8_t *__restrict__ score_dump, size_t score_stride) {
@@ -150,7 +151,7 @@ __global__ __launch_bounds__(256) void k_fused_strips(
       // bytes of this pyramid's buffer that may be read (the tile can overhang the last image row
       // when col0 + pitch > vstep: flat addressing like the reference, but never past the buffer)
       const ptrdiff_t lim = (ptrdiff_t)P.rows * P.vstep - ((ptrdiff_t)L.row0 * P.vstep + L.col0);
-      for (int i = tid; i < nrows * vpr; i += 256) {
+      for (int i = tid; i < nrows * vpr; i += NT) {
         const int r = (int)__umulhi((uint32_t)i, L.vpr_recip), v = i - r * vpr;
         const ptrdiff_t off = (ptrdiff_t)(y_lo + r) * P.vstep + 16 * v;
         u32x4 d;
@@ -167,14 +168,14 @@ __global__ __launch_bounds__(256) void k_fused_strips(
       }
     } else {
       const ptrdiff_t lim = (ptrdiff_t)P.rows * P.vstep - ((ptrdiff_t)L.row0 * P.vstep + L.col0);
-      for (int i = tid; i < nrows * pitch; i += 256) {
+      for (int i = tid; i < nrows * pitch; i += NT) {
         const int r = i / pitch, cx = i - r * pitch;
         const ptrdiff_t off = (ptrdiff_t)(y_lo + r) * P.vstep + cx;
         tile[r * pitch + cx] = off < lim ? im[off] : (uint8_t)0;
       }
     }
     const int nz = ((L.R + 3) * pitch) >> 4;
-    for (int i = tid; i < nz; i += 256) ((lds_u4 *)sc)[i] = (u32x4)(0u);
+    for (int i = tid; i < nz; i += NT) ((lds_u4 *)sc)[i] = (u32x4)(0u);
   }
   __syncthreads();
 
@@ -316,7 +317,7 @@ __global__ __launch_bounds__(256) void k_fused_strips(
 
   if (P.dump_score) {   // debug / parity hook: rows this strip owns, [ys, ye)
     uint8_t *dst = score_dump + (size_t)pyr * score_stride + (size_t)L.row0 * P.vstep + L.col0;
-    for (int i = tid; i < (ye - ys) * pitch; i += 256) {
+    for (int i = tid; i < (ye - ys) * pitch; i += NT) {
       const int r = i / pitch, x = i - r * pitch;
       if (x >= B && x < max(Lxend, wmod ? Lw + 2 : 0)) dst[(ptrdiff_t)(ys + r) * P.vstep + x] = sc[(r + 1) * pitch + x];
     }
@@ -456,6 +457,7 @@ __global__ __launch_bounds__(256) void k_gather(const FusedParams P,
 //   the aligned rows are parked in LDS and the 256 BRIEF tests (Brief.h:52) read them back,
 //   32 pairs per half-wave per round, one ballot = one descriptor word for each keypoint.
 // ===========================================================================
+constexpr int OWAVES = 4;                           // waves per k_gather_orb workgroup
 constexpr int ORB_PITCH = 48;                       // one 48-byte (3 x 16 B) window per patch row
 constexpr int ORB_PATCH_BYTES = 32 * ORB_PITCH + 16;   // 31 rows (+1 idle) + slack for the byte shift
 
@@ -486,7 +488,7 @@ __global__ __launch_bounds__(256) void k_gather_orb(
   const int S = P.strips_per_pyr;
   // LDS carve: patches (4 waves x 2 x 1 KiB) | strip offsets (S+1) | this chunk's keypoints
   uint8_t *patches = osm;
-  uint32_t *soff = (uint32_t *)(osm + WAVES * 2 * ORB_PATCH_BYTES);
+  uint32_t *soff = (uint32_t *)(osm + OWAVES * 2 * ORB_PATCH_BYTES);
   uint32_t *kpl = soff + ((S + 1 + 3) & ~3);
 
   // ---- exclusive scan of the strip counts (strip order = reference push_back order) ----
@@ -523,7 +525,7 @@ __global__ __launch_bounds__(256) void k_gather_orb(
   if (lo >= hi) return;
 
   // ---- pull this chunk's keypoints out of the staging buffer ----
-  for (int st = wv; st < S; st += WAVES) {
+  for (int st = wv; st < S; st += OWAVES) {
     const uint32_t s0 = soff[st], s1 = soff[st + 1];
     if (s1 <= lo || s0 >= hi || s1 == s0) continue;
     int li = 0;
@@ -564,7 +566,7 @@ __global__ __launch_bounds__(256) void k_gather_orb(
   uint8_t *patch = patches + (wv * 2 + half) * ORB_PATCH_BYTES;
   uint32_t *dsc = desc + (size_t)pyr * desc_stride;
   const uint32_t npairs = (hi - lo + 1) >> 1;
-  for (uint32_t it = wv; it < npairs; it += WAVES) {
+  for (uint32_t it = wv; it < npairs; it += OWAVES) {
     const uint32_t idx = lo + 2 * it + half;                       // this half-wave's keypoint
     const bool valid = idx < hi;
     const uint32_t p = kpl[valid ? idx - lo : 0];

@@ -686,7 +686,7 @@ int run_fused(pislam_ctx *c, const pislam_frontend_params *p, const pf::FusedPar
   auto kern = vec ? pf::k_fused_strips<true> : pf::k_fused_strips<false>;
   if (lds > 64 * 1024)
     HIPCHK(c, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(kern, grid, dim3(256), lds, c->stream, F, pyramids, stride, c->w_stage.as<uint32_t>(),
+  hipLaunchKernelGGL(kern, grid, dim3(pf::NT), lds, c->stream, F, pyramids, stride, c->w_stage.as<uint32_t>(),
                      c->w_stripcnt.as<uint32_t>(), dump, dump_stride);
   PCHK(launch_ok(c, "k_fused_strips"));
   HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
@@ -707,7 +707,7 @@ int run_fused(pislam_ctx *c, const pislam_frontend_params *p, const pf::FusedPar
   // gather + orbCompute in one launch: (chunks, batch) workgroups
   int nch = c->opt_orb_chunks > 0 ? c->opt_orb_chunks : std::min(64, std::max(8, 2048 / batch));
   const size_t per_max = ((size_t)p->max_keypoints + nch - 1) / nch;
-  size_t olds = (size_t)pf::WAVES * 2 * pf::ORB_PATCH_BYTES + sizeof(uint32_t) * (((size_t)F.strips_per_pyr + 1 + 3) & ~(size_t)3) +
+  size_t olds = (size_t)pf::OWAVES * 2 * pf::ORB_PATCH_BYTES + sizeof(uint32_t) * (((size_t)F.strips_per_pyr + 1 + 3) & ~(size_t)3) +
                 sizeof(uint32_t) * per_max;
   if (olds > 150 * 1024) return fail(c, PISLAM_ERR_INVALID, "max_keypoints too large for the fused ORB kernel");
   if (olds > 64 * 1024)
