@@ -112,6 +112,64 @@ __device__ __forceinline__ uint8_t harris_score(const P *c, int pitch, int32_t t
   return harris_eval(sxx >> 4, syy >> 4, sxy >> 4, threshold);   // Harris.h:243-247
 }
 
+// The same score on packed signed 16-bit pairs: one register holds two horizontally adjacent
+// columns, so the halving adds, the 16-bit wrapped row-pair products of Harris.h:166-213 (exactly
+// v_pk_mul_lo_u16 / v_pk_mad_u16 semantics) and their widening sums (v_dot2) each cover two columns
+// per instruction.  Rows are fetched as two (byte-unaligned) dwords.  ~40 % fewer instructions and
+// far fewer live registers than the scalar form; results are identical (GPU parity tests).
+typedef short pk_s2 __attribute__((ext_vector_type(2)));
+typedef unsigned short pk_u2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) uint8_t lds_byte;
+typedef __attribute__((address_space(3))) uint32_t lds_word;
+// row0 = &tile[y-3][x-3] in LDS (any byte alignment: gfx950 serves unaligned ds_read_b32)
+__device__ __forceinline__ uint8_t harris_score_pk(const lds_byte *row0, int pitch_bytes, int32_t threshold) {
+  pk_s2 P[8][4];
+#pragma unroll
+  for (int r = 0; r < 8; r++) {
+    const lds_word *rp = (const lds_word *)(row0 + r * pitch_bytes);
+    const uint32_t w0 = rp[0], w1 = rp[1];
+    P[r][0] = __builtin_bit_cast(pk_s2, __builtin_amdgcn_perm(0, w0, 0x0c010c00u));
+    P[r][1] = __builtin_bit_cast(pk_s2, __builtin_amdgcn_perm(0, w0, 0x0c030c02u));
+    P[r][2] = __builtin_bit_cast(pk_s2, __builtin_amdgcn_perm(0, w1, 0x0c010c00u));
+    P[r][3] = __builtin_bit_cast(pk_s2, __builtin_amdgcn_perm(0, w1, 0x0c030c02u));
+  }
+  uint32_t sxx = 0, syy = 0;
+  int32_t sxy = 0;
+  const pk_s2 one = {1, 1};
+#pragma unroll
+  for (int n = 0; n < 6; n += 2) {
+    pk_s2 dx[2][3], dy[2][3];
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+      const int m = n + h;
+#pragma unroll
+      for (int k = 0; k < 3; k++) {
+        // dx: Harris.h:139-162
+        const pk_s2 e0 = (P[m][k + 1] - P[m][k]) >> 1;
+        const pk_s2 e1 = (P[m + 1][k + 1] - P[m + 1][k]) >> 1;
+        const pk_s2 e2 = (P[m + 2][k + 1] - P[m + 2][k]) >> 1;
+        dx[h][k] = (((e0 + e2) >> 1) + e1) >> 1;
+        // dy: Harris.h:123-135
+        const pk_s2 d0 = (P[m + 2][k] - P[m][k]) >> 1;          // columns 2k, 2k+1
+        const pk_s2 d2 = (P[m + 2][k + 1] - P[m][k + 1]) >> 1;  // columns 2k+2, 2k+3
+        const pk_s2 d1 = __builtin_bit_cast(pk_s2, __builtin_amdgcn_alignbit(__builtin_bit_cast(uint32_t, d2),
+                                                                            __builtin_bit_cast(uint32_t, d0), 16));
+        dy[h][k] = (d1 + ((d0 + d2) >> 1)) >> 1;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      const pk_s2 xx = dx[0][k] * dx[0][k] + dx[1][k] * dx[1][k];     // 16-bit wrap per column
+      const pk_s2 yy = dy[0][k] * dy[0][k] + dy[1][k] * dy[1][k];
+      const pk_s2 xy = dx[0][k] * dy[0][k] + dx[1][k] * dy[1][k];
+      sxx = __builtin_amdgcn_udot2(__builtin_bit_cast(pk_u2, xx), __builtin_bit_cast(pk_u2, one), sxx, false);
+      syy = __builtin_amdgcn_udot2(__builtin_bit_cast(pk_u2, yy), __builtin_bit_cast(pk_u2, one), syy, false);
+      sxy = __builtin_amdgcn_sdot2(xy, one, sxy, false);
+    }
+  }
+  return harris_eval(sxx >> 4, syy >> 4, sxy >> 4, threshold);
+}
+
 // ---------------------------------------------------------------------------
 // 2x2-block non-max suppression — reference Fast.h:228-312.
 // s points at S[y][x] (block origin).  Returns the packed keypoint

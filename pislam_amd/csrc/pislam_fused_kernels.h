@@ -104,7 +104,7 @@ __device__ __attribute__((noinline)) void harris_overflow(lds_u8 *tile, lds_u8 *
                                                           bool valid, uint32_t e) {
   if (valid) {
     const int x = e & 0xffff, r = e >> 16;
-    sc[r * pitch + x] = harris_score(tile + (r + 3) * pitch + x, pitch, hthr);
+    sc[r * pitch + x] = harris_score_pk(tile + r * pitch + x - 3, pitch, hthr);
   }
 }
 
@@ -202,7 +202,8 @@ __global__ __launch_bounds__(NT) void k_fused_strips(
   auto harris_batch = [&](bool valid, uint32_t e) {
     if (valid) {
       const int x = e & 0xffff, r = e >> 16;
-      sc[r * pitch + x] = (ablate & 32) ? (uint8_t)200 : harris_score(tile + (r + 3) * pitch + x, pitch, hthr);
+      sc[r * pitch + x] = (ablate & 32) ? (uint8_t)200
+                                       : harris_score_pk(tile + r * pitch + x - 3, pitch, hthr);
     }
   };
   auto fast_batch = [&](bool valid, uint32_t e) {
