@@ -58,6 +58,25 @@ __device__ __forceinline__ bool fast9(const P *c, int pitch, int thr) {
   return has_arc9(dm) || has_arc9(bm);
 }
 
+// The same test when it is known per lane which side can hold an arc.  A dark arc and a bright arc
+// cannot coexist (9 + 9 > 16), and "p < lo" <=> "~p > ~lo", so one compare per ring pixel suffices:
+// side = 0 tests p > hi, side = -1 tests ~p > ~lo.  Lanes whose compass test fired on BOTH sides
+// (rare) must be run through fast9 instead.
+template <class P>
+__device__ __forceinline__ bool fast9_sided(const P *c, int pitch, int thr, int side /* 0 or -1 */) {
+  const int v = c[0];
+  const int bound = side ? ~(v - thr) : (v + thr);
+  uint32_t m = 0;
+#define PISLAM_F(k, dy, dx)                                       \
+  {                                                               \
+    const int p = c[(dy) * pitch + (dx)];                         \
+    m |= (uint32_t)((p ^ side) > bound) << (k);                   \
+  }
+  PISLAM_RING16(PISLAM_F)
+#undef PISLAM_F
+  return has_arc9(m);
+}
+
 // ---------------------------------------------------------------------------
 // Harris 6x6 Sobel score byte — reference Harris.h:80-248 + harrisEval
 // Harris.h:37-69.  c points at img[y][x].
@@ -201,6 +220,30 @@ __device__ __forceinline__ uint32_t nms_block(const P *s, int pitch, int x, int 
     return 0;
   }
 #undef S_
+}
+
+// Branch-free form of the same decision for one block whose 4x4 neighbourhood is already in
+// registers: w0..w3 = the dwords S[y-1..y+2][x-1..x+2] (byte k = column x-1+k).  One LDS round trip
+// instead of a chain of data-dependent reads; identical result to nms_block.
+__device__ __forceinline__ uint32_t nms_block_regs(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3, int x, int y) {
+#define BYTE_(w, k) (((w) >> (8 * (k))) & 0xffu)
+  const uint32_t v0 = BYTE_(w1, 1), v1 = BYTE_(w1, 2), v2 = BYTE_(w2, 1), v3 = BYTE_(w2, 2);
+  const uint32_t a0 = BYTE_(w0, 0), a1 = BYTE_(w0, 1), a2 = BYTE_(w0, 2), a3 = BYTE_(w0, 3);
+  const uint32_t b0 = BYTE_(w1, 0), b3 = BYTE_(w1, 3), c0 = BYTE_(w2, 0), c3 = BYTE_(w2, 3);
+  const uint32_t d0 = BYTE_(w3, 0), d1 = BYTE_(w3, 1), d2 = BYTE_(w3, 2), d3 = BYTE_(w3, 3);
+#undef BYTE_
+  const bool s0 = (v0 > v1) & (v0 > v2) & (v0 > v3);                                   // Fast.h:264
+  const bool s1 = !s0 & (v1 > v2) & (v1 > v3);                                         // Fast.h:275
+  const bool s2 = !s0 & !s1 & (v2 > v3);                                               // Fast.h:287
+  const bool ok0 = (v0 >= a0) & (v0 >= b0) & (v0 > c0) & (v0 >= a1) & (v0 >= a2);      // Fast.h:265-270
+  const bool ok1 = (v1 >= a1) & (v1 >= a2) & (v1 >= a3) & (v1 > b3) & (v1 > c3);       // Fast.h:276-282
+  const bool ok2 = (v2 >= b0) & (v2 >= c0) & (v2 > d0) & (v2 > d1) & (v2 > d2);        // Fast.h:288-293
+  const bool ok3 = (v3 > d1) & (v3 > d2) & (v3 >= b3) & (v3 > c3) & (v3 > d3);         // Fast.h:299-305
+  const bool any = (v0 | v1 | v2 | v3) != 0;                                           // Fast.h:237
+  const uint32_t v = s0 ? v0 : (s1 ? v1 : (s2 ? v2 : v3));
+  const bool ok = s0 ? ok0 : (s1 ? ok1 : (s2 ? ok2 : ok3));
+  const int dx = (s0 | s2) ? 0 : 1, dy = (s0 | s1) ? 0 : 1;
+  return (any & ok) ? encode_fast(v, x + dx, y + dy) : 0u;
 }
 
 // ---------------------------------------------------------------------------

@@ -88,14 +88,15 @@ __device__ __forceinline__ bool fast_pretest(const uint8_t *c, int pitch, int th
 typedef unsigned short us2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ us2 as_us2(uint32_t v) { return __builtin_bit_cast(us2, v); }
 __device__ __forceinline__ uint32_t as_u32(us2 v) { return __builtin_bit_cast(uint32_t, v); }
-__device__ __forceinline__ uint32_t pretest_pk(uint32_t c, uint32_t u, uint32_t d, uint32_t l, uint32_t r,
-                                               uint32_t t2) {
+__device__ __forceinline__ void pretest_pk(uint32_t c, uint32_t u, uint32_t d, uint32_t l, uint32_t r,
+                                           uint32_t t2, uint32_t &bright, uint32_t &dark) {
   const us2 C = as_us2(c), U = as_us2(u), D = as_us2(d), Lf = as_us2(l), Rt = as_us2(r), T = as_us2(t2);
   const us2 a = __builtin_elementwise_min(__builtin_elementwise_max(U, D), __builtin_elementwise_max(Lf, Rt));
   const us2 b = __builtin_elementwise_max(__builtin_elementwise_min(U, D), __builtin_elementwise_min(Lf, Rt));
   const us2 hi = C + T, lo = C - T;            // lo may wrap negative: compared as signed 16 bit below
   // bright: a > hi <=> (hi - a) < 0 ;  dark: b < lo <=> (b - lo) < 0   (all magnitudes < 2^10)
-  return as_u32(hi - a) | as_u32(b - lo);
+  bright = as_u32(hi - a);
+  dark = as_u32(b - lo);
 }
 
 // Rare path (shared corner queue full): score the flagged lanes right away.  Kept out of line so
@@ -209,6 +210,8 @@ __global__ __launch_bounds__(NT) void k_fused_strips(
   auto fast_batch = [&](bool valid, uint32_t e) {
     bool corner = false;
     const int x = e & 0xffff, r = e >> 16;
+    // (a one-sided test keyed on which compass side fired was measured: 16 % of the candidates fire on
+    //  both sides, so nearly every 64-lane batch needed the second pass and it was slower)
     if (valid) corner = fast9(tile + (r + 3) * pitch + x, pitch, thr);
     // Fast.h:172: only x < w-B is scored; over-classified columns keep 0xff
     const bool toh = corner && x < Lw - B;
@@ -244,14 +247,16 @@ __global__ __launch_bounds__(NT) void k_fused_strips(
     const uint32_t wu = *(const lds_u32 *)(trow + x0 - 3 * pitch);
     const uint32_t wd = *(const lds_u32 *)(trow + x0 + 3 * pitch);
     // even pixels (x0, x0+2) and odd pixels (x0+1, x0+3), zero-extended to 16 bit by v_perm_b32
-    const uint32_t re = pretest_pk(__builtin_amdgcn_perm(0, wc, 0x0c020c00u), __builtin_amdgcn_perm(0, wu, 0x0c020c00u),
-                                   __builtin_amdgcn_perm(0, wd, 0x0c020c00u),
-                                   __builtin_amdgcn_perm(wc, wl, 0x0c030c01u),      // x-3: l.b1, l.b3
-                                   __builtin_amdgcn_perm(wr, wc, 0x0c050c03u), t2); // x+3: c.b3, r.b1
-    const uint32_t ro = pretest_pk(__builtin_amdgcn_perm(0, wc, 0x0c030c01u), __builtin_amdgcn_perm(0, wu, 0x0c030c01u),
-                                   __builtin_amdgcn_perm(0, wd, 0x0c030c01u),
-                                   __builtin_amdgcn_perm(wc, wl, 0x0c040c02u),      // x-3: l.b2, c.b0
-                                   __builtin_amdgcn_perm(wr, wc, 0x0c060c04u), t2); // x+3: r.b0, r.b2
+    uint32_t be, de, bo, dd;
+    pretest_pk(__builtin_amdgcn_perm(0, wc, 0x0c020c00u), __builtin_amdgcn_perm(0, wu, 0x0c020c00u),
+               __builtin_amdgcn_perm(0, wd, 0x0c020c00u),
+               __builtin_amdgcn_perm(wc, wl, 0x0c030c01u),      // x-3: l.b1, l.b3
+               __builtin_amdgcn_perm(wr, wc, 0x0c050c03u), t2, be, de); // x+3: c.b3, r.b1
+    pretest_pk(__builtin_amdgcn_perm(0, wc, 0x0c030c01u), __builtin_amdgcn_perm(0, wu, 0x0c030c01u),
+               __builtin_amdgcn_perm(0, wd, 0x0c030c01u),
+               __builtin_amdgcn_perm(wc, wl, 0x0c040c02u),      // x-3: l.b2, c.b0
+               __builtin_amdgcn_perm(wr, wc, 0x0c060c04u), t2, bo, dd); // x+3: r.b0, r.b2
+    const uint32_t re = be | de, ro = bo | dd;
     uint32_t fe = valid ? re & 0x80008000u : 0u, fo = valid ? ro & 0x80008000u : 0u;
     if (!aligned4) {                     // generic border: mask the pixels outside [B, xend)
       if (x0 + 0 < B || x0 + 0 >= Lxend) fe &= ~0x00008000u;
@@ -339,8 +344,14 @@ __global__ __launch_bounds__(NT) void k_fused_strips(
     ra = rb = 0;
     const uint32_t m = *(const lds_u32 *)(srow + x0) | *(const lds_u32 *)(srow + pitch + x0);
     if (m != 0) {
-      if ((m & 0xffffu) && x0 < xlim) ra = nms_block(srow + x0, pitch, x0, y);
-      if ((m >> 16) && x0 + 2 < xlim) rb = nms_block(srow + x0 + 2, pitch, x0 + 2, y);
+      // rows y-1..y+2, columns x0-1..x0+2 (left block) and x0+1..x0+4 (right block): 8 unaligned dwords
+      const lds_u8 *p0 = srow - pitch + x0 - 1;
+      const uint32_t a0 = *(const lds_u32 *)(p0), b0 = *(const lds_u32 *)(p0 + 2);
+      const uint32_t a1 = *(const lds_u32 *)(p0 + pitch), b1 = *(const lds_u32 *)(p0 + pitch + 2);
+      const uint32_t a2 = *(const lds_u32 *)(p0 + 2 * pitch), b2 = *(const lds_u32 *)(p0 + 2 * pitch + 2);
+      const uint32_t a3 = *(const lds_u32 *)(p0 + 3 * pitch), b3 = *(const lds_u32 *)(p0 + 3 * pitch + 2);
+      if (x0 < xlim) ra = nms_block_regs(a0, a1, a2, a3, x0, y);
+      if (x0 + 2 < xlim) rb = nms_block_regs(b0, b1, b2, b3, x0 + 2, y);
     }
   };
   const bool pairs = (B & 3) == 0;                  // block origins dword-aligned in pairs
