@@ -58,6 +58,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--pipeline", type=int, default=0, help="0 auto (fused), 1 staged, 2 fused")
     ap.add_argument("--strip-rows", type=int, default=0)
+    ap.add_argument("--orb-chunks", type=int, default=0)
     ap.add_argument("--ablate", type=int, default=0, help="profiling only (results invalid): fused-kernel phase mask")
     args = ap.parse_args()
 
@@ -86,6 +87,7 @@ def main():
     ctx = Context(device=local_rank, stream=stream.cuda_stream)
     ctx.set_option("pipeline", args.pipeline)
     ctx.set_option("strip_rows", args.strip_rows)
+    ctx.set_option("orb_chunks", args.orb_chunks)
     ctx.set_option("ablate", args.ablate)
     fe = OrbFrontend(levels, vstep=640, rows=rows, max_keypoints=args.max_keypoints, ctx=ctx)
     fe.reserve(B)

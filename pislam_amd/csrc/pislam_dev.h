@@ -140,13 +140,18 @@ typedef short pk_s2 __attribute__((ext_vector_type(2)));
 typedef unsigned short pk_u2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) uint8_t lds_byte;
 typedef __attribute__((address_space(3))) uint32_t lds_word;
-// row0 = &tile[y-3][x-3] in LDS (any byte alignment: gfx950 serves unaligned ds_read_b32)
+// row0 = &tile[y-3][x-3] in LDS, any byte alignment.  gfx950 serves byte-unaligned ds_read_b32 but
+// stalls ~47 cycles on each (SQ_LDS_UNALIGNED_STALL), so every row is fetched as three aligned
+// dwords and funnel-shifted with v_alignbyte.
 __device__ __forceinline__ uint8_t harris_score_pk(const lds_byte *row0, int pitch_bytes, int32_t threshold) {
   pk_s2 P[8][4];
+  const uint32_t sh = (uint32_t)(uintptr_t)row0 & 3u;     // tile base and pitch are 16-byte aligned
+  const lds_byte *base = row0 - sh;
 #pragma unroll
   for (int r = 0; r < 8; r++) {
-    const lds_word *rp = (const lds_word *)(row0 + r * pitch_bytes);
-    const uint32_t w0 = rp[0], w1 = rp[1];
+    const lds_word *rp = (const lds_word *)(base + r * pitch_bytes);
+    const uint32_t i0 = rp[0], i1 = rp[1], i2 = rp[2];
+    const uint32_t w0 = __builtin_amdgcn_alignbyte(i1, i0, sh), w1 = __builtin_amdgcn_alignbyte(i2, i1, sh);
     P[r][0] = __builtin_bit_cast(pk_s2, __builtin_amdgcn_perm(0, w0, 0x0c010c00u));
     P[r][1] = __builtin_bit_cast(pk_s2, __builtin_amdgcn_perm(0, w0, 0x0c030c02u));
     P[r][2] = __builtin_bit_cast(pk_s2, __builtin_amdgcn_perm(0, w1, 0x0c010c00u));

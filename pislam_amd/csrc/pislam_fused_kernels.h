@@ -344,12 +344,18 @@ __global__ __launch_bounds__(NT) void k_fused_strips(
     ra = rb = 0;
     const uint32_t m = *(const lds_u32 *)(srow + x0) | *(const lds_u32 *)(srow + pitch + x0);
     if (m != 0) {
-      // rows y-1..y+2, columns x0-1..x0+2 (left block) and x0+1..x0+4 (right block): 8 unaligned dwords
-      const lds_u8 *p0 = srow - pitch + x0 - 1;
-      const uint32_t a0 = *(const lds_u32 *)(p0), b0 = *(const lds_u32 *)(p0 + 2);
-      const uint32_t a1 = *(const lds_u32 *)(p0 + pitch), b1 = *(const lds_u32 *)(p0 + pitch + 2);
-      const uint32_t a2 = *(const lds_u32 *)(p0 + 2 * pitch), b2 = *(const lds_u32 *)(p0 + 2 * pitch + 2);
-      const uint32_t a3 = *(const lds_u32 *)(p0 + 3 * pitch), b3 = *(const lds_u32 *)(p0 + 3 * pitch + 2);
+      // rows y-1..y+2, columns x0-1..x0+2 (left block) and x0+1..x0+4 (right block): three ALIGNED
+      // dwords per row + v_alignbyte (unaligned ds_read_b32 stalls ~47 cycles each on gfx950)
+      const lds_u8 *p0 = srow - pitch + x0;
+      uint32_t a[4], b[4];
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const uint32_t wl = *(const lds_u32 *)(p0 + k * pitch - 4), wc = *(const lds_u32 *)(p0 + k * pitch),
+                       wr = *(const lds_u32 *)(p0 + k * pitch + 4);
+        a[k] = __builtin_amdgcn_alignbyte(wc, wl, 3);     // columns x0-1 .. x0+2
+        b[k] = __builtin_amdgcn_alignbyte(wr, wc, 1);     // columns x0+1 .. x0+4
+      }
+      const uint32_t a0 = a[0], a1 = a[1], a2 = a[2], a3 = a[3], b0 = b[0], b1 = b[1], b2 = b[2], b3 = b[3];
       if (x0 < xlim) ra = nms_block_regs(a0, a1, a2, a3, x0, y);
       if (x0 + 2 < xlim) rb = nms_block_regs(b0, b1, b2, b3, x0 + 2, y);
     }
@@ -558,6 +564,7 @@ __global__ __launch_bounds__(256) void k_gather_orb(
   // ---- describe: two keypoints per wave iteration ----
   const uint8_t *im = pyramids + (size_t)pyr * pyr_stride;
   const ptrdiff_t img_bytes = (ptrdiff_t)P.rows * P.vstep;
+  const int vstep = P.vstep;
   const int half = lane >> 5, r = lane & 31;          // r = patch row index, dy = r - 15 (r = 31 idle)
   const int dy = r - 15;
   // per-lane circle mask for its row: byte j of the 32 covers dx = j - 15
@@ -578,30 +585,68 @@ __global__ __launch_bounds__(256) void k_gather_orb(
   uint8_t *patch = patches + (wv * 2 + half) * ORB_PATCH_BYTES;
   uint32_t *dsc = desc + (size_t)pyr * desc_stride;
   const uint32_t npairs = (hi - lo + 1) >> 1;
-  for (uint32_t it = wv; it < npairs; it += OWAVES) {
-    const uint32_t idx = lo + 2 * it + half;                       // this half-wave's keypoint
-    const bool valid = idx < hi;
-    const uint32_t p = kpl[valid ? idx - lo : 0];
-    const int x = decode_x(p), y = decode_y(p);
-    // 48-byte window [a16, a16+48) of row y+dy covering the 32 patch bytes x-15..x+16: three
-    // 16-byte loads per lane instead of nine dwords (the loads are row-divergent, so the number of
-    // load instructions is what the L1 pays for); vstep % 16 == 0 makes the shift row-independent.
-    const ptrdiff_t start = (ptrdiff_t)(y + dy) * P.vstep + (x - 15);
-    const ptrdiff_t a16 = start & ~(ptrdiff_t)15;
-    const uint32_t sh = (uint32_t)(start & 15);
-    uint4 win[3];
+  // Each patch row needs the 48-byte window [a16, a16+48) covering its 32 bytes x-15..x+16.  The L1
+  // processes a divergent load at about one distinct cache line per cycle, so the loads are laid out
+  // for coalescing: slot = lane + 64 j  ->  (keypoint half, row, 16-byte chunk) with the three chunks
+  // of a row in ADJACENT lanes (one or two lines per row instead of three requests).  Each lane
+  // parks its chunk in the LDS patch; the moments then read whole rows back (lane = row).
+  // vstep % 16 == 0 makes the byte shift row-independent.  The loads of the NEXT pair are issued
+  // before the current pair is processed (software prefetch).
+  struct Win {
+    uint4 w[3];
+  };
+  auto kp_of = [&](uint32_t it, int h, int &x, int &y) {
+    const uint32_t idx = lo + 2 * it + h;
+    const bool v = it < npairs && idx < hi;
+    const uint32_t p = kpl[v ? idx - lo : 0];
+    x = decode_x(p);
+    y = decode_y(p);
+    return v;
+  };
+  auto fetch = [&](uint32_t it) {
+    Win f;
 #pragma unroll
-    for (int k = 0; k < 3; k++) {
-      const ptrdiff_t a = a16 + 16 * k;
-      win[k] = (valid && r < 31 && a >= 0 && a + 16 <= img_bytes) ? *(const uint4 *)(im + a) : make_uint4(0, 0, 0, 0);
+    for (int j = 0; j < 3; j++) {
+      const int slot = lane + 64 * j;                 // 0..191, 186 used
+      const int h = slot >= 93 ? 1 : 0, within = slot - 93 * h;
+      const int row = within / 3, chunk = within - 3 * row;
+      int x, y;
+      const bool v = kp_of(it, h, x, y) && slot < 186;
+      const ptrdiff_t start = (ptrdiff_t)(y + row - 15) * vstep + (x - 15);
+      const ptrdiff_t a = (start & ~(ptrdiff_t)15) + 16 * chunk;
+      f.w[j] = (v && a >= 0 && a + 16 <= img_bytes) ? *(const uint4 *)(im + a) : make_uint4(0, 0, 0, 0);
+    }
+    return f;
+  };
+  if (P.ablate & 64) return;                        // profiling only: prologue cost
+  uint8_t *wave_patches = patches + (wv * 2) * ORB_PATCH_BYTES;
+  Win nxt = fetch(wv);
+  for (uint32_t it = wv; it < npairs; it += OWAVES) {
+    const Win cur = nxt;
+    nxt = fetch(it + OWAVES);
+    const uint32_t idx = lo + 2 * it + half;
+    int x, y;
+    const bool valid = kp_of(it, half, x, y);
+    const uint32_t sh = (uint32_t)(((ptrdiff_t)(y + dy) * vstep + (x - 15)) & 15);
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+      const int slot = lane + 64 * j;
+      const int h = slot >= 93 ? 1 : 0, within = slot - 93 * h;
+      const int row = within / 3, chunk = within - 3 * row;
+      if (slot < 186) *(uint4 *)(wave_patches + h * ORB_PATCH_BYTES + row * ORB_PITCH + 16 * chunk) = cur.w[j];
     }
     uint8_t *prow = patch + r * ORB_PITCH;
-#pragma unroll
-    for (int k = 0; k < 3; k++) *(uint4 *)(prow + 16 * k) = win[k];
-    // read the row back dword-aligned to the PATCH (byte-unaligned LDS reads are fine on gfx950)
+    // read the row back aligned to the PATCH: 9 aligned dwords + v_alignbyte (byte-unaligned
+    // ds_read_b32 works on gfx950 but costs ~47 stall cycles each — SQ_LDS_UNALIGNED_STALL)
     uint32_t row[8];
+    {
+      const uint8_t *pa = prow + (sh & ~3u);
+      uint32_t in[9];
 #pragma unroll
-    for (int k = 0; k < 8; k++) row[k] = *(const uint32_t *)(prow + sh + 4 * k);
+      for (int k = 0; k < 9; k++) in[k] = *(const uint32_t *)(pa + 4 * k);
+#pragma unroll
+      for (int k = 0; k < 8; k++) row[k] = __builtin_amdgcn_alignbyte(in[k + 1], in[k], sh & 3u);
+    }
     // moments of this row: sum v and sum |dx| v, left (dx<0) and right (dx>0) separately
     uint32_t sv = 0, left = 0, right = 0;
 #pragma unroll
@@ -623,14 +668,18 @@ __global__ __launch_bounds__(256) void k_gather_orb(
     // BRIEF: pair k = 32*round + r of this half's keypoint -> bit r of word `round`
     const uint32_t *tab = ::g_brief_ofs.v + rot * 256 + r;   // defined by the including TU
     // the patch's byte (dy,dx) sits at (dy+15)*48 + sh + dx+15; sh is the same for every row
-    const uint32_t sh0 = (uint32_t)(((ptrdiff_t)y * P.vstep + (x - 15)) & 15);
+    const uint32_t sh0 = (uint32_t)(((ptrdiff_t)y * vstep + (x - 15)) & 15);
     uint32_t myword = 0;
-    for (int round = 0; round < words; round++) {
-      const uint32_t e = tab[32 * round];
+    uint32_t ent[8];
+#pragma unroll
+    for (int round = 0; round < 8; round++) ent[round] = tab[32 * round];   // all 8 table loads in flight
+#pragma unroll
+    for (int round = 0; round < 8; round++) {
+      const uint32_t e = ent[round];
       const uint32_t a = patch[(e & 0xffffu) + sh0], b = patch[(e >> 16) + sh0];
       const uint64_t m = __ballot(a < b);                           // Brief.h:52
       const uint32_t w = half ? (uint32_t)(m >> 32) : (uint32_t)m;
-      if (r == round) myword = w;
+      if (r == round) myword = w;                                   // rounds >= words are never stored
     }
     if (valid && r < words) dsc[(size_t)idx * words + r] = myword;
   }

@@ -705,7 +705,7 @@ int run_fused(pislam_ctx *c, const pislam_frontend_params *p, const pf::FusedPar
     return launch_ok(c, "k_orb<batch>");
   }
   // gather + orbCompute in one launch: (chunks, batch) workgroups
-  int nch = c->opt_orb_chunks > 0 ? c->opt_orb_chunks : std::min(64, std::max(8, 2048 / batch));
+  int nch = c->opt_orb_chunks > 0 ? c->opt_orb_chunks : std::min(64, std::max(16, 4096 / batch));
   const size_t per_max = ((size_t)p->max_keypoints + nch - 1) / nch;
   size_t olds = (size_t)pf::OWAVES * 2 * pf::ORB_PATCH_BYTES + sizeof(uint32_t) * (((size_t)F.strips_per_pyr + 1 + 3) & ~(size_t)3) +
                 sizeof(uint32_t) * per_max;
