@@ -41,7 +41,9 @@ constexpr int QCAP_G = 128;            // 4-pixel groups that passed the SAD pre
 constexpr int QCAP_F = 320;            // FAST candidates (< 64 before a <= 256 push)
 constexpr int QCAP = QCAP_G + QCAP_F;  // dwords of private queue space per wave
 constexpr int QH_SHARED = 512;         // workgroup-shared queue of corners awaiting their Harris score
-constexpr int SHARED_Q = QH_SHARED;
+constexpr int QN_SHARED = 512;         // workgroup-shared queue of pixels with a non-zero score (NMS candidates)
+constexpr int QS_SHARED = 256;         // survivors of one strip awaiting their rank (lives in the dead image tile)
+constexpr int SHARED_Q = QH_SHARED + QN_SHARED;
 
 struct FusedLevel {
   int w, h;          // level size
@@ -136,12 +138,10 @@ __global__ __launch_bounds__(NT) void k_fused_strips(
 
   const uint8_t *im = pyramids + (size_t)pyr * pyr_stride + (size_t)L.row0 * P.vstep + L.col0;
   const int tid = threadIdx.x;
-  __shared__ uint32_t sh_ctr[4];                    // [0] corners queued, [1] first overflowed slot, [2] left-over candidates
-  if (tid == 0) {
-    sh_ctr[0] = 0;
-    sh_ctr[1] = QH_SHARED;
-    sh_ctr[2] = 0;
-  }
+  // [0] corners queued, [1] first overflowed corner slot, [2] non-zero scores queued,
+  // [3] set when a queue overflowed -> NMS falls back to scanning the score tile, [4] survivors
+  __shared__ uint32_t sh_ctr[8];
+  if (tid < 8) sh_ctr[tid] = tid == 1 ? QH_SHARED : 0;
 
   // ---- stage the image rows [ys-4, min(ye+6, h)) and clear the score tile ---------------
   {
@@ -190,6 +190,7 @@ __global__ __launch_bounds__(NT) void k_fused_strips(
   // and are scored by all waves together once FAST is finished.  The waves' left-over FAST
   // candidates (< 64 each) are merged the same way.
   lds_u32 *shq_h = queues + WAVES * QCAP;
+  lds_u32 *shq_n = shq_h + QH_SHARED;
   int ng = 0, nf = 0;                               // wave-uniform queue fills
   // NOTE: the lambdas below capture by reference; they must only touch LOCAL copies of kernel
   // arguments — capturing `P` itself makes the compiler spill the whole 800-byte struct to scratch.
@@ -200,12 +201,30 @@ __global__ __launch_bounds__(NT) void k_fused_strips(
   const bool wmod = (Lw & 15) != 0;
 
   // score rows r = 0 .. R+2  <->  level rows ys-1+r ; image tile row of level row y is y-(ys-4)
+  // every pixel that ends up with a non-zero score is also queued as an NMS candidate, so phase D
+  // visits ~100 blocks per strip instead of scanning the whole score tile
+  auto push_nonzero = [&](bool nz, uint32_t e) {
+    const uint64_t m = __ballot(nz);
+    if (m) {
+      const int cnt = __popcll(m);
+      int base = 0;
+      if (lane == 0) base = (int)atomicAdd(&sh_ctr[2], (uint32_t)cnt);
+      base = __builtin_amdgcn_readfirstlane(base);
+      if (base + cnt <= QN_SHARED) {
+        if (nz) shq_n[base + ballot_rank(m)] = e;
+      } else if (lane == 0) {
+        sh_ctr[3] = 1;
+      }
+    }
+  };
   auto harris_batch = [&](bool valid, uint32_t e) {
+    uint8_t score = 0;
     if (valid) {
       const int x = e & 0xffff, r = e >> 16;
-      sc[r * pitch + x] = (ablate & 32) ? (uint8_t)200
-                                       : harris_score_pk(tile + r * pitch + x - 3, pitch, hthr);
+      score = (ablate & 32) ? (uint8_t)200 : harris_score_pk(tile + r * pitch + x - 3, pitch, hthr);
+      sc[r * pitch + x] = score;
     }
+    push_nonzero(score != 0, e);
   };
   auto fast_batch = [&](bool valid, uint32_t e) {
     bool corner = false;
@@ -216,6 +235,7 @@ __global__ __launch_bounds__(NT) void k_fused_strips(
     // Fast.h:172: only x < w-B is scored; over-classified columns keep 0xff
     const bool toh = corner && x < Lw - B;
     if (corner && !toh) sc[r * pitch + x] = 0xff;
+    push_nonzero(corner && !toh, e);
     const uint64_t m = __ballot(toh);
     if (m) {
       const int cnt = __popcll(m);
@@ -225,7 +245,10 @@ __global__ __launch_bounds__(NT) void k_fused_strips(
       if (base + cnt <= QH_SHARED) {
         if (toh) shq_h[base + ballot_rank(m)] = e;
       } else {                                     // queue full: score these right away
-        if (lane == 0) atomicMin(&sh_ctr[1], (uint32_t)base);
+        if (lane == 0) {
+          atomicMin(&sh_ctr[1], (uint32_t)base);
+          sh_ctr[3] = 1;                           // their scores are not queued for NMS: scan instead
+        }
         harris_overflow(tile, sc, pitch, hthr, toh, e);
       }
     }
@@ -330,6 +353,70 @@ __global__ __launch_bounds__(NT) void k_fused_strips(
   }
 
   if (ablate & 8) return;
+  // ---- phase D (queue-driven): 2x2-block NMS only where a non-zero score exists ---------------
+  // Each queued pixel evaluates the block it lies in (Fast.h:228-312) and emits it iff it is the
+  // block's winner, so several corners in one block yield exactly one keypoint.  Survivors are
+  // ranked by their block-raster key (count of smaller keys) = the reference's push_back order.
+  if (sh_ctr[3] == 0) {
+    lds_u32 *shq_s = (lds_u32 *)tile;              // survivors (packed keypoints); image tile is dead now
+    lds_u32 *shq_k = shq_s + QS_SHARED;            // their block-raster keys
+    const int tn = (int)sh_ctr[2];
+    const int own_rows = ye - ys;                   // owned score rows r = 1 .. own_rows
+    const int xlimq = Lw - B;
+    for (int c0 = wave * 64; c0 < tn; c0 += WAVES * 64) {
+      const bool valid = c0 + lane < tn;
+      const uint32_t e = shq_n[min(c0 + lane, tn - 1)];
+      const int x = e & 0xffff, r = e >> 16;
+      const int bx = B + ((x - B) & ~1), rb = 1 + ((r - 1) & ~1);   // block origin (column, score row)
+      const bool owned = valid && r >= 1 && r <= own_rows && bx < xlimq;
+      uint32_t res = 0;
+      if (owned) {
+        const int cb = (bx - 1) & ~3;               // aligned dword holding column bx-1
+        const uint32_t shb = (uint32_t)(bx - 1) & 3u;
+        uint32_t w[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          const lds_u8 *rowp = sc + (rb - 1 + k) * pitch + cb;
+          w[k] = __builtin_amdgcn_alignbyte(*(const lds_u32 *)(rowp + 4), *(const lds_u32 *)rowp, shb);
+        }
+        res = nms_block_regs(w[0], w[1], w[2], w[3], bx, ys + rb - 1);
+        // only the block's winner emits (the other non-zero pixels of the block stay silent)
+        if (decode_x(res) != x || decode_y(res) != ys - 1 + r) res = 0;
+      }
+      const uint64_t m = __ballot(res != 0);
+      if (m) {
+        const int cnt = __popcll(m);
+        int base = 0;
+        if (lane == 0) base = (int)atomicAdd(&sh_ctr[4], (uint32_t)cnt);
+        base = __builtin_amdgcn_readfirstlane(base);
+        if (base + cnt <= QS_SHARED) {
+          if (res) {
+            const int slot_i = base + ballot_rank(m);
+            shq_s[slot_i] = res;
+            shq_k[slot_i] = ((uint32_t)(decode_y(res) - B) >> 1) << 12 | ((uint32_t)(decode_x(res) - B) >> 1);
+          }
+        } else if (lane == 0) {
+          sh_ctr[3] = 2;                            // too many survivors for the ranking buffer
+        }
+      }
+    }
+    __syncthreads();
+    if (sh_ctr[3] == 0) {
+      if (ablate & 128) return;
+      const int ns = (int)sh_ctr[4];
+      const size_t strip_slot = (size_t)pyr * P.slots_per_pyr + L.slot0 + (size_t)s * (L.R >> 1) * L.nbx;
+      const uint32_t add_xy = ((uint32_t)L.col0 << 12) | (uint32_t)L.row0;      // README.md:78
+      for (int i = tid; i < ns; i += NT) {
+        const uint32_t key = shq_k[i];
+        int rank = 0;
+        for (int j = 0; j < ns; j++) rank += shq_k[j] < key;
+        stage_kp[strip_slot + rank] = shq_s[i] + add_xy;
+      }
+      if (tid == 0) strip_count[(size_t)pyr * P.strips_per_pyr + L.strip0 + s] = (uint32_t)ns;
+      return;
+    }
+  }
+  // Fallback (a queue overflowed: very dense corners): scan the whole score tile.
   // ---- phase D: NMS in ONE pass.  The image tile is dead after the Harris phase, so its LDS is
   // reused as per-block-row survivor buffers: a wave appends its row's survivors in raster order,
   // then (after a barrier) the rows are copied out back to back = block-raster order of the strip.
@@ -390,6 +477,7 @@ __global__ __launch_bounds__(NT) void k_fused_strips(
     if (lane == 0) rowcnt[br] = cnt;
   }
   __syncthreads();
+  if (ablate & 128) return;                         // profiling only: NMS compute without the copy-out
   const size_t strip_slot = (size_t)pyr * P.slots_per_pyr + L.slot0 + (size_t)s * (L.R >> 1) * nbx;
   const uint32_t add_xy = ((uint32_t)L.col0 << 12) | (uint32_t)L.row0;      // README.md:78
   for (int br = wave; br < nbr; br += WAVES) {
