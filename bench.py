@@ -59,6 +59,8 @@ def main():
     ap.add_argument("--pipeline", type=int, default=0, help="0 auto (fused), 1 staged, 2 fused")
     ap.add_argument("--strip-rows", type=int, default=0)
     ap.add_argument("--orb-chunks", type=int, default=0)
+    ap.add_argument("--log-bucket-size", type=int, default=0, help="fastExtract logBucketSize (README uses 4)")
+    ap.add_argument("--bucket-limit", type=int, default=5, help="fastExtract bucketLimit (README uses 3)")
     ap.add_argument("--ablate", type=int, default=0, help="profiling only (results invalid): fused-kernel phase mask")
     args = ap.parse_args()
 
@@ -89,7 +91,8 @@ def main():
     ctx.set_option("strip_rows", args.strip_rows)
     ctx.set_option("orb_chunks", args.orb_chunks)
     ctx.set_option("ablate", args.ablate)
-    fe = OrbFrontend(levels, vstep=640, rows=rows, max_keypoints=args.max_keypoints, ctx=ctx)
+    fe = OrbFrontend(levels, vstep=640, rows=rows, max_keypoints=args.max_keypoints, ctx=ctx,
+                     log_bucket_size=args.log_bucket_size, bucket_limit=args.bucket_limit)
     fe.reserve(B)
     kp, desc, counts = fe.alloc_outputs(B, dev)
 
@@ -155,7 +158,7 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {
                 "workload": "batch=256 synthetic 640x480 pyramids per GPU, 8 levels x1.2 stacked (vstep=640, "
-                            "2210 rows), border=16, FAST threshold=20, Harris threshold=1<<15, no buckets, "
+                            "2210 rows), border=16, FAST threshold=20, Harris threshold=1<<15, " + ("no buckets" if not args.log_bucket_size else f"buckets <{args.log_bucket_size},{args.bucket_limit}>") + ", "
                             "256-bit descriptors (BASELINE.json configs[1])",
                 "batch_per_gpu": B, "global_batch": B * world, "distinct_pyramids_per_gpu": min(distinct, B),
                 "keypoints_per_pyramid": total_kp_step / (B * world),

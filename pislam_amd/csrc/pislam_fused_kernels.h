@@ -63,6 +63,7 @@ struct FusedParams {
   int vstep, rows, border, thr;
   int32_t hthr;
   int batch;
+  int lbs, limit;    // fastExtract logBucketSize (0 = none; fused path: 2..5) and bucketLimit
   int dump_score;    // debug: also write the score tile to the HBM score map
   int ablate;        // profiling only: bit0 stop after staging, bit1 pretest only, bit2 no Harris, bit3 no NMS
   FusedLevel lv[MAX_LEVELS];
@@ -406,17 +407,105 @@ __global__ __launch_bounds__(NT) void k_fused_strips(
       const int ns = (int)sh_ctr[4];
       const size_t strip_slot = (size_t)pyr * P.slots_per_pyr + L.slot0 + (size_t)s * (L.R >> 1) * L.nbx;
       const uint32_t add_xy = ((uint32_t)L.col0 << 12) | (uint32_t)L.row0;      // README.md:78
-      for (int i = tid; i < ns; i += NT) {
-        const uint32_t key = shq_k[i];
-        int rank = 0;
-        for (int j = 0; j < ns; j++) rank += shq_k[j] < key;
-        stage_kp[strip_slot + rank] = shq_s[i] + add_xy;
+      if (P.lbs == 0) {
+        for (int i = tid; i < ns; i += NT) {
+          const uint32_t key = shq_k[i];
+          int rank = 0;
+          for (int j = 0; j < ns; j++) rank += shq_k[j] < key;
+          stage_kp[strip_slot + rank] = shq_s[i] + add_xy;
+        }
+        if (tid == 0) strip_count[(size_t)pyr * P.strips_per_pyr + L.strip0 + s] = (uint32_t)ns;
+        return;
       }
-      if (tid == 0) strip_count[(size_t)pyr * P.strips_per_pyr + L.strip0 + s] = (uint32_t)ns;
+      // Buckets (Fast.h:314-352): a cell = one bucket x one flush interval = 2^lbs x 2^lbs pixels of
+      // block origins; it keeps its `limit` largest packed words, ASCENDING; cells are emitted in
+      // (cell-row, bucket) order.  Strip heights are multiples of the cell size, so cells never
+      // straddle strips.  Pass 1 marks the survivors that make their cell's top-`limit`, pass 2 ranks
+      // the kept ones by (cell, value).
+      const int lbs = P.lbs, limit = P.limit;
+      for (int i = tid; i < ns; i += NT) {
+        const uint32_t v = shq_s[i];
+        const uint32_t cell = (((uint32_t)(decode_y(v) - B) >> lbs) << 12) | ((uint32_t)(decode_x(v) - B) >> lbs);
+        shq_k[i] = cell;
+      }
+      __syncthreads();
+      lds_u32 *keep = shq_k + QS_SHARED;
+      for (int i = tid; i < ns; i += NT) {
+        const uint32_t v = shq_s[i], cell = shq_k[i];
+        int greater = 0;
+        for (int j = 0; j < ns; j++) greater += (shq_k[j] == cell) & (shq_s[j] > v);
+        keep[i] = greater < limit;
+      }
+      __syncthreads();
+      int kept_here = 0;
+      for (int i = tid; i < ns; i += NT) {
+        if (!keep[i]) continue;
+        const uint32_t v = shq_s[i], cell = shq_k[i];
+        int rank = 0;
+        for (int j = 0; j < ns; j++)
+          rank += keep[j] & ((shq_k[j] < cell) | ((shq_k[j] == cell) & (shq_s[j] < v)));
+        stage_kp[strip_slot + rank] = v + add_xy;
+        kept_here++;
+      }
+      if (kept_here) atomicAdd(&sh_ctr[5], (uint32_t)kept_here);
+      __syncthreads();
+      if (tid == 0) strip_count[(size_t)pyr * P.strips_per_pyr + L.strip0 + s] = sh_ctr[5];
       return;
     }
   }
   // Fallback (a queue overflowed: very dense corners): scan the whole score tile.
+  if (P.lbs != 0) {
+    // Bucket mode: one wave per cell, top-`limit` by repeated wave-max over the cell's blocks.
+    const int lbs = P.lbs, limit = P.limit, bs = 1 << lbs, hb = bs >> 1;
+    const int ncx = (Lw - 2 * B - 1) / bs + 1;                     // Fast.h:201 numBuckets
+    const int ncy = (ye - ys + bs - 1) / bs;
+    const int ncell = ncx * ncy, nblk = hb * hb;
+    const int capc = min(limit, nblk);                              // survivors a cell can keep
+    lds_u32 *cellres = (lds_u32 *)tile;                             // ncell x capc  (<= #blocks dwords)
+    lds_u32 *cellcnt = cellres + ncell * capc;                      // ncell
+    lds_u32 *cand = queues + wave * QCAP;                           // per-wave scratch: nblk <= 256 dwords
+    const int xlimc = Lw - B;
+    for (int cell = wave; cell < ncell; cell += WAVES) {
+      const int cy = cell / ncx, cx = cell - cy * ncx;
+      for (int i = lane; i < nblk; i += 64) {
+        const int by = i / hb, bxi = i - by * hb;
+        const int x = B + cx * bs + 2 * bxi, y = ys + cy * bs + 2 * by;
+        uint32_t r0 = 0;
+        if (x < xlimc && y < ye) r0 = nms_block(sc + (y - ys + 1) * pitch + x, pitch, x, y);
+        cand[i] = r0;
+      }
+      int nf_c = 0;
+      for (int k = 0; k < capc; k++) {
+        uint32_t best = 0;
+        for (int i = lane; i < nblk; i += 64) best = max(best, cand[i]);
+        best = wave_max_u32(best);
+        if (best == 0) break;
+        for (int i = lane; i < nblk; i += 64)
+          if (cand[i] == best) cand[i] = 0;
+        if (lane == 0) cellres[cell * capc + k] = best;               // descending; reversed on emit
+        nf_c++;
+      }
+      if (lane == 0) cellcnt[cell] = (uint32_t)nf_c;
+    }
+    __syncthreads();
+    const size_t strip_slot = (size_t)pyr * P.slots_per_pyr + L.slot0 + (size_t)s * (L.R >> 1) * L.nbx;
+    const uint32_t add_xy = ((uint32_t)L.col0 << 12) | (uint32_t)L.row0;
+    for (int cell = wave; cell < ncell; cell += WAVES) {
+      const uint32_t n = cellcnt[cell];
+      if (n == 0) continue;
+      uint32_t off = 0;
+      for (int k = lane; k < cell; k += 64) off += cellcnt[k];
+      off = (uint32_t)wave_sum((int)off);
+      if ((uint32_t)lane < n) stage_kp[strip_slot + off + lane] = cellres[cell * capc + (n - 1 - lane)] + add_xy;
+    }
+    if (wave == 0) {
+      uint32_t tot = 0;
+      for (int k = lane; k < ncell; k += 64) tot += cellcnt[k];
+      tot = (uint32_t)wave_sum((int)tot);
+      if (lane == 0) strip_count[(size_t)pyr * P.strips_per_pyr + L.strip0 + s] = tot;
+    }
+    return;
+  }
   // ---- phase D: NMS in ONE pass.  The image tile is dead after the Harris phase, so its LDS is
   // reused as per-block-row survivor buffers: a wave appends its row's survivors in raster order,
   // then (after a barrier) the rows are copied out back to back = block-raster order of the strip.

@@ -630,6 +630,10 @@ bool build_fused_plan(const pislam_ctx *c, const pislam_frontend_params *p, cons
   F->hthr = p->harris_threshold;
   F->batch = batch;
   F->dump_score = c->opt_dump_score;
+  F->lbs = p->log_bucket_size;
+  F->limit = p->bucket_limit;
+  // fused bucket mode: cells of 4..32 px (they must fit a strip and the per-wave scratch)
+  if (p->log_bucket_size != 0 && (p->log_bucket_size < 2 || p->log_bucket_size > 5)) return false;
   F->ablate = c->opt_ablate;
   int strips = 0, slots = 0;
   size_t lds = 0;
@@ -654,6 +658,10 @@ bool build_fused_plan(const pislam_ctx *c, const pislam_frontend_params *p, cons
     if (R == 0) {
       R = (8192 / L.w) & ~1;
       R = std::min(32, std::max(16, R));
+    }
+    if (p->log_bucket_size) {            // strips hold whole bucket rows
+      const int bs = 1 << p->log_bucket_size;
+      R = std::max(bs, (R / bs) * bs);
     }
     L.R = R;
     L.nstrips = cdiv(ny, R);
@@ -774,9 +782,9 @@ PISLAM_EXPORT int pislam_orb_frontend_batch(pislam_ctx *c, const pislam_frontend
   c->last_stride = pyr_bytes;
   pf::FusedParams F;
   size_t lds = 0;
-  bool fused = c->opt_pipeline != 1 && p->log_bucket_size == 0 && build_fused_plan(c, p, lv, batch, &F, &lds);
+  bool fused = c->opt_pipeline != 1 && build_fused_plan(c, p, lv, batch, &F, &lds);
   if (c->opt_pipeline == 2 && !fused)
-    return fail(c, PISLAM_ERR_INVALID, "fused pipeline unavailable for these parameters (buckets / LDS size)");
+    return fail(c, PISLAM_ERR_INVALID, "fused pipeline unavailable for these parameters (bucket size / LDS size)");
   c->last_pipeline = fused ? 2 : 1;
   HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
   if (fused) {

@@ -80,8 +80,7 @@ def test_batch_path_on_reference_demo_pyramid(gpu_ctx, demo, pipeline):
         sm = None
     if sm is not None:
         assert sha16(sm) == SURVEY_PINS["score"]
-    # bucketed mode (README's recommended <4,3>): auto mode picks the staged pipeline for it
-    gpu_ctx.set_option("pipeline", 0)
+    # bucketed mode (README's recommended <4,3>), same pipeline
     feb = OrbFrontend(demo["levels"], vstep=640, rows=2210, max_keypoints=4096, log_bucket_size=4,
                       bucket_limit=3, ctx=gpu_ctx)
     feb(pyr, kp, desc, counts)
@@ -238,18 +237,41 @@ def test_fused_odd_shapes_and_unaligned_layouts(gpu_ctx, orc):
     dev = torch.device("cuda:0")
     d_pyr = torch.from_numpy(pyr).to(dev)
     res = {}
-    for pl in (1, 2):
-        gpu_ctx.set_option("pipeline", pl)
-        try:
-            fe = OrbFrontend(levels, vstep=vstep, rows=rows, max_keypoints=8192, ctx=gpu_ctx)
-            kp, desc, counts = fe.alloc_outputs(B, dev)
-            fe(d_pyr, kp, desc, counts)
-            torch.cuda.synchronize()
-            res[pl] = tuple(t.cpu().numpy().view(np.uint32) for t in (counts, kp, desc))
-        finally:
-            gpu_ctx.set_option("pipeline", 0)
-    for a, b in zip(res[1], res[2]):
-        assert (a == b).all()
+    for lb, lim in [(0, 5), (4, 3), (2, 1), (3, 2), (5, 40)]:
+        for pl in (1, 2):
+            gpu_ctx.set_option("pipeline", pl)
+            try:
+                fe = OrbFrontend(levels, vstep=vstep, rows=rows, max_keypoints=8192, log_bucket_size=lb,
+                                 bucket_limit=lim, ctx=gpu_ctx)
+                kp, desc, counts = fe.alloc_outputs(B, dev)
+                fe(d_pyr, kp, desc, counts)
+                torch.cuda.synchronize()
+                res[pl] = tuple(t.cpu().numpy().view(np.uint32) for t in (counts, kp, desc))
+            finally:
+                gpu_ctx.set_option("pipeline", 0)
+        for a, b in zip(res[1], res[2]):
+            assert (a == b).all(), (lb, lim)
+        if lb:      # buckets vs the oracle on one pyramid (dense noise -> exercises the per-cell fallback)
+            c, k, d = res[2]
+            exp = []
+            for (w, h, r0, c0) in levels:
+                view = np.ascontiguousarray(pyr[3, r0:r0 + h].reshape(-1)[c0:])
+                view = np.concatenate([view, np.zeros((-len(view)) % vstep, np.uint8)]).reshape(-1, vstep)
+                lkp, _, _ = orc.pyramid(view, [(w, h, 0)], log_bucket=lb, bucket_limit=lim)
+                exp.append(lkp + np.uint32((c0 << 12) | r0))
+            exp = np.concatenate(exp)
+            assert c[3] == len(exp) and (k[3, :len(exp)] == exp).all(), (lb, lim)
+    gpu_ctx.set_option("pipeline", 1)
+    fe = OrbFrontend(levels, vstep=vstep, rows=rows, max_keypoints=8192, ctx=gpu_ctx)
+    kp, desc, counts = fe.alloc_outputs(B, dev)
+    fe(d_pyr, kp, desc, counts)
+    torch.cuda.synchronize()
+    res[1] = tuple(t.cpu().numpy().view(np.uint32) for t in (counts, kp, desc))
+    gpu_ctx.set_option("pipeline", 2)
+    fe(d_pyr, kp, desc, counts)
+    torch.cuda.synchronize()
+    res[2] = tuple(t.cpu().numpy().view(np.uint32) for t in (counts, kp, desc))
+    gpu_ctx.set_option("pipeline", 0)
     # and against the oracle, level by level (col0 != 0 -> offset views)
     c, k, d = res[2]
     for b in (0, 5, 10):
@@ -277,8 +299,6 @@ def test_batch_parity_on_synthetic_pyramids(gpu_ctx, orc, pipeline):
     dev = torch.device("cuda:0")
     d_pyr = torch.from_numpy(pyr).to(dev)
     for lb, lim, cap in [(0, 5, 4096), (4, 3, 4096), (0, 5, 300)]:
-        if lb and pipeline == 2:
-            continue            # buckets run on the staged pipeline (auto mode falls back)
         fe = OrbFrontend(levels, vstep=640, rows=2210, max_keypoints=cap, log_bucket_size=lb, bucket_limit=lim,
                          ctx=gpu_ctx)
         kp, desc, counts = fe.alloc_outputs(B, dev)
