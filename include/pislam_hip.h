@@ -122,6 +122,25 @@ int pislam_brief_describe(pislam_ctx *ctx, int vstep, int words, const uint8_t *
  * kernels use (behaviour of Brief.h:28-53); host memory, 30720 bytes. */
 const int8_t *pislam_brief_table(void);
 
+/* ---- image preparation ("next" tier) -------------------- */
+
+/* replaces pislam::gaussian5x5<vstep>(width,height,img,out) — reference include/Gaussian.h:48.
+ * Separable [1 4 6 4 1]/16 built from rounding halving adds, vertical then horizontal, reflect-101
+ * borders: bit-exact to the reference's stated expectation (test/GaussianTest.cpp:159-215).
+ * Writes the width x height region only; img == out (in place) is allowed. */
+int pislam_gaussian5x5(pislam_ctx *ctx, int vstep, int width, int height, const uint8_t *img,
+                       uint8_t *out);
+
+/* replace pislam::bilinear7_8<vstep> / bilinear13_16<vstep>(width,height,img,out) — reference
+ * include/Bilinear.h:42 / :165; arithmetic of test/BilinearTest.cpp:171-196 / :198-233.  The image
+ * must be padded to a multiple of 8 / 16 in both dimensions (Bilinear.h:32,155); output dimensions
+ * round down (floor(w*7/8) x floor(h*7/8), resp. 13/16); like the reference, whole 7x7 / 13x13
+ * output blocks are written.  img == out is allowed. */
+int pislam_bilinear7_8(pislam_ctx *ctx, int vstep, int width, int height, const uint8_t *img,
+                       uint8_t *out);
+int pislam_bilinear13_16(pislam_ctx *ctx, int vstep, int width, int height, const uint8_t *img,
+                         uint8_t *out);
+
 /* ---- the measured path: a batch of stacked pyramids, device resident --- */
 
 typedef struct pislam_level {

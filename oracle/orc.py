@@ -61,6 +61,11 @@ def lib():
                                   ctypes.c_void_p, _i, ctypes.c_void_p, ctypes.c_void_p, _sz,
                                   ctypes.c_void_p]
         L.orc_pyramid.restype = _sz
+        for name in ("orc_gaussian5x5", "orc_bilinear7_8", "orc_bilinear13_16"):
+            getattr(L, name).argtypes = [_i, _i, _i, c_u8p]
+            getattr(L, name).restype = None
+        L.orc_fill_spiral.argtypes = [_i, _i, _i, _i, _i, c_u8p]
+        L.orc_fill_spiral.restype = None
         _LIB = L
     return _LIB
 
@@ -151,3 +156,28 @@ def pyramid(img, levels, fast_threshold=20, harris_threshold=1 << 15, border=16,
     m = min(n, cap)
     res = (kp[:m].copy(), desc[:m].copy(), lc)
     return res + (score,) if return_score else res
+
+
+def gaussian5x5(img, width, height):
+    """test/GaussianTest.cpp:159-215 reference(): in place on a 2-D uint8 [rows][vstep] array."""
+    assert img.dtype == np.uint8 and img.flags.c_contiguous
+    lib().orc_gaussian5x5(img.shape[1], width, height, img.ctypes.data)
+
+
+def bilinear7_8(img, width, height):
+    """test/BilinearTest.cpp:171-196 reference7_8(): in place."""
+    assert img.dtype == np.uint8 and img.flags.c_contiguous
+    lib().orc_bilinear7_8(img.shape[1], width, height, img.ctypes.data)
+
+
+def bilinear13_16(img, width, height):
+    """test/BilinearTest.cpp:208-233 reference13_16(): in place."""
+    assert img.dtype == np.uint8 and img.flags.c_contiguous
+    lib().orc_bilinear13_16(img.shape[1], width, height, img.ctypes.data)
+
+
+def fill_spiral(vstep, width, height, cx, cy, rows=None):
+    """test/TestUtil.cpp:28-55 fill_spiral into a fresh [rows][vstep] buffer (rows >= height)."""
+    buf = np.zeros((rows or height, vstep), np.uint8)
+    lib().orc_fill_spiral(vstep, width, height, cx, cy, buf.ctypes.data)
+    return buf

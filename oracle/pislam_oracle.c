@@ -496,3 +496,103 @@ ORC_API size_t orc_pyramid(int vstep, int border, int fast_threshold, int32_t ha
   orc_orb_compute(vstep, words, img, kp, stored, desc);
   return n;
 }
+
+/* ========================================================================= */
+/* "Next" tier: image preparation.  The reference's NEON/asm  */
+/* (Gaussian.h, Bilinear.h) cannot be built here; its OWN tests state the       */
+/* expected arithmetic as scalar reference functions, restated below.           */
+/* ========================================================================= */
+
+/* test/GaussianTest.cpp:32 — RHADD(a,b) = (a>>1)+(b>>1)+((a|b)&1) = (a+b+1)>>1 */
+static inline unsigned rhadd(unsigned a, unsigned b) { return (a >> 1) + (b >> 1) + ((a | b) & 1u); }
+
+/* test/GaussianTest.cpp:159-215 `reference()`: in-place separable [1 4 6 4 1]/16 built from RHADDs,
+ * vertical pass then horizontal pass on its result, reflect-101 borders.  (pislam::gaussian5x5<vstep>,
+ * Gaussian.h:48, is asserted equal to this on the width x height region.) */
+ORC_API void orc_gaussian5x5(int vstep, int width, int height, uint8_t *m) {
+  for (int j = 0; j < width; j++) {                          /* GaussianTest.cpp:162-186 */
+    unsigned a = m[2 * vstep + j], b = m[1 * vstep + j], c = m[j], d = m[1 * vstep + j], e;
+    for (int i = 0; i < height; i++) {
+      if (i == height - 2) e = c;
+      else if (i == height - 1) e = a;
+      else e = m[(ptrdiff_t)(i + 2) * vstep + j];
+      unsigned x = rhadd(a, e), y = rhadd(b, d);
+      x = rhadd(x, c);
+      x = rhadd(x, c);
+      m[(ptrdiff_t)i * vstep + j] = (uint8_t)rhadd(x, y);
+      a = b; b = c; c = d; d = e;
+    }
+  }
+  for (int i = 0; i < height; i++) {                         /* GaussianTest.cpp:189-213 */
+    uint8_t *r = m + (ptrdiff_t)i * vstep;
+    unsigned a = r[2], b = r[1], c = r[0], d = r[1], e;
+    for (int j = 0; j < width; j++) {
+      if (j == width - 2) e = c;
+      else if (j == width - 1) e = a;
+      else e = r[j + 2];
+      unsigned x = rhadd(a, e), y = rhadd(b, d);
+      x = rhadd(x, c);
+      x = rhadd(x, c);
+      r[j] = (uint8_t)rhadd(x, y);
+      a = b; b = c; c = d; d = e;
+    }
+  }
+}
+
+/* test/BilinearTest.cpp:35 — RSHR(a,n) = (a>>n) + ((a>>(n-1))&1) = (a + 2^(n-1)) >> n */
+static inline int rshr8(int a) { return (a >> 8) + ((a >> 7) & 1); }
+
+/* test/BilinearTest.cpp:171-196 `reference7_8()`: in place, per 8x8 block 7x7 outputs.
+ * (pislam::bilinear7_8<vstep>, Bilinear.h:42, is asserted equal on the (h*7/8) x (w*7/8) region.) */
+ORC_API void orc_bilinear7_8(int vstep, int width, int height, uint8_t *m) {
+  static const int f[7] = {238, 201, 165, 128, 91, 55, 18};
+  for (int i = 0, oi = 0; i < height; i += 8, oi += 7)
+    for (int j = 0, oj = 0; j < width; j += 8, oj += 7)
+      for (int y = 0; y < 7; y++)
+        for (int x = 0; x < 7; x++) {
+          const int p00 = m[(ptrdiff_t)vstep * (i + y) + (j + x)], p01 = m[(ptrdiff_t)vstep * (i + y) + (j + x + 1)];
+          const int p10 = m[(ptrdiff_t)vstep * (i + y + 1) + (j + x)], p11 = m[(ptrdiff_t)vstep * (i + y + 1) + (j + x + 1)];
+          const int h0 = rshr8(p00 * f[x] + p01 * f[6 - x]);
+          const int h1 = rshr8(p10 * f[x] + p11 * f[6 - x]);
+          m[(ptrdiff_t)vstep * (oi + y) + (oj + x)] = (uint8_t)rshr8(h0 * f[y] + h1 * f[6 - y]);
+        }
+}
+
+static inline int map13(int i) {                             /* BilinearTest.cpp:198-206 */
+  if (i > 3) i += 1;
+  if (i > 9) i += 1;
+  return i;
+}
+
+/* test/BilinearTest.cpp:208-233 `reference13_16()` (note f[10] = 138, as in Bilinear.h:172-180). */
+ORC_API void orc_bilinear13_16(int vstep, int width, int height, uint8_t *m) {
+  static const int f[13] = {226, 167, 108, 49, 246, 187, 128, 69, 10, 207, 138, 89, 30};
+  for (int i = 0, oi = 0; i < height; i += 16, oi += 13)
+    for (int j = 0, oj = 0; j < width; j += 16, oj += 13)
+      for (int y = 0; y < 13; y++)
+        for (int x = 0; x < 13; x++) {
+          const int yy = i + map13(y), xx = j + map13(x);
+          const int p00 = m[(ptrdiff_t)vstep * yy + xx], p01 = m[(ptrdiff_t)vstep * yy + xx + 1];
+          const int p10 = m[(ptrdiff_t)vstep * (yy + 1) + xx], p11 = m[(ptrdiff_t)vstep * (yy + 1) + xx + 1];
+          const int h0 = rshr8(p00 * f[x] + p01 * f[12 - x]);
+          const int h1 = rshr8(p10 * f[x] + p11 * f[12 - x]);
+          m[(ptrdiff_t)vstep * (oi + y) + (oj + x)] = (uint8_t)rshr8(h0 * f[y] + h1 * f[12 - y]);
+        }
+}
+
+/* test/TestUtil.cpp:28-55 fill_spiral — the fixture of GaussianTest / BilinearTest (golden-ratio spiral
+ * of 0xff on zeros; float32 math as in the reference). */
+ORC_API void orc_fill_spiral(int vstep, int width, int height, int cx, int cy, uint8_t *buffer) {
+  (void)width;
+  memset(buffer, 0, (size_t)vstep * (size_t)height);
+  const float phi = (1 + sqrtf(5)) / 2;
+  for (float theta = 0; theta < 20; theta += 0.01f) {
+    const float r = powf(phi, (float)(theta * M_2_PI));
+    const float x = r * cosf(theta), y = r * sinf(theta);
+    int i = (int)(y + cy), j = (int)(x + cx);
+    if (0 <= i && i < vstep && 0 <= j && j < vstep && i < height) buffer[i * vstep + j] = 0xff;
+    i = (int)(-y + cy);
+    j = (int)(-x + cx);
+    if (0 <= i && i < vstep && 0 <= j && j < vstep && i < height) buffer[i * vstep + j] = 0xff;
+  }
+}

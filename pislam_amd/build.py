@@ -10,7 +10,7 @@ CSRC = os.path.join(PKG, "csrc")
 LIBDIR = os.path.join(PKG, "lib")
 LIB = os.path.join(LIBDIR, "libpislam_hip.so")
 SOURCES = ["pislam_hip.hip"]
-HEADERS = ["pislam_dev.h", "pislam_stage_kernels.h", "pislam_fused_kernels.h", "brief_table.inc"]
+HEADERS = ["pislam_dev.h", "pislam_stage_kernels.h", "pislam_fused_kernels.h", "pislam_prep_kernels.h", "brief_table.inc"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
          "-fvisibility=hidden"]
 

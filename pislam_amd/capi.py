@@ -49,6 +49,9 @@ SYMBOLS = {
     "pislam_orb_angles": (_i, [_vp, _vp, _sz, _vp]),
     "pislam_brief_describe": (_i, [_vp, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     "pislam_brief_table": (ctypes.POINTER(ctypes.c_int8), []),
+    "pislam_gaussian5x5": (_i, [_vp, _i, _i, _i, _vp, _vp]),
+    "pislam_bilinear7_8": (_i, [_vp, _i, _i, _i, _vp, _vp]),
+    "pislam_bilinear13_16": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "pislam_orb_frontend_batch": (_i, [_vp, ctypes.POINTER(FrontendParams), ctypes.POINTER(Level), _vp,
                                        _sz, _i, _vp, _vp, _vp]),
     "pislam_frontend_reserve": (_i, [_vp, ctypes.POINTER(FrontendParams), ctypes.POINTER(Level), _i]),

@@ -39,6 +39,7 @@ __device__ const BriefOfsTab g_brief_ofs = make_brief_ofs();
 
 #include "pislam_stage_kernels.h"
 #include "pislam_fused_kernels.h"
+#include "pislam_prep_kernels.h"
 
 #define PISLAM_EXPORT extern "C" __attribute__((visibility("default")))
 
@@ -79,7 +80,7 @@ struct pislam_ctx {
   hipStream_t stream = nullptr;
   std::string err;
   // staging for host-pointer calls
-  DevBuf s_img, s_out, s_pts, s_desc, s_misc, s_rots;
+  DevBuf s_img, s_out, s_pts, s_desc, s_misc, s_rots, s_tmp;
   // compaction scratch (shared by extract and the batch pipeline)
   DevBuf w_cnt, w_off, w_total, w_cellkp;
   // batch pipeline workspace
@@ -358,7 +359,7 @@ PISLAM_EXPORT int pislam_ctx_destroy(pislam_ctx *c) {
   if (!c) return PISLAM_ERR_INVALID;
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
-  for (DevBuf *b : {&c->s_img, &c->s_out, &c->s_pts, &c->s_desc, &c->s_misc, &c->s_rots, &c->w_cnt,
+  for (DevBuf *b : {&c->s_img, &c->s_out, &c->s_pts, &c->s_desc, &c->s_misc, &c->s_rots, &c->s_tmp, &c->w_cnt,
                     &c->w_off, &c->w_total, &c->w_cellkp, &c->w_score, &c->w_stage, &c->w_stripcnt})
     b->release();
   for (auto &e : c->ev)
@@ -585,6 +586,79 @@ PISLAM_EXPORT int pislam_harris_score_points(pislam_ctx *c, int vstep, const uin
   PCHK(launch_ok(c, "k_harris_points"));
   PCHK(stage_out(c, ss, scores, n));
   return sync(c);
+}
+
+
+// ===========================================================================
+// image preparation ("next" tier): gaussian5x5, bilinear7_8, bilinear13_16
+// ===========================================================================
+namespace {
+// kind 0 = gaussian5x5, 1 = bilinear7_8, 2 = bilinear13_16
+int prep_common(pislam_ctx *c, int kind, int vstep, int width, int height, const uint8_t *img, uint8_t *out) {
+  if (!c) return PISLAM_ERR_INVALID;
+  if (!img || !out) return fail(c, PISLAM_ERR_INVALID, "null image");
+  if (vstep <= 0 || width <= 0 || height <= 0) return fail(c, PISLAM_ERR_INVALID, "bad vstep/width/height");
+  const int N = kind == 0 ? 1 : (kind == 1 ? 8 : 16);
+  const int wpad = (width + N - 1) / N * N, hpad = (height + N - 1) / N * N;   // Bilinear.h:32,155 padding
+  if (wpad > vstep) return fail(c, PISLAM_ERR_INVALID, "width (padded to the block size) exceeds vstep");
+  if (kind == 0 && (width < 3 || height < 3)) return fail(c, PISLAM_ERR_INVALID, "gaussian5x5 needs at least 3x3");
+  HIPCHK(c, hipSetDevice(c->device));
+  const size_t in_bytes = (size_t)hpad * vstep;
+  const int M = kind == 1 ? 7 : 13;
+  const size_t out_rows = kind == 0 ? (size_t)height : (size_t)(hpad / N) * M;
+  const size_t out_bytes = out_rows * vstep;
+  Staged si, so;
+  PCHK(stage_in(c, c->s_img, img, in_bytes, &si));
+  const bool inplace = img == out;
+  const uint8_t *d_src = (const uint8_t *)si.dev;
+  uint8_t *d_dst;
+  if (inplace) {
+    // results are a pure function of the ORIGINAL image (as the reference's in-place loops are):
+    // run from a private copy of the source
+    if (c->s_tmp.ensure(in_bytes) != PISLAM_OK) return fail(c, PISLAM_ERR_NOMEM, "hipMalloc(prep temp)");
+    HIPCHK(c, hipMemcpyAsync(c->s_tmp.p, d_src, in_bytes, hipMemcpyDeviceToDevice, c->stream));
+    d_src = c->s_tmp.as<uint8_t>();
+    d_dst = (uint8_t *)si.dev;
+    so = si;
+  } else {
+    PCHK(stage_in(c, c->s_out, out, std::max(out_bytes, (size_t)1), &so));   // keep untouched bytes
+    d_dst = (uint8_t *)so.dev;
+  }
+  if (kind == 0) {
+    dim3 grid(cdiv(width, pp::G_TW), cdiv(height, pp::G_TH), 1);
+    hipLaunchKernelGGL(pp::k_gaussian5x5, grid, dim3(256), 0, c->stream, d_src, d_dst, vstep, vstep, (size_t)0,
+                       (size_t)0, width, height);
+  } else if (kind == 1) {
+    dim3 grid(cdiv(wpad / 8 * 7, 64), cdiv(hpad / 8 * 7, 4), 1);
+    hipLaunchKernelGGL((pp::k_bilinear<8, 7>), grid, dim3(256), 0, c->stream, d_src, d_dst, vstep, vstep, (size_t)0,
+                       (size_t)0, width, height);
+  } else {
+    dim3 grid(cdiv(wpad / 16 * 13, 64), cdiv(hpad / 16 * 13, 4), 1);
+    hipLaunchKernelGGL((pp::k_bilinear<16, 13>), grid, dim3(256), 0, c->stream, d_src, d_dst, vstep, vstep, (size_t)0,
+                       (size_t)0, width, height);
+  }
+  PCHK(launch_ok(c, "prep kernel"));
+  if (so.host) {
+    PCHK(stage_out(c, so, out, out_bytes));   // rows the kernels can have written
+    PCHK(sync(c));
+  } else if (si.host) {
+    PCHK(sync(c));
+  }
+  return PISLAM_OK;
+}
+}  // namespace
+
+PISLAM_EXPORT int pislam_gaussian5x5(pislam_ctx *c, int vstep, int width, int height, const uint8_t *img,
+                                     uint8_t *out) {
+  return prep_common(c, 0, vstep, width, height, img, out);
+}
+PISLAM_EXPORT int pislam_bilinear7_8(pislam_ctx *c, int vstep, int width, int height, const uint8_t *img,
+                                     uint8_t *out) {
+  return prep_common(c, 1, vstep, width, height, img, out);
+}
+PISLAM_EXPORT int pislam_bilinear13_16(pislam_ctx *c, int vstep, int width, int height, const uint8_t *img,
+                                       uint8_t *out) {
+  return prep_common(c, 2, vstep, width, height, img, out);
 }
 
 // ===========================================================================

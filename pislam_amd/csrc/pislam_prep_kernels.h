@@ -1,0 +1,110 @@
+// pislam_prep_kernels.h — image preparation ("next" tier): the 5x5 Gaussian and
+// the 7/8 and 13/16 bilinear reductions of reference include/Gaussian.h / include/Bilinear.h.
+// The expected arithmetic is the one the reference's own tests state as scalar references
+// (test/GaussianTest.cpp:159-215, test/BilinearTest.cpp:171-233); these kernels are bit-exact to it.
+// All three are pure HBM streaming kernels (1 byte read + ~1 byte written per pixel).
+#pragma once
+#include "pislam_dev.h"
+
+namespace pp {
+
+// rounding halving add, GaussianTest.cpp:32 / the vrhadd tree of Gaussian.h:182-237
+__device__ __forceinline__ uint32_t rhadd(uint32_t a, uint32_t b) { return (a + b + 1) >> 1; }
+// [1 4 6 4 1]/16 as the reference builds it: RHADD(RHADD(RHADD(RHADD(a,e),c),c), RHADD(b,d))
+__device__ __forceinline__ uint32_t tap5(uint32_t a, uint32_t b, uint32_t c, uint32_t d, uint32_t e) {
+  return rhadd(rhadd(rhadd(rhadd(a, e), c), c), rhadd(b, d));
+}
+// reflect-101 index (GaussianTest.cpp:164-175,191-202): -1 -> 1, -2 -> 2, n -> n-2, n+1 -> n-3
+__device__ __forceinline__ int reflect101(int i, int n) {
+  i = i < 0 ? -i : i;
+  return i >= n ? 2 * (n - 1) - i : i;
+}
+
+// ---------------------------------------------------------------------------
+// gaussian5x5 — reference Gaussian.h:48 (behaviour: GaussianTest.cpp:159-215).
+// grid (tiles_x, tiles_y, batch); 256 threads; output tile 128 x 16.  The tile plus a 2 px halo is
+// staged into LDS with the border reflection applied, the vertical pass runs LDS -> LDS, the
+// horizontal pass produces 4 pixels per lane and stores them as one dword.
+// src and dst must not alias (the ABI stages in-place calls through a temporary).
+// ---------------------------------------------------------------------------
+constexpr int G_TW = 128, G_TH = 16;
+__global__ __launch_bounds__(256) void k_gaussian5x5(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst,
+                                                     int vstep_src, int vstep_dst, size_t stride_src,
+                                                     size_t stride_dst, int width, int height) {
+  __shared__ uint8_t in[(G_TH + 4) * (G_TW + 4)];
+  __shared__ uint8_t mid[G_TH * (G_TW + 4)];
+  const uint8_t *s = src + (size_t)blockIdx.z * stride_src;
+  uint8_t *d = dst + (size_t)blockIdx.z * stride_dst;
+  const int x0 = blockIdx.x * G_TW, y0 = blockIdx.y * G_TH;
+  for (int i = threadIdx.x; i < (G_TH + 4) * (G_TW + 4); i += 256) {
+    const int r = i / (G_TW + 4), c = i - r * (G_TW + 4);
+    const int gy = reflect101(y0 - 2 + r, height), gx = reflect101(x0 - 2 + c, width);
+    // tiles may overhang the image: clamp so that the (unused) reads stay inside it
+    in[i] = s[(ptrdiff_t)min(max(gy, 0), height - 1) * vstep_src + min(max(gx, 0), width - 1)];
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < G_TH * (G_TW + 4); i += 256) {
+    const int r = i / (G_TW + 4), c = i - r * (G_TW + 4);
+    const uint8_t *p = in + r * (G_TW + 4) + c;
+    mid[i] = (uint8_t)tap5(p[0], p[G_TW + 4], p[2 * (G_TW + 4)], p[3 * (G_TW + 4)], p[4 * (G_TW + 4)]);
+  }
+  __syncthreads();
+  // horizontal pass: the reference reflects the VERTICAL RESULT at the left/right image border
+  // (GaussianTest.cpp:189-213); the halo columns of `mid` hold exactly those reflected columns
+  // because reflection commutes with the column-wise vertical pass.
+  for (int i = threadIdx.x; i < G_TH * (G_TW / 4); i += 256) {
+    const int r = i / (G_TW / 4), q = i - r * (G_TW / 4);
+    const int gy = y0 + r, gx = x0 + 4 * q;
+    if (gy >= height || gx >= width) continue;
+    const uint8_t *p = mid + r * (G_TW + 4) + 4 * q;
+    uint32_t o[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) o[k] = tap5(p[k], p[k + 1], p[k + 2], p[k + 3], p[k + 4]);
+    uint8_t *out = d + (ptrdiff_t)gy * vstep_dst + gx;
+    if (gx + 4 <= width && (((uintptr_t)out) & 3) == 0) {
+      *(uint32_t *)out = o[0] | (o[1] << 8) | (o[2] << 16) | (o[3] << 24);
+    } else {
+      for (int k = 0; k < 4 && gx + k < width; k++) out[k] = (uint8_t)o[k];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// bilinear7_8 / bilinear13_16 — reference Bilinear.h:42 / :165 (behaviour:
+// BilinearTest.cpp:171-196 / :198-233).  One lane per output pixel; every N x N source block
+// (N = 8 or 16) yields M x M outputs (M = 7 or 13); the four taps and two filter weights per axis
+// come from small constant tables.  The reference's fixed-point rounding RSHR(a,8) = (a+128)>>8.
+// Writes the same full M x M blocks the scalar reference writes (outputs beyond
+// floor(w*M/N) x floor(h*M/N) depend on the caller's padding, exactly as in the reference).
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ int rshr8(int a) { return (a + 128) >> 8; }
+
+template <int N, int M>
+__global__ __launch_bounds__(256) void k_bilinear(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst,
+                                                  int vstep_src, int vstep_dst, size_t stride_src,
+                                                  size_t stride_dst, int width, int height) {
+  // filter banks: Bilinear.h:49-52 (7/8) and Bilinear.h:172-180 (13/16; f[10] = 138 as in the reference)
+  constexpr int F7[7] = {238, 201, 165, 128, 91, 55, 18};
+  constexpr int F13[13] = {226, 167, 108, 49, 246, 187, 128, 69, 10, 207, 138, 89, 30};
+  const int nbx = (width + N - 1) / N, nby = (height + N - 1) / N;
+  const int ow = nbx * M, oh = nby * M;
+  const int ox = blockIdx.x * 64 + (threadIdx.x & 63), oy = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (ox >= ow || oy >= oh) return;
+  const uint8_t *s = src + (size_t)blockIdx.z * stride_src;
+  uint8_t *d = dst + (size_t)blockIdx.z * stride_dst;
+  const int bx = ox / M, x = ox - bx * M, by = oy / M, y = oy - by * M;
+  int sx = x, sy = y, fx0, fx1, fy0, fy1;
+  if (M == 7) {
+    fx0 = F7[x]; fx1 = F7[6 - x]; fy0 = F7[y]; fy1 = F7[6 - y];
+  } else {
+    sx += (x > 3) + (x > 8);      // map13 (BilinearTest.cpp:198-206): skip source columns 4 and 10
+    sy += (y > 3) + (y > 8);
+    fx0 = F13[x]; fx1 = F13[12 - x]; fy0 = F13[y]; fy1 = F13[12 - y];
+  }
+  const uint8_t *p = s + (ptrdiff_t)(by * N + sy) * vstep_src + (bx * N + sx);
+  const int h0 = rshr8(p[0] * fx0 + p[1] * fx1);
+  const int h1 = rshr8(p[vstep_src] * fx0 + p[vstep_src + 1] * fx1);
+  d[(ptrdiff_t)oy * vstep_dst + ox] = (uint8_t)rshr8(h0 * fy0 + h1 * fy1);
+}
+
+}  // namespace pp

@@ -162,6 +162,26 @@ def orbCompute(img, points, descriptors: list | None = None, *, words=8,
     return desc
 
 
+# ---- Gaussian.h:48, Bilinear.h:42, Bilinear.h:165 -------------------------------------
+def gaussian5x5(width, height, img, out, *, ctx: Context | None = None):
+    """pislam::gaussian5x5<vstep>(width, height, img, out); img may be out (in place)."""
+    ctx = ctx or default_context()
+    ctx.check(ctx.lib.pislam_gaussian5x5(ctx.h, _vstep(img), width, height, ptr(img), ptr(out)), "pislam_gaussian5x5")
+
+
+def bilinear7_8(width, height, img, out, *, ctx: Context | None = None):
+    """pislam::bilinear7_8<vstep>(width, height, img, out)."""
+    ctx = ctx or default_context()
+    ctx.check(ctx.lib.pislam_bilinear7_8(ctx.h, _vstep(img), width, height, ptr(img), ptr(out)), "pislam_bilinear7_8")
+
+
+def bilinear13_16(width, height, img, out, *, ctx: Context | None = None):
+    """pislam::bilinear13_16<vstep>(width, height, img, out)."""
+    ctx = ctx or default_context()
+    ctx.check(ctx.lib.pislam_bilinear13_16(ctx.h, _vstep(img), width, height, ptr(img), ptr(out)),
+              "pislam_bilinear13_16")
+
+
 # ---- the measured path ---------------------------------------------------------
 class OrbFrontend:
     """Batch of device-resident stacked pyramids -> keypoints + descriptors + counts.

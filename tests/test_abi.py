@@ -63,6 +63,8 @@ def test_dropin_headers_compile_against_reference_usage(tmp_path):
 #include <cstdint>
 #include "pislam/Fast.h"
 #include "pislam/Orb.h"
+#include "pislam/Gaussian.h"
+#include "pislam/Bilinear.h"
 struct L { int width, height; };
 static L pyramidLevels[8] = {{640,480},{533,400},{444,333},{370,278},{309,231},{257,193},{214,161},{179,134}};
 static uint8_t img[2210][640];
@@ -82,6 +84,9 @@ int main() {
     y += height;
   }
   pislam::orbCompute<640, 8>(img, keypoints, descriptors);
+  pislam::gaussian5x5<640>(640, 480, img, img);
+  pislam::bilinear7_8<640>(640, 480, img, out);
+  pislam::bilinear13_16<640>(640, 480, img, out);
   std::vector<uint32_t> p2;
   pislam::fastExtract<640, 16>(640, 480, &out[0], p2);
   uint32_t e = pislam::encodeFast(1, 2, 3);

@@ -1,0 +1,106 @@
+"""Image preparation: gaussian5x5 / bilinear7_8 / bilinear13_16.
+
+CPU part: the oracle's restatement of the reference tests' scalar references against independent
+numpy formulations.  GPU part: the HIP kernels against the oracle over the reference tests' own
+parameter ranges and fixtures (GaussianTest: 16..63 x 16..63 spiral, vstep 640; BilinearTest:
+1..47 x 1..47 spiral + random, vstep 64)."""
+import numpy as np
+import pytest
+
+
+def np_bilinear(a, w, h, N, M, f, skip):
+    out = {}
+    r = lambda v: (v + 128) >> 8
+    smap = [i + sum(i > s for s in skip) for i in range(M)]
+    for by in range(-(-h // N)):
+        for bx in range(-(-w // N)):
+            for y in range(M):
+                for x in range(M):
+                    p = a[by * N + smap[y]:by * N + smap[y] + 2, bx * N + smap[x]:bx * N + smap[x] + 2].astype(int)
+                    h0 = r(p[0, 0] * f[x] + p[0, 1] * f[M - 1 - x])
+                    h1 = r(p[1, 0] * f[x] + p[1, 1] * f[M - 1 - x])
+                    out[(by * M + y, bx * M + x)] = r(h0 * f[y] + h1 * f[M - 1 - y])
+    return out
+
+
+def test_oracle_gaussian_equals_numpy_rhadd_tree(orc):
+    from pislam_amd import synth
+    rng = np.random.default_rng(0)
+    for w, h in [(16, 16), (50, 37), (63, 17), (640, 480), (3, 3), (5, 4)]:
+        a = rng.integers(0, 256, (h + 3, max(w + 5, 8)), dtype=np.uint8)
+        b = a.copy()
+        orc.gaussian5x5(b, w, h)
+        assert (b[:h, :w] == synth.gaussian5x5(a[:h, :w])).all(), (w, h)
+        assert (b[h:] == a[h:]).all() and (b[:, w:] == a[:, w:]).all()
+    # a constant image stays constant, an impulse of 255 spreads to the binomial kernel (rounded)
+    c = np.full((20, 24), 77, np.uint8); orc.gaussian5x5(c, 24, 20); assert (c == 77).all()
+    imp = np.zeros((21, 24), np.uint8); imp[10, 12] = 255; orc.gaussian5x5(imp, 24, 21)
+    assert imp[10, 12] == imp.max() and imp[10, 10] == imp[10, 14] and imp[8, 12] == imp[12, 12] and imp[7, 12] == 0
+
+
+def test_oracle_bilinear_equals_pure_function_of_the_original(orc):
+    """The reference's in-place loops (BilinearTest.cpp:171-233) equal an out-of-place evaluation on
+    the original image; also the 13/16 filter bank keeps the reference's f[10] = 138."""
+    rng = np.random.default_rng(1)
+    f7 = [238, 201, 165, 128, 91, 55, 18]
+    f13 = [226, 167, 108, 49, 246, 187, 128, 69, 10, 207, 138, 89, 30]
+    for w, h in [(40, 33), (8, 8), (47, 1), (1, 47), (23, 31)]:
+        a = rng.integers(0, 256, (64, 64), dtype=np.uint8)
+        b = a.copy(); orc.bilinear7_8(b, w, h)
+        for (oy, ox), v in np_bilinear(a, w, h, 8, 7, f7, []).items():
+            assert b[oy, ox] == v
+        b = a.copy(); orc.bilinear13_16(b, w, h)
+        for (oy, ox), v in np_bilinear(a, w, h, 16, 13, f13, [3, 8]).items():
+            assert b[oy, ox] == v
+    flat = np.full((64, 64), 200, np.uint8); orc.bilinear7_8(flat, 48, 48)
+    assert (flat[:42, :42] == 200).all()
+
+
+@pytest.mark.gpu
+def test_gaussian5x5_reference_test_matrix(gpu_ctx, orc):
+    """GaussianTest.spiral/random over Range(16,64)^2 at vstep 640, in place, plus VGA / 720p."""
+    from pislam_amd import frontend as fe
+    rng = np.random.default_rng(2)
+    sizes = [(w, h) for w in range(16, 64, 5) for h in range(16, 64, 7)] + [(63, 63), (16, 16), (640, 480), (1280, 720), (3, 3), (129, 17)]
+    for w, h in sizes:
+        vstep = 640 if w <= 640 else 1280
+        for kind in ("spiral", "random"):
+            if kind == "spiral":
+                a = orc.fill_spiral(vstep, w, h, vstep // 3, vstep // 3, rows=h + 2)
+            else:
+                a = rng.integers(0, 256, (h + 2, vstep), dtype=np.uint8)
+            exp = a.copy(); orc.gaussian5x5(exp, w, h)
+            g = a.copy(); fe.gaussian5x5(w, h, g, g, ctx=gpu_ctx)              # in place, like the reference test
+            assert (g == exp).all(), (w, h, kind, np.argwhere(g != exp)[:4])
+            out = np.full_like(a, 9); fe.gaussian5x5(w, h, a, out, ctx=gpu_ctx)   # out of place: only w x h written
+            assert (out[:h, :w] == exp[:h, :w]).all() and (out[h:] == 9).all() and (out[:, w:] == 9).all()
+
+
+@pytest.mark.gpu
+def test_bilinear_reference_test_matrix(gpu_ctx, orc):
+    """BilinearTest.{spiral,random}{7_8,13_16} over Range(1,48)^2 at vstep 64, in place."""
+    from pislam_amd import frontend as fe
+    rng = np.random.default_rng(3)
+    for w in list(range(1, 48, 3)) + [47, 16, 32]:
+        for h in list(range(1, 48, 5)) + [47, 16, 32]:
+            sp = orc.fill_spiral(64, w, h, 21, 21, rows=64)
+            rd = rng.integers(0, 256, (64, 64), dtype=np.uint8)
+            for a in (sp, rd):
+                for name, N, M in (("bilinear7_8", 8, 7), ("bilinear13_16", 16, 13)):
+                    exp = a.copy(); getattr(orc, name)(exp, w, h)
+                    g = a.copy(); getattr(fe, name)(w, h, g, g, ctx=gpu_ctx)
+                    assert (g == exp).all(), (name, w, h, np.argwhere(g != exp)[:4])
+                    # the region the reference's tests assert on
+                    oh, ow = h * M // N, w * M // N
+                    out = np.zeros_like(a); getattr(fe, name)(w, h, a, out, ctx=gpu_ctx)
+                    assert (out[:oh, :ow] == exp[:oh, :ow]).all()
+    # VGA and a device-resident call
+    import torch
+    a = rng.integers(0, 256, (480, 640), dtype=np.uint8)
+    for name in ("bilinear7_8", "bilinear13_16"):
+        exp = a.copy(); getattr(orc, name)(exp, 640, 480)
+        d_in = torch.from_numpy(a).cuda(); d_out = torch.zeros_like(d_in)
+        getattr(fe, name)(640, 480, d_in, d_out, ctx=gpu_ctx)
+        torch.cuda.synchronize()
+        M, N = (7, 8) if name == "bilinear7_8" else (13, 16)
+        assert (d_out.cpu().numpy()[:480 * M // N, :640 * M // N] == exp[:480 * M // N, :640 * M // N]).all()
