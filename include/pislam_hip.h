@@ -163,6 +163,19 @@ typedef struct pislam_frontend_params {
   int32_t max_keypoints;    /* capacity per pyramid of keypoints/descriptors   */
 } pislam_frontend_params;
 
+/* On-GPU pyramid build (BASELINE config 5).  The reference ships no pyramid builder (README.md:28-31)
+ * but provides the two reductions to build one from (Bilinear.h:28-30,153): level k+1 =
+ * bilinear7_8 (steps[k] = 1) or bilinear13_16 (steps[k] = 2) of level k, level 0 = gaussian5x5 of the
+ * frame (blur != 0) or the frame itself.  pislam_pyramid_layout computes the level table of a vertically
+ * stacked pyramid (dimensions round down, every level's slot keeps the padding rows its reduction
+ * reads); pislam_pyramid_build_batch fills `batch` pyramids from `batch` device-resident frames.
+ * The result equals running the reference functions level by level on a zero-initialised buffer. */
+int pislam_pyramid_layout(int width, int height, int nlevels, const int32_t *steps, int vstep_min,
+                          pislam_level *levels, int32_t *vstep, int32_t *rows);
+int pislam_pyramid_build_batch(pislam_ctx *ctx, int nlevels, const int32_t *steps, const pislam_level *levels,
+                               const uint8_t *frames, int frame_vstep, size_t frame_stride, int batch,
+                               uint8_t *pyramids, int vstep, int rows, size_t pyramid_stride, int blur);
+
 /* Runs, for every pyramid b in [0,batch) and every level l (in order), the
  * call sequence of reference demo/demo.cpp:77-101 / README.md:67-82:
  *   fastDetect -> fastScoreHarris -> fastExtract (y += row0, x += col0)

@@ -52,6 +52,10 @@ SYMBOLS = {
     "pislam_gaussian5x5": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "pislam_bilinear7_8": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "pislam_bilinear13_16": (_i, [_vp, _i, _i, _i, _vp, _vp]),
+    "pislam_pyramid_layout": (_i, [_i, _i, _i, ctypes.POINTER(ctypes.c_int32), _i, ctypes.POINTER(Level),
+                                   ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32)]),
+    "pislam_pyramid_build_batch": (_i, [_vp, _i, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(Level), _vp, _i, _sz,
+                                        _i, _vp, _i, _i, _sz, _i]),
     "pislam_orb_frontend_batch": (_i, [_vp, ctypes.POINTER(FrontendParams), ctypes.POINTER(Level), _vp,
                                        _sz, _i, _vp, _vp, _vp]),
     "pislam_frontend_reserve": (_i, [_vp, ctypes.POINTER(FrontendParams), ctypes.POINTER(Level), _i]),

@@ -661,6 +661,105 @@ PISLAM_EXPORT int pislam_bilinear13_16(pislam_ctx *c, int vstep, int width, int 
   return prep_common(c, 2, vstep, width, height, img, out);
 }
 
+
+// ---------------------------------------------------------------------------
+// on-GPU pyramid build (BASELINE config 5): frame -> gaussian5x5 -> level 0, then a chain of
+// bilinear7_8 / bilinear13_16 reductions, every level written into a vertically stacked pyramid.
+// ---------------------------------------------------------------------------
+PISLAM_EXPORT int pislam_pyramid_layout(int width, int height, int nlevels, const int32_t *steps, int vstep_min,
+                                        pislam_level *levels, int32_t *vstep, int32_t *rows) {
+  if (width <= 0 || height <= 0 || nlevels < 1 || nlevels > 16 || !levels || (nlevels > 1 && !steps))
+    return PISLAM_ERR_INVALID;
+  int w = width, h = height, row = 0, maxcols = width;
+  for (int l = 0; l < nlevels; l++) {
+    int written = 0;                       // rows the reduction INTO this level writes (whole 7x7 / 13x13 blocks)
+    if (l > 0) {
+      if (steps[l - 1] == 1) {
+        written = (h + 7) / 8 * 7;
+        maxcols = std::max(maxcols, (w + 7) / 8 * 7);
+        w = w * 7 / 8;                     // Bilinear.h:34-35: round down
+        h = h * 7 / 8;
+      } else if (steps[l - 1] == 2) {
+        written = (h + 15) / 16 * 13;
+        maxcols = std::max(maxcols, (w + 15) / 16 * 13);
+        w = w * 13 / 16;                   // Bilinear.h:157-158
+        h = h * 13 / 16;
+      } else {
+        return PISLAM_ERR_INVALID;
+      }
+    }
+    if (w < 3 || h < 3) return PISLAM_ERR_INVALID;
+    levels[l].width = w;
+    levels[l].height = h;
+    levels[l].row0 = row;
+    levels[l].col0 = 0;
+    // the slot holds the padding rows the next reduction reads (Bilinear.h:32,155) and every row the
+    // reduction into this level writes
+    row += std::max((h + 15) / 16 * 16, written);
+  }
+  if (vstep) *vstep = std::max(vstep_min, (maxcols + 15) / 16 * 16);
+  if (rows) *rows = row;
+  return PISLAM_OK;
+}
+
+PISLAM_EXPORT int pislam_pyramid_build_batch(pislam_ctx *c, int nlevels, const int32_t *steps,
+                                             const pislam_level *levels, const uint8_t *frames, int frame_vstep,
+                                             size_t frame_stride, int batch, uint8_t *pyramids, int vstep,
+                                             int rows, size_t pyramid_stride, int blur) {
+  if (!c) return PISLAM_ERR_INVALID;
+  if (!levels || !frames || !pyramids || batch <= 0 || nlevels < 1 || nlevels > 16 || (nlevels > 1 && !steps))
+    return fail(c, PISLAM_ERR_INVALID, "bad argument");
+  if (!is_device_ptr(frames) || !is_device_ptr(pyramids))
+    return fail(c, PISLAM_ERR_INVALID, "the pyramid builder takes device pointers only");
+  for (int l = 0; l < nlevels; l++) {
+    const int pad = l + 1 < nlevels ? (steps[l] == 1 ? 8 : 16) : 1;
+    const int wp = (levels[l].width + pad - 1) / pad * pad, hp = (levels[l].height + pad - 1) / pad * pad;
+    if (levels[l].col0 != 0 || wp > vstep || levels[l].row0 + hp > rows || pyramid_stride < (size_t)rows * vstep)
+      return fail(c, PISLAM_ERR_INVALID, "level (with its bilinear padding) does not fit the pyramid buffer");
+  }
+  for (int l = 0; l + 1 < nlevels; l++) {           // whole output blocks must land inside the next level's slot
+    const int N = steps[l] == 1 ? 8 : 16, M = steps[l] == 1 ? 7 : 13;
+    const int oh = (levels[l].height + N - 1) / N * M, ow = (levels[l].width + N - 1) / N * M;
+    const int slot_end = l + 2 < nlevels ? levels[l + 2].row0 : rows;
+    if (ow > vstep || levels[l + 1].row0 + oh > slot_end)
+      return fail(c, PISLAM_ERR_INVALID, "a reduction's output blocks overrun the next level's slot (use pislam_pyramid_layout)");
+  }
+  if (levels[0].width > frame_vstep || frame_stride < (size_t)levels[0].height * frame_vstep)
+    return fail(c, PISLAM_ERR_INVALID, "frame buffer too small");
+  HIPCHK(c, hipSetDevice(c->device));
+  // padding bytes are read by the bilinear steps and by FAST's right-edge columns: define them as zero
+  HIPCHK(c, hipMemsetAsync(pyramids, 0, pyramid_stride * (size_t)batch, c->stream));
+  const int w0 = levels[0].width, h0 = levels[0].height;
+  if (blur) {
+    hipLaunchKernelGGL(pp::k_gaussian5x5, dim3(cdiv(w0, pp::G_TW), cdiv(h0, pp::G_TH), batch), dim3(256), 0, c->stream,
+                       frames, pyramids + (size_t)levels[0].row0 * vstep, frame_vstep, vstep, frame_stride,
+                       pyramid_stride, w0, h0);
+    PCHK(launch_ok(c, "k_gaussian5x5"));
+  } else {
+    HIPCHK(c, hipMemcpy2DAsync(pyramids + (size_t)levels[0].row0 * vstep, vstep, frames, frame_vstep, w0, h0,
+                               hipMemcpyDeviceToDevice, c->stream));
+    for (int b = 1; b < batch; b++)
+      HIPCHK(c, hipMemcpy2DAsync(pyramids + b * pyramid_stride + (size_t)levels[0].row0 * vstep, vstep,
+                                 frames + b * frame_stride, frame_vstep, w0, h0, hipMemcpyDeviceToDevice, c->stream));
+  }
+  for (int l = 0; l + 1 < nlevels; l++) {
+    const uint8_t *src = pyramids + (size_t)levels[l].row0 * vstep;
+    uint8_t *dst = pyramids + (size_t)levels[l + 1].row0 * vstep;
+    const int w = levels[l].width, h = levels[l].height;
+    if (steps[l] == 1) {
+      const int wp = (w + 7) / 8 * 8, hp = (h + 7) / 8 * 8;
+      hipLaunchKernelGGL((pp::k_bilinear<8, 7>), dim3(cdiv(wp / 8 * 7, 64), cdiv(hp / 8 * 7, 4), batch), dim3(256), 0,
+                         c->stream, src, dst, vstep, vstep, pyramid_stride, pyramid_stride, w, h);
+    } else {
+      const int wp = (w + 15) / 16 * 16, hp = (h + 15) / 16 * 16;
+      hipLaunchKernelGGL((pp::k_bilinear<16, 13>), dim3(cdiv(wp / 16 * 13, 64), cdiv(hp / 16 * 13, 4), batch), dim3(256),
+                         0, c->stream, src, dst, vstep, vstep, pyramid_stride, pyramid_stride, w, h);
+    }
+    PCHK(launch_ok(c, "k_bilinear"));
+  }
+  return PISLAM_OK;
+}
+
 // ===========================================================================
 // batch pipeline (staged: one launch group per level, blockIdx.z = pyramid)
 // ===========================================================================

@@ -182,6 +182,37 @@ def bilinear13_16(width, height, img, out, *, ctx: Context | None = None):
               "pislam_bilinear13_16")
 
 
+# ---- on-GPU pyramid build (BASELINE config 5) ------------------------------------------
+DEFAULT_CHAIN = (2, 1, 2, 2, 1, 2, 2)     # 13/16, 7/8, 13/16, ... : (13/16)^2 * 7/8 = 0.578 ~ 1.2^-3
+
+
+class PyramidBuilder:
+    """frames uint8 [batch][h][w] (device) -> stacked pyramids uint8 [batch][rows][vstep] (device):
+    level 0 = gaussian5x5(frame), level k+1 = bilinear13_16 / bilinear7_8 of level k."""
+
+    def __init__(self, width: int, height: int, steps=DEFAULT_CHAIN, *, blur=True, vstep_min=0,
+                 ctx: Context | None = None):
+        self.ctx = ctx or default_context()
+        self.nlevels = len(steps) + 1
+        self.steps = (ctypes.c_int32 * max(1, len(steps)))(*steps)
+        self.levels_c = (Level * self.nlevels)()
+        vs, rows = ctypes.c_int32(0), ctypes.c_int32(0)
+        rc = self.ctx.lib.pislam_pyramid_layout(width, height, self.nlevels, self.steps, vstep_min, self.levels_c,
+                                                ctypes.byref(vs), ctypes.byref(rows))
+        if rc != 0:
+            raise capi.PislamError(f"pislam_pyramid_layout failed ({rc})")
+        self.vstep, self.rows, self.blur = vs.value, rows.value, bool(blur)
+        self.levels = [(l.width, l.height, l.row0, l.col0) for l in self.levels_c]
+
+    def __call__(self, frames, pyramids):
+        c = self.ctx
+        batch = int(frames.shape[0])
+        c.check(c.lib.pislam_pyramid_build_batch(c.h, self.nlevels, self.steps, self.levels_c, ptr(frames),
+                                                 int(frames.shape[2]), int(frames.shape[1]) * int(frames.shape[2]),
+                                                 batch, ptr(pyramids), self.vstep, self.rows, self.rows * self.vstep,
+                                                 int(self.blur)), "pislam_pyramid_build_batch")
+
+
 # ---- the measured path ---------------------------------------------------------
 class OrbFrontend:
     """Batch of device-resident stacked pyramids -> keypoints + descriptors + counts.

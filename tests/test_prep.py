@@ -104,3 +104,48 @@ def test_bilinear_reference_test_matrix(gpu_ctx, orc):
         torch.cuda.synchronize()
         M, N = (7, 8) if name == "bilinear7_8" else (13, 16)
         assert (d_out.cpu().numpy()[:480 * M // N, :640 * M // N] == exp[:480 * M // N, :640 * M // N]).all()
+
+
+@pytest.mark.gpu
+def test_pyramid_build_equals_reference_functions_in_sequence(gpu_ctx, orc):
+    """config 5 builder: gaussian5x5 then the 13/16, 7/8 chain on a zeroed stacked buffer == the oracle
+    running the reference tests' scalar references in the same order; then ORB on the built pyramid."""
+    import torch
+    from pislam_amd.frontend import OrbFrontend, PyramidBuilder
+    from pislam_amd import synth
+    rng = np.random.default_rng(9)
+    for (w0, h0, steps) in [(1280, 720, (2, 1, 2, 2, 1, 2, 2)), (333, 251, (1, 2, 1)), (640, 480, (2, 2))]:
+        pb = PyramidBuilder(w0, h0, steps, ctx=gpu_ctx)
+        B = 3
+        frames = np.stack([synth.make_level0(50 + i, w0, h0) if i else rng.integers(0, 256, (h0, w0), dtype=np.uint8)
+                           for i in range(B)])
+        d_fr = torch.from_numpy(frames).cuda()
+        d_pyr = torch.empty((B, pb.rows, pb.vstep), dtype=torch.uint8, device="cuda")
+        pb(d_fr, d_pyr)
+        torch.cuda.synchronize()
+        got = d_pyr.cpu().numpy()
+        for b in range(B):
+            exp = np.zeros((pb.rows, pb.vstep), np.uint8)
+            w, h, r0, _ = pb.levels[0]
+            exp[r0:r0 + h, :w] = frames[b]
+            lvl = exp[r0:]
+            orc.gaussian5x5(lvl, w, h)
+            for k, st in enumerate(steps):
+                w, h, r0, _ = pb.levels[k]
+                tmp = exp[r0:].copy()                       # out-of-place: level k -> level k+1 slot
+                (orc.bilinear7_8 if st == 1 else orc.bilinear13_16)(tmp, w, h)
+                w1, h1, r1, _ = pb.levels[k + 1]
+                N, M = (8, 7) if st == 1 else (16, 13)
+                oh, ow = -(-h // N) * M, -(-w // N) * M      # whole blocks, like the reference loops
+                exp[r1:r1 + oh, :ow] = tmp[:oh, :ow]
+                assert (w1, h1) == (w * M // N, h * M // N)
+            assert (got[b] == exp).all(), (w0, h0, b, np.argwhere(got[b] != exp)[:4])
+        # ORB front-end on the built pyramids == oracle on the same buffers
+        fe = OrbFrontend(pb.levels, vstep=pb.vstep, rows=pb.rows, max_keypoints=8192, ctx=gpu_ctx)
+        kp, desc, counts = fe.alloc_outputs(B, d_pyr.device)
+        fe(d_pyr, kp, desc, counts)
+        torch.cuda.synchronize()
+        c = counts.cpu().numpy().view(np.uint32); k = kp.cpu().numpy().view(np.uint32); d = desc.cpu().numpy().view(np.uint32)
+        for b in (1, 2):
+            okp, odesc, _ = orc.pyramid(got[b], [l[:3] for l in pb.levels])
+            assert c[b] == len(okp) and (k[b, :len(okp)] == okp).all() and (d[b, :len(okp)] == odesc).all()
