@@ -56,6 +56,10 @@ def main():
                     help="distinct synthetic pyramids generated per GPU (0 = all of the batch)")
     ap.add_argument("--max-keypoints", type=int, default=4096)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", default="vga", choices=["vga", "1280x960", "720p-build"],
+                    help="vga = BASELINE configs[1] (default, the headline); 1280x960 = configs[3] (packed layout, "
+                         "vstep 1280); 720p-build = configs[4] (gaussian5x5 + bilinear pyramid build on the GPU inside "
+                         "the timed step)")
     ap.add_argument("--pipeline", type=int, default=0, help="0 auto (fused), 1 staged, 2 fused")
     ap.add_argument("--strip-rows", type=int, default=0)
     ap.add_argument("--orb-chunks", type=int, default=0)
@@ -75,28 +79,53 @@ def main():
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 
-    levels = synth.level_table()                           # demo.cpp:38-47 table, 2210 stacked rows
-    rows = synth.pyramid_rows(levels)
+    builder = None
+    d_frames = None
+    if args.workload == "vga":
+        levels = synth.level_table()                       # demo.cpp:38-47 table, 2210 stacked rows
+        vstep, w0, h0 = 640, 640, 480
+    elif args.workload == "1280x960":
+        levels = synth.packed_level_table(1280, 960)       # 3768 rows: levels 4|5 and 6|7 side by side
+        vstep, w0, h0 = 1280, 1280, 960
+    else:
+        from pislam_amd.frontend import PyramidBuilder
+        w0, h0 = 1280, 720
     B = args.batch
-    distinct = args.distinct or B
+    distinct = args.distinct or (B if args.workload == "vga" else min(B, 16))
     first = rank * B
-    host = synth.make_batch(first, min(distinct, B))
-    d_pyr = torch.from_numpy(host).to(dev)
-    if distinct < B:
-        d_pyr = d_pyr[torch.arange(B, device=dev) % distinct].contiguous()
-
     stream = torch.cuda.current_stream(dev)
     ctx = Context(device=local_rank, stream=stream.cuda_stream)
     ctx.set_option("pipeline", args.pipeline)
     ctx.set_option("strip_rows", args.strip_rows)
     ctx.set_option("orb_chunks", args.orb_chunks)
     ctx.set_option("ablate", args.ablate)
-    fe = OrbFrontend(levels, vstep=640, rows=rows, max_keypoints=args.max_keypoints, ctx=ctx,
+    if args.workload == "720p-build":
+        builder = PyramidBuilder(w0, h0, ctx=ctx)
+        levels, vstep = builder.levels, builder.vstep
+        rows = builder.rows
+        fr = np.stack([synth.make_level0(first + i, w0, h0) for i in range(min(distinct, B))])
+        d_frames = torch.from_numpy(fr).to(dev)
+        if distinct < B:
+            d_frames = d_frames[torch.arange(B, device=dev) % distinct].contiguous()
+        d_pyr = torch.empty((B, rows, vstep), dtype=torch.uint8, device=dev)
+        builder(d_frames, d_pyr)
+        torch.cuda.synchronize()
+        host = d_pyr[:min(distinct, B)].cpu().numpy()
+    else:
+        rows = synth.pyramid_rows(levels)
+        host = synth.make_batch(first, min(distinct, B), w0=w0, h0=h0, vstep=vstep, levels=levels)
+        d_pyr = torch.from_numpy(host).to(dev)
+        if distinct < B:
+            d_pyr = d_pyr[torch.arange(B, device=dev) % distinct].contiguous()
+
+    fe = OrbFrontend(levels, vstep=vstep, rows=rows, max_keypoints=args.max_keypoints, ctx=ctx,
                      log_bucket_size=args.log_bucket_size, bucket_limit=args.bucket_limit)
     fe.reserve(B)
     kp, desc, counts = fe.alloc_outputs(B, dev)
 
     def step():
+        if builder is not None:
+            builder(d_frames, d_pyr)
         fe(d_pyr, kp, desc, counts)
         return pdist.gather_counts(counts, world)
 
@@ -136,7 +165,9 @@ def main():
     value = total_kp_step * args.steps / dt
 
     if rank == 0:
-        valid_px = sum(w * h for w, h, _ in levels)
+        valid_px = sum(t[0] * t[1] for t in levels)
+        if builder is not None:            # config 5: + source frame read + pyramid write
+            valid_px += w0 * h0 + sum(t[0] * t[1] for t in levels)
         # algorithmic bytes: every valid pixel once + 36 B per keypoint + 4 B count
         b_alg_launch = B * (valid_px + 4) + 36 * local_kp
         fused = args.pipeline != 1
@@ -146,7 +177,7 @@ def main():
         achieved = b_alg_launch / (launch_ms * 1e-3) / 1e9
         traffic = None                                  # HBM bytes per launch from the committed PMC passes
         tpath = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
-        if fused and B == 256 and os.path.exists(tpath):
+        if fused and B == 256 and args.workload == "vga" and not args.log_bucket_size and os.path.exists(tpath):
             try:
                 traffic = json.load(open(tpath))["kernels"]["k_fused_strips"]["hbm_bytes_per_launch"]
             except Exception:
@@ -157,8 +188,14 @@ def main():
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {
-                "workload": "batch=256 synthetic 640x480 pyramids per GPU, 8 levels x1.2 stacked (vstep=640, "
-                            "2210 rows), border=16, FAST threshold=20, Harris threshold=1<<15, " + ("no buckets" if not args.log_bucket_size else f"buckets <{args.log_bucket_size},{args.bucket_limit}>") + ", "
+                "workload": {"vga": f"batch={B} synthetic 640x480 pyramids per GPU, 8 levels x1.2 stacked (vstep=640, "
+                                    "2210 rows)",
+                             "1280x960": f"batch={B} synthetic 1280x960 pyramids per GPU, 8 levels x1.2, packed layout "
+                                         "(vstep=1280, 3768 rows, levels 4|5 and 6|7 side by side)",
+                             "720p-build": f"batch={B} synthetic 1280x720 frames per GPU; gaussian5x5 + "
+                                           "13/16,7/8,13/16,13/16,7/8,13/16,13/16 bilinear pyramid built on the GPU inside "
+                                           f"the step (vstep={vstep}, {rows} rows)"}[args.workload] +
+                            ", border=16, FAST threshold=20, Harris threshold=1<<15, " + ("no buckets" if not args.log_bucket_size else f"buckets <{args.log_bucket_size},{args.bucket_limit}>") + ", "
                             "256-bit descriptors (BASELINE.json configs[1])",
                 "batch_per_gpu": B, "global_batch": B * world, "distinct_pyramids_per_gpu": min(distinct, B),
                 "keypoints_per_pyramid": total_kp_step / (B * world),
@@ -176,8 +213,10 @@ def main():
                 "stage_ms": {"detect+score+nms": ev_stage_ms[0], "gather": ev_stage_ms[1], "orb": ev_stage_ms[2]},
             },
         }
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(host, levels)
+        if world == 1 and not args.no_cpu_baseline and all(len(t) < 4 or t[3] == 0 for t in levels):
+            # (the oracle's whole-pyramid driver takes vertically stacked levels; the packed 1280x960
+            #  layout is covered by the parity tests, not by the timed CPU leg)
+            out["cpu_baseline"] = cpu_baseline(host, [tuple(t[:3]) for t in levels])
         print(json.dumps(out))
     if world > 1:
         torch.distributed.barrier()

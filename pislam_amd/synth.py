@@ -35,7 +35,28 @@ def level_table(w0: int = 640, h0: int = 480, nlevels: int = 8, scale: float = 1
 
 
 def pyramid_rows(levels) -> int:
-    return int(sum(h for _, h, _ in levels))
+    return int(max(t[2] + t[1] for t in levels))
+
+
+def packed_level_table(w0: int = 1280, h0: int = 960, nlevels: int = 8, scale: float = 1.2, vstep: int | None = None):
+    """[(width, height, row0, col0)]: like level_table but small levels share rows side by side so that
+    a 1280x960 pyramid stays below the 12-bit y limit of encodeFast (Util.h:27-29).
+    A level is placed right of the previous one when both fit in `vstep` with a >= 2 px zero gap
+    (rounded up to a 16-byte aligned column); otherwise it starts a new row band."""
+    vstep = vstep or w0
+    sizes = [(int(np.floor(w0 / scale ** k + 0.5)), int(np.floor(h0 / scale ** k + 0.5))) for k in range(nlevels)]
+    out, row, band_h, col = [], 0, 0, 0
+    for k, (w, h) in enumerate(sizes):
+        c0 = (col + 2 + 15) // 16 * 16 if col else 0
+        if col and c0 + w <= vstep and k >= nlevels // 2:
+            out.append((w, h, row, c0))
+            band_h = max(band_h, h)
+            col = c0 + w
+        else:
+            row += band_h
+            out.append((w, h, row, 0))
+            band_h, col = h, w
+    return out
 
 
 def _rhadd(a, b):
@@ -132,10 +153,12 @@ def make_pyramid(index: int, w0: int = 640, h0: int = 480, nlevels: int = 8,
     if vstep is None:
         vstep = w0
     l0 = make_level0(index, w0, h0, nshapes)
-    rows = max(r0 + h for _, h, r0 in levels)
+    rows = max(t[2] + t[1] for t in levels)
     out = np.zeros((rows, vstep), np.uint8)
-    for k, (w, h, r0) in enumerate(levels):
-        out[r0:r0 + h, :w] = l0 if (w, h) == (w0, h0) else _resize_bilinear(l0, w, h)
+    for t in levels:
+        w, h, r0 = t[0], t[1], t[2]
+        c0 = t[3] if len(t) > 3 else 0
+        out[r0:r0 + h, c0:c0 + w] = l0 if (w, h) == (w0, h0) else _resize_bilinear(l0, w, h)
     return out
 
 

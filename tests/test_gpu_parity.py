@@ -362,3 +362,42 @@ def test_full_batch_properties(gpu_ctx, orc, pipeline):
         assert (np.diff(lvl) >= 0).all()
         key = lvl * (1 << 24) + ((y - np.array([levels[l][2] for l in lvl])) // 2) * 4096 + x // 2
         assert (np.diff(key) > 0).all()
+
+
+def test_packed_1280x960_layout(gpu_ctx, orc):
+    """BASELINE configs[3]: 1280x960, vstep 1280, levels 4|5 and 6|7 side by side (12-bit y limit of
+    encodeFast, Util.h:27-29): both pipelines equal the oracle run level by level."""
+    import torch
+    from pislam_amd import synth
+    from pislam_amd.frontend import OrbFrontend
+    levels = synth.packed_level_table(1280, 960)
+    rows = synth.pyramid_rows(levels)
+    assert rows == 3768 and max(t[3] + t[0] for t in levels) <= 1280
+    pyr = synth.make_batch(900, 2, w0=1280, h0=960, vstep=1280, levels=levels)
+    dev = torch.device("cuda:0")
+    d_pyr = torch.from_numpy(pyr).to(dev)
+    res = {}
+    for pl in (1, 2):
+        gpu_ctx.set_option("pipeline", pl)
+        try:
+            fe = OrbFrontend(levels, vstep=1280, rows=rows, max_keypoints=16384, ctx=gpu_ctx)
+            kp, desc, counts = fe.alloc_outputs(2, dev)
+            fe(d_pyr, kp, desc, counts)
+            torch.cuda.synchronize()
+            res[pl] = tuple(t.cpu().numpy().view(np.uint32) for t in (counts, kp, desc))
+        finally:
+            gpu_ctx.set_option("pipeline", 0)
+    for a, b in zip(res[1], res[2]):
+        assert (a == b).all()
+    c, k, d = res[2]
+    for b in range(2):
+        exp = []
+        for (w, h, r0, c0) in levels:
+            view = np.ascontiguousarray(pyr[b, r0:r0 + h].reshape(-1)[c0:])
+            view = np.concatenate([view, np.zeros((-len(view)) % 1280, np.uint8)]).reshape(-1, 1280)
+            lkp, _, _ = orc.pyramid(view, [(w, h, 0)])
+            exp.append(lkp + np.uint32((c0 << 12) | r0))
+        exp = np.concatenate(exp)
+        assert c[b] == len(exp) and (k[b, :len(exp)] == exp).all()
+        assert (d[b, :len(exp)] == orc.orb_compute(pyr[b], exp)).all()
+        assert ((k[b, :len(exp)] & 0xFFF) < 4096).all()
