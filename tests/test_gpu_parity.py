@@ -401,3 +401,34 @@ def test_packed_1280x960_layout(gpu_ctx, orc):
         assert c[b] == len(exp) and (k[b, :len(exp)] == exp).all()
         assert (d[b, :len(exp)] == orc.orb_compute(pyr[b], exp)).all()
         assert ((k[b, :len(exp)] & 0xFFF) < 4096).all()
+
+
+def test_fused_unaligned_vstep(gpu_ctx, orc):
+    """vstep % 16 != 0: scalar LDS staging + generic gather / per-keypoint ORB kernels on the fused path."""
+    import torch
+    from pislam_amd.frontend import OrbFrontend
+    rng = np.random.default_rng(5)
+    vstep, rows = 203, 150
+    levels = [(150, 90, 0, 0), (101, 60, 90, 3)]
+    pyr = rng.integers(0, 256, (5, rows, vstep), dtype=np.uint8)
+    pyr[:, :, ::2] = (pyr[:, :, ::2] // 128) * 128
+    dev = torch.device("cuda:0")
+    gpu_ctx.set_option("pipeline", 2)
+    try:
+        fe = OrbFrontend(levels, vstep=vstep, rows=rows, max_keypoints=4096, ctx=gpu_ctx)
+        kp, desc, counts = fe.alloc_outputs(5, dev)
+        fe(torch.from_numpy(pyr).to(dev), kp, desc, counts)
+        torch.cuda.synchronize()
+    finally:
+        gpu_ctx.set_option("pipeline", 0)
+    c, k, d = (t.cpu().numpy().view(np.uint32) for t in (counts, kp, desc))
+    for b in range(5):
+        exp = []
+        for (w, h, r0, c0) in levels:
+            view = np.ascontiguousarray(pyr[b, r0:r0 + h].reshape(-1)[c0:])
+            view = np.concatenate([view, np.zeros((-len(view)) % vstep, np.uint8)]).reshape(-1, vstep)
+            lkp, _, _ = orc.pyramid(view, [(w, h, 0)])
+            exp.append(lkp + np.uint32((c0 << 12) | r0))
+        exp = np.concatenate(exp)
+        assert c[b] == len(exp) and (k[b, :len(exp)] == exp).all()
+        assert (d[b, :len(exp)] == orc.orb_compute(pyr[b], exp)).all()
