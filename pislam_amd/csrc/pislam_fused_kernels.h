@@ -153,7 +153,7 @@ __global__ __launch_bounds__(NT) void k_fused_strips(
       // bytes of this pyramid's buffer that may be read (the tile can overhang the last image row
       // when col0 + pitch > vstep: flat addressing like the reference, but never past the buffer)
       const ptrdiff_t lim = (ptrdiff_t)P.rows * P.vstep - ((ptrdiff_t)L.row0 * P.vstep + L.col0);
-      for (int i = tid; i < nrows * vpr; i += NT) {
+      for (int i = tid; i < ((P.ablate & 256) ? 0 : nrows * vpr); i += NT) {   // ablate 256: profiling without the HBM read
         const int r = (int)__umulhi((uint32_t)i, L.vpr_recip), v = i - r * vpr;
         const ptrdiff_t off = (ptrdiff_t)(y_lo + r) * P.vstep + 16 * v;
         u32x4 d;
@@ -684,7 +684,8 @@ __global__ __launch_bounds__(256) void k_gather_orb(
   // LDS carve: patches (4 waves x 2 x 1 KiB) | strip offsets (S+1) | this chunk's keypoints
   uint8_t *patches = osm;
   uint32_t *soff = (uint32_t *)(osm + OWAVES * 2 * ORB_PATCH_BYTES);
-  uint32_t *kpl = soff + ((S + 1 + 3) & ~3);
+  uint32_t *sslot = soff + ((S + 1 + 3) & ~3);       // staging slot base of every strip
+  uint32_t *kpl = sslot + ((S + 3) & ~3);
 
   // ---- exclusive scan of the strip counts (strip order = reference push_back order) ----
   const uint32_t *cnt = strip_count + (size_t)pyr * S;
@@ -703,7 +704,12 @@ __global__ __launch_bounds__(256) void k_gather_orb(
     __syncthreads();
     uint32_t pre = carry;
     for (int w = 0; w < wv; w++) pre += wsum[w];
-    if (i < S) soff[i] = pre + incl - v;
+    if (i < S) {
+      soff[i] = pre + incl - v;
+      int li = 0;
+      while (li + 1 < P.nlevels && i >= P.lv[li + 1].strip0) li++;
+      sslot[i] = (uint32_t)(P.lv[li].slot0 + (i - P.lv[li].strip0) * (P.lv[li].R >> 1) * P.lv[li].nbx);
+    }
     __syncthreads();
     if (tid == 255) carry = pre + incl;
     __syncthreads();
@@ -719,22 +725,17 @@ __global__ __launch_bounds__(256) void k_gather_orb(
   const uint32_t lo = min((uint32_t)ch * per, nkp), hi = min(lo + per, nkp);
   if (lo >= hi) return;
 
-  // ---- pull this chunk's keypoints out of the staging buffer ----
-  for (int st = wv; st < S; st += OWAVES) {
-    const uint32_t s0 = soff[st], s1 = soff[st + 1];
-    if (s1 <= lo || s0 >= hi || s1 == s0) continue;
-    int li = 0;
-    while (li + 1 < P.nlevels && st >= P.lv[li + 1].strip0) li++;
-    const FusedLevel &L = P.lv[li];
-    const size_t slot = (size_t)pyr * P.slots_per_pyr + L.slot0 + (size_t)(st - L.strip0) * (L.R >> 1) * L.nbx;
-    for (uint32_t k = lane; k < s1 - s0; k += 64) {
-      const uint32_t pos = s0 + k;
-      if (pos >= lo && pos < hi) {
-        const uint32_t v = stage_kp[slot + k];
-        kpl[pos - lo] = v;
-        kp[(size_t)pyr * kp_stride + pos] = v;
-      }
+  // ---- pull this chunk's keypoints out of the staging buffer: one thread per keypoint, its strip
+  // found by binary search in the strip offsets ----
+  for (uint32_t pos = lo + tid; pos < hi; pos += 256) {
+    int a = 0, b = S;                                  // largest st with soff[st] <= pos
+    while (b - a > 1) {
+      const int m = (a + b) >> 1;
+      if (soff[m] <= pos) a = m; else b = m;
     }
+    const uint32_t v = stage_kp[(size_t)pyr * P.slots_per_pyr + sslot[a] + (pos - soff[a])];
+    kpl[pos - lo] = v;
+    kp[(size_t)pyr * kp_stride + pos] = v;
   }
   __syncthreads();
 
@@ -772,55 +773,70 @@ __global__ __launch_bounds__(256) void k_gather_orb(
   struct Win {
     uint4 w[3];
   };
-  auto kp_of = [&](uint32_t it, int h, int &x, int &y) {
-    const uint32_t idx = lo + 2 * it + h;
-    const bool v = it < npairs && idx < hi;
-    const uint32_t p = kpl[v ? idx - lo : 0];
-    x = decode_x(p);
-    y = decode_y(p);
-    return v;
+  // loop-invariant slot geometry of this lane: slot j -> keypoint half, byte offset of its 16-byte
+  // chunk relative to the patch origin (y-15, x-15), and where it is parked in the LDS patch
+  int sl_h[3], sl_park[3];
+  ptrdiff_t sl_rel[3];
+  bool sl_on[3];
+#pragma unroll
+  for (int j = 0; j < 3; j++) {
+    const int slot = lane + 64 * j;                   // 0..191, 186 used
+    const int h = slot >= 93 ? 1 : 0, within = slot - 93 * h;
+    const int row = within / 3, chunk = within - 3 * row;
+    sl_h[j] = h;
+    sl_on[j] = slot < 186;
+    sl_rel[j] = (ptrdiff_t)row * vstep + 16 * chunk;
+    sl_park[j] = h * ORB_PATCH_BYTES + row * ORB_PITCH + 16 * chunk;
+  }
+  lds_u8 *wave_patches = (lds_u8 *)(patches + (wv * 2) * ORB_PATCH_BYTES);
+  const lds_u32 *kpl_l = (const lds_u32 *)kpl;
+  // the two keypoints of pair `it`: packed words (0 when absent)
+  auto pair_of = [&](uint32_t it, uint32_t &p0, uint32_t &p1) {
+    const uint32_t i0 = lo + 2 * it;
+    p0 = (it < npairs) ? kpl_l[i0 - lo] : 0u;
+    p1 = (it < npairs && i0 + 1 < hi) ? kpl_l[i0 + 1 - lo] : 0u;
   };
-  auto fetch = [&](uint32_t it) {
+  auto fetch = [&](uint32_t p0, uint32_t p1) {
     Win f;
+    // byte offset of the patch origin (row y-15, column x-15) of either keypoint
+    const ptrdiff_t org0 = (ptrdiff_t)(decode_y(p0) - 15) * vstep + (decode_x(p0) - 15);
+    const ptrdiff_t org1 = (ptrdiff_t)(decode_y(p1) - 15) * vstep + (decode_x(p1) - 15);
 #pragma unroll
     for (int j = 0; j < 3; j++) {
-      const int slot = lane + 64 * j;                 // 0..191, 186 used
-      const int h = slot >= 93 ? 1 : 0, within = slot - 93 * h;
-      const int row = within / 3, chunk = within - 3 * row;
-      int x, y;
-      const bool v = kp_of(it, h, x, y) && slot < 186;
-      const ptrdiff_t start = (ptrdiff_t)(y + row - 15) * vstep + (x - 15);
-      const ptrdiff_t a = (start & ~(ptrdiff_t)15) + 16 * chunk;
+      const ptrdiff_t org = sl_h[j] ? org1 : org0;
+      const bool v = sl_on[j] && (sl_h[j] ? p1 : p0) != 0;
+      const ptrdiff_t a = ((org + sl_rel[j]) & ~(ptrdiff_t)15) + 0;   // vstep % 16 == 0: row offsets keep the alignment
       f.w[j] = (v && a >= 0 && a + 16 <= img_bytes) ? *(const uint4 *)(im + a) : make_uint4(0, 0, 0, 0);
     }
     return f;
   };
   if (P.ablate & 64) return;                        // profiling only: prologue cost
-  uint8_t *wave_patches = patches + (wv * 2) * ORB_PATCH_BYTES;
-  Win nxt = fetch(wv);
+  uint32_t np0, np1;
+  pair_of(wv, np0, np1);
+  Win nxt = fetch(np0, np1);
+  lds_u8 *patch_l = wave_patches + half * ORB_PATCH_BYTES;
   for (uint32_t it = wv; it < npairs; it += OWAVES) {
     const Win cur = nxt;
-    nxt = fetch(it + OWAVES);
+    const uint32_t p0 = np0, p1 = np1;
+    pair_of(it + OWAVES, np0, np1);
+    nxt = fetch(np0, np1);
     const uint32_t idx = lo + 2 * it + half;
-    int x, y;
-    const bool valid = kp_of(it, half, x, y);
-    const uint32_t sh = (uint32_t)(((ptrdiff_t)(y + dy) * vstep + (x - 15)) & 15);
+    const uint32_t pme = half ? p1 : p0;
+    const bool valid = pme != 0;
+    const int x = decode_x(pme), y = decode_y(pme);
+    const uint32_t sh = (uint32_t)(((ptrdiff_t)(y - 15) * vstep + (x - 15)) & 15);   // same for every row
 #pragma unroll
-    for (int j = 0; j < 3; j++) {
-      const int slot = lane + 64 * j;
-      const int h = slot >= 93 ? 1 : 0, within = slot - 93 * h;
-      const int row = within / 3, chunk = within - 3 * row;
-      if (slot < 186) *(uint4 *)(wave_patches + h * ORB_PATCH_BYTES + row * ORB_PITCH + 16 * chunk) = cur.w[j];
-    }
-    uint8_t *prow = patch + r * ORB_PITCH;
+    for (int j = 0; j < 3; j++)
+      if (sl_on[j]) *(lds_u4 *)(wave_patches + sl_park[j]) = (u32x4){cur.w[j].x, cur.w[j].y, cur.w[j].z, cur.w[j].w};
+    const lds_u8 *prow = patch_l + r * ORB_PITCH;
     // read the row back aligned to the PATCH: 9 aligned dwords + v_alignbyte (byte-unaligned
     // ds_read_b32 works on gfx950 but costs ~47 stall cycles each — SQ_LDS_UNALIGNED_STALL)
     uint32_t row[8];
     {
-      const uint8_t *pa = prow + (sh & ~3u);
+      const lds_u8 *pa = prow + (sh & ~3u);
       uint32_t in[9];
 #pragma unroll
-      for (int k = 0; k < 9; k++) in[k] = *(const uint32_t *)(pa + 4 * k);
+      for (int k = 0; k < 9; k++) in[k] = *(const lds_u32 *)(pa + 4 * k);
 #pragma unroll
       for (int k = 0; k < 8; k++) row[k] = __builtin_amdgcn_alignbyte(in[k + 1], in[k], sh & 3u);
     }
@@ -845,7 +861,7 @@ __global__ __launch_bounds__(256) void k_gather_orb(
     // BRIEF: pair k = 32*round + r of this half's keypoint -> bit r of word `round`
     const uint32_t *tab = ::g_brief_ofs.v + rot * 256 + r;   // defined by the including TU
     // the patch's byte (dy,dx) sits at (dy+15)*48 + sh + dx+15; sh is the same for every row
-    const uint32_t sh0 = (uint32_t)(((ptrdiff_t)y * vstep + (x - 15)) & 15);
+    const lds_u8 *bp = patch_l + sh;
     uint32_t myword = 0;
     uint32_t ent[8];
 #pragma unroll
@@ -853,7 +869,7 @@ __global__ __launch_bounds__(256) void k_gather_orb(
 #pragma unroll
     for (int round = 0; round < 8; round++) {
       const uint32_t e = ent[round];
-      const uint32_t a = patch[(e & 0xffffu) + sh0], b = patch[(e >> 16) + sh0];
+      const uint32_t a = bp[e & 0xffffu], b = bp[e >> 16];
       const uint64_t m = __ballot(a < b);                           // Brief.h:52
       const uint32_t w = half ? (uint32_t)(m >> 32) : (uint32_t)m;
       if (r == round) myword = w;                                   // rounds >= words are never stored

@@ -889,6 +889,7 @@ int run_fused(pislam_ctx *c, const pislam_frontend_params *p, const pf::FusedPar
   int nch = c->opt_orb_chunks > 0 ? c->opt_orb_chunks : std::min(64, std::max(16, 4096 / batch));
   const size_t per_max = ((size_t)p->max_keypoints + nch - 1) / nch;
   size_t olds = (size_t)pf::OWAVES * 2 * pf::ORB_PATCH_BYTES + sizeof(uint32_t) * (((size_t)F.strips_per_pyr + 1 + 3) & ~(size_t)3) +
+                sizeof(uint32_t) * (((size_t)F.strips_per_pyr + 3) & ~(size_t)3) +
                 sizeof(uint32_t) * per_max;
   if (olds > 150 * 1024) return fail(c, PISLAM_ERR_INVALID, "max_keypoints too large for the fused ORB kernel");
   if (olds > 64 * 1024)
