@@ -112,76 +112,25 @@ __device__ __attribute__((noinline)) void harris_overflow(lds_u8 *tile, lds_u8 *
   }
 }
 
-template <bool VEC16>
-__global__ __launch_bounds__(NT) void k_fused_strips(
-    const FusedParams P, const uint8_t *__restrict__ pyramids, size_t pyr_stride,
-    uint32_t *__restrict__ stage_kp, uint32_t *__restrict__ strip_count,
-    uint8_t *__restrict__ score_dump, size_t score_stride) {
-  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-  // XCD-aware mapping: workgroup b runs on XCD b%8; keep all strips of one pyramid on one XCD so
-  // the halo rows shared by neighbouring strips are served by that XCD's L2.
-  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-  const int pyr = (slot / P.strips_per_pyr) * 8 + xcd;
-  if (pyr >= P.batch) return;
-  int s = slot % P.strips_per_pyr;
-  int li = 0;
-  while (li + 1 < P.nlevels && s >= P.lv[li + 1].strip0) li++;
-  const FusedLevel L = P.lv[li];
-  s -= L.strip0;
-  const int B = P.border;
-  const int ys = B + s * L.R;                       // first block-row y of the strip
-  const int ye = min(ys + L.R, L.h - B);            // one past the last row owned
+// Scalar copies of the kernel arguments the strip body needs (the by-value FusedParams must not be
+// captured by reference anywhere: hipcc then spills the whole 800-byte struct to scratch).
+struct StripArgs {
+  int border, thr, ablate, dump_score, lbs, limit, vstep, slots_per_pyr, strips_per_pyr;
+  int32_t hthr;
+};
+
+// Everything after the image tile is staged and the score tile zeroed: phases A0 .. D of one strip.
+// `sh_ctr` (8 dwords of LDS, [1] = QH_SHARED, others 0) must be initialised and a barrier passed.
+// Shared by the one-strip-per-workgroup kernel and the persistent kernel.
+__device__ __forceinline__ void strip_body(const StripArgs A, const FusedLevel L, const int pyr, const int s,
+                                           const int ys, const int ye, lds_u8 *tile, lds_u8 *sc, lds_u32 *queues,
+                                           uint32_t *sh_ctr, uint32_t *__restrict__ stage_kp,
+                                           uint32_t *__restrict__ strip_count, uint8_t *__restrict__ score_dump,
+                                           size_t score_stride) {
+  const int B = A.border;
   const int pitch = L.pitch;
-  const int trows = L.R + 10;                       // image tile rows  [ys-4, ys+R+6)
-  lds_u8 *tile = (lds_u8 *)smem;
-  lds_u8 *sc = tile + trows * pitch;                // score tile rows  [ys-1, ys+R+2)
-  lds_u32 *queues = (lds_u32 *)(sc + (L.R + 3) * pitch);
-
-  const uint8_t *im = pyramids + (size_t)pyr * pyr_stride + (size_t)L.row0 * P.vstep + L.col0;
   const int tid = threadIdx.x;
-  // [0] corners queued, [1] first overflowed corner slot, [2] non-zero scores queued,
-  // [3] set when a queue overflowed -> NMS falls back to scanning the score tile, [4] survivors
-  __shared__ uint32_t sh_ctr[8];
-  if (tid < 8) sh_ctr[tid] = tid == 1 ? QH_SHARED : 0;
-
-  // ---- stage the image rows [ys-4, min(ye+6, h)) and clear the score tile ---------------
-  {
-    const int y_lo = ys - 4;
-    const int nrows = min(ye + 6, L.h) - y_lo;
-    if (VEC16) {
-      const int vpr = pitch >> 4;                   // 16-byte vectors per row
-      // bytes of this pyramid's buffer that may be read (the tile can overhang the last image row
-      // when col0 + pitch > vstep: flat addressing like the reference, but never past the buffer)
-      const ptrdiff_t lim = (ptrdiff_t)P.rows * P.vstep - ((ptrdiff_t)L.row0 * P.vstep + L.col0);
-      for (int i = tid; i < ((P.ablate & 256) ? 0 : nrows * vpr); i += NT) {   // ablate 256: profiling without the HBM read
-        const int r = (int)__umulhi((uint32_t)i, L.vpr_recip), v = i - r * vpr;
-        const ptrdiff_t off = (ptrdiff_t)(y_lo + r) * P.vstep + 16 * v;
-        u32x4 d;
-        if (off + 16 <= lim) {
-          d = *(const u32x4 *)(im + off);
-        } else {
-          uint32_t w4[4] = {0, 0, 0, 0};          // tail of the buffer: byte-wise, zero beyond the end
-#pragma unroll
-          for (int k = 0; k < 16; k++)
-            if (off + k < lim) w4[k >> 2] |= (uint32_t)im[off + k] << (8 * (k & 3));
-          d = (u32x4){w4[0], w4[1], w4[2], w4[3]};
-        }
-        *(lds_u4 *)(tile + r * pitch + 16 * v) = d;
-      }
-    } else {
-      const ptrdiff_t lim = (ptrdiff_t)P.rows * P.vstep - ((ptrdiff_t)L.row0 * P.vstep + L.col0);
-      for (int i = tid; i < nrows * pitch; i += NT) {
-        const int r = i / pitch, cx = i - r * pitch;
-        const ptrdiff_t off = (ptrdiff_t)(y_lo + r) * P.vstep + cx;
-        tile[r * pitch + cx] = off < lim ? im[off] : (uint8_t)0;
-      }
-    }
-    const int nz = ((L.R + 3) * pitch) >> 4;
-    for (int i = tid; i < nz; i += NT) ((lds_u4 *)sc)[i] = (u32x4)(0u);
-  }
-  __syncthreads();
-
-  if (P.ablate & 1) return;
+  if (A.ablate & 1) return;
   const int lane = lane_id();
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform (keeps loops scalar)
   lds_u32 *qg = queues + wave * QCAP;              // 4-pixel groups for the exact pretest
@@ -195,9 +144,9 @@ __global__ __launch_bounds__(NT) void k_fused_strips(
   int ng = 0, nf = 0;                               // wave-uniform queue fills
   // NOTE: the lambdas below capture by reference; they must only touch LOCAL copies of kernel
   // arguments — capturing `P` itself makes the compiler spill the whole 800-byte struct to scratch.
-  const int thr = P.thr;
-  const int32_t hthr = P.hthr;
-  const int ablate = P.ablate;
+  const int thr = A.thr;
+  const int32_t hthr = A.hthr;
+  const int ablate = A.ablate;
   const int Lw = L.w, Lxend = L.xend, Lh = L.h;
   const bool wmod = (Lw & 15) != 0;
 
@@ -345,11 +294,11 @@ __global__ __launch_bounds__(NT) void k_fused_strips(
   }
   __syncthreads();
 
-  if (P.dump_score) {   // debug / parity hook: rows this strip owns, [ys, ye)
-    uint8_t *dst = score_dump + (size_t)pyr * score_stride + (size_t)L.row0 * P.vstep + L.col0;
+  if (A.dump_score) {   // debug / parity hook: rows this strip owns, [ys, ye)
+    uint8_t *dst = score_dump + (size_t)pyr * score_stride + (size_t)L.row0 * A.vstep + L.col0;
     for (int i = tid; i < (ye - ys) * pitch; i += NT) {
       const int r = i / pitch, x = i - r * pitch;
-      if (x >= B && x < max(Lxend, wmod ? Lw + 2 : 0)) dst[(ptrdiff_t)(ys + r) * P.vstep + x] = sc[(r + 1) * pitch + x];
+      if (x >= B && x < max(Lxend, wmod ? Lw + 2 : 0)) dst[(ptrdiff_t)(ys + r) * A.vstep + x] = sc[(r + 1) * pitch + x];
     }
   }
 
@@ -405,16 +354,16 @@ __global__ __launch_bounds__(NT) void k_fused_strips(
     if (sh_ctr[3] == 0) {
       if (ablate & 128) return;
       const int ns = (int)sh_ctr[4];
-      const size_t strip_slot = (size_t)pyr * P.slots_per_pyr + L.slot0 + (size_t)s * (L.R >> 1) * L.nbx;
+      const size_t strip_slot = (size_t)pyr * A.slots_per_pyr + L.slot0 + (size_t)s * (L.R >> 1) * L.nbx;
       const uint32_t add_xy = ((uint32_t)L.col0 << 12) | (uint32_t)L.row0;      // README.md:78
-      if (P.lbs == 0) {
+      if (A.lbs == 0) {
         for (int i = tid; i < ns; i += NT) {
           const uint32_t key = shq_k[i];
           int rank = 0;
           for (int j = 0; j < ns; j++) rank += shq_k[j] < key;
           stage_kp[strip_slot + rank] = shq_s[i] + add_xy;
         }
-        if (tid == 0) strip_count[(size_t)pyr * P.strips_per_pyr + L.strip0 + s] = (uint32_t)ns;
+        if (tid == 0) strip_count[(size_t)pyr * A.strips_per_pyr + L.strip0 + s] = (uint32_t)ns;
         return;
       }
       // Buckets (Fast.h:314-352): a cell = one bucket x one flush interval = 2^lbs x 2^lbs pixels of
@@ -422,7 +371,7 @@ __global__ __launch_bounds__(NT) void k_fused_strips(
       // (cell-row, bucket) order.  Strip heights are multiples of the cell size, so cells never
       // straddle strips.  Pass 1 marks the survivors that make their cell's top-`limit`, pass 2 ranks
       // the kept ones by (cell, value).
-      const int lbs = P.lbs, limit = P.limit;
+      const int lbs = A.lbs, limit = A.limit;
       for (int i = tid; i < ns; i += NT) {
         const uint32_t v = shq_s[i];
         const uint32_t cell = (((uint32_t)(decode_y(v) - B) >> lbs) << 12) | ((uint32_t)(decode_x(v) - B) >> lbs);
@@ -449,14 +398,14 @@ __global__ __launch_bounds__(NT) void k_fused_strips(
       }
       if (kept_here) atomicAdd(&sh_ctr[5], (uint32_t)kept_here);
       __syncthreads();
-      if (tid == 0) strip_count[(size_t)pyr * P.strips_per_pyr + L.strip0 + s] = sh_ctr[5];
+      if (tid == 0) strip_count[(size_t)pyr * A.strips_per_pyr + L.strip0 + s] = sh_ctr[5];
       return;
     }
   }
   // Fallback (a queue overflowed: very dense corners): scan the whole score tile.
-  if (P.lbs != 0) {
+  if (A.lbs != 0) {
     // Bucket mode: one wave per cell, top-`limit` by repeated wave-max over the cell's blocks.
-    const int lbs = P.lbs, limit = P.limit, bs = 1 << lbs, hb = bs >> 1;
+    const int lbs = A.lbs, limit = A.limit, bs = 1 << lbs, hb = bs >> 1;
     const int ncx = (Lw - 2 * B - 1) / bs + 1;                     // Fast.h:201 numBuckets
     const int ncy = (ye - ys + bs - 1) / bs;
     const int ncell = ncx * ncy, nblk = hb * hb;
@@ -488,7 +437,7 @@ __global__ __launch_bounds__(NT) void k_fused_strips(
       if (lane == 0) cellcnt[cell] = (uint32_t)nf_c;
     }
     __syncthreads();
-    const size_t strip_slot = (size_t)pyr * P.slots_per_pyr + L.slot0 + (size_t)s * (L.R >> 1) * L.nbx;
+    const size_t strip_slot = (size_t)pyr * A.slots_per_pyr + L.slot0 + (size_t)s * (L.R >> 1) * L.nbx;
     const uint32_t add_xy = ((uint32_t)L.col0 << 12) | (uint32_t)L.row0;
     for (int cell = wave; cell < ncell; cell += WAVES) {
       const uint32_t n = cellcnt[cell];
@@ -502,7 +451,7 @@ __global__ __launch_bounds__(NT) void k_fused_strips(
       uint32_t tot = 0;
       for (int k = lane; k < ncell; k += 64) tot += cellcnt[k];
       tot = (uint32_t)wave_sum((int)tot);
-      if (lane == 0) strip_count[(size_t)pyr * P.strips_per_pyr + L.strip0 + s] = tot;
+      if (lane == 0) strip_count[(size_t)pyr * A.strips_per_pyr + L.strip0 + s] = tot;
     }
     return;
   }
@@ -567,7 +516,7 @@ __global__ __launch_bounds__(NT) void k_fused_strips(
   }
   __syncthreads();
   if (ablate & 128) return;                         // profiling only: NMS compute without the copy-out
-  const size_t strip_slot = (size_t)pyr * P.slots_per_pyr + L.slot0 + (size_t)s * (L.R >> 1) * nbx;
+  const size_t strip_slot = (size_t)pyr * A.slots_per_pyr + L.slot0 + (size_t)s * (L.R >> 1) * nbx;
   const uint32_t add_xy = ((uint32_t)L.col0 << 12) | (uint32_t)L.row0;      // README.md:78
   for (int br = wave; br < nbr; br += WAVES) {
     const uint32_t n = rowcnt[br];
@@ -579,8 +528,82 @@ __global__ __launch_bounds__(NT) void k_fused_strips(
   if (tid == 0) {
     uint32_t tot = 0;
     for (int k = 0; k < nbr; k++) tot += rowcnt[k];
-    strip_count[(size_t)pyr * P.strips_per_pyr + L.strip0 + s] = tot;
+    strip_count[(size_t)pyr * A.strips_per_pyr + L.strip0 + s] = tot;
   }
+}
+
+template <bool VEC16>
+__global__ __launch_bounds__(NT) void k_fused_strips(
+    const FusedParams P, const uint8_t *__restrict__ pyramids, size_t pyr_stride,
+    uint32_t *__restrict__ stage_kp, uint32_t *__restrict__ strip_count,
+    uint8_t *__restrict__ score_dump, size_t score_stride) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  // XCD-aware mapping: workgroup b runs on XCD b%8; keep all strips of one pyramid on one XCD so
+  // the halo rows shared by neighbouring strips are served by that XCD's L2.
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int pyr = (slot / P.strips_per_pyr) * 8 + xcd;
+  if (pyr >= P.batch) return;
+  int s = slot % P.strips_per_pyr;
+  int li = 0;
+  while (li + 1 < P.nlevels && s >= P.lv[li + 1].strip0) li++;
+  const FusedLevel L = P.lv[li];
+  s -= L.strip0;
+  const int B = P.border;
+  const int ys = B + s * L.R;                       // first block-row y of the strip
+  const int ye = min(ys + L.R, L.h - B);            // one past the last row owned
+  const int pitch = L.pitch;
+  const int trows = L.R + 10;                       // image tile rows  [ys-4, ys+R+6)
+  lds_u8 *tile = (lds_u8 *)smem;
+  lds_u8 *sc = tile + trows * pitch;                // score tile rows  [ys-1, ys+R+2)
+  lds_u32 *queues = (lds_u32 *)(sc + (L.R + 3) * pitch);
+
+  const uint8_t *im = pyramids + (size_t)pyr * pyr_stride + (size_t)L.row0 * P.vstep + L.col0;
+  const int tid = threadIdx.x;
+  // [0] corners queued, [1] first overflowed corner slot, [2] non-zero scores queued,
+  // [3] set when a queue overflowed -> NMS falls back to scanning the score tile, [4] survivors
+  __shared__ uint32_t sh_ctr[8];
+  if (tid < 8) sh_ctr[tid] = tid == 1 ? QH_SHARED : 0;
+
+  // ---- stage the image rows [ys-4, min(ye+6, h)) and clear the score tile ---------------
+  {
+    const int y_lo = ys - 4;
+    const int nrows = min(ye + 6, L.h) - y_lo;
+    if (VEC16) {
+      const int vpr = pitch >> 4;                   // 16-byte vectors per row
+      // bytes of this pyramid's buffer that may be read (the tile can overhang the last image row
+      // when col0 + pitch > vstep: flat addressing like the reference, but never past the buffer)
+      const ptrdiff_t lim = (ptrdiff_t)P.rows * P.vstep - ((ptrdiff_t)L.row0 * P.vstep + L.col0);
+      for (int i = tid; i < ((P.ablate & 256) ? 0 : nrows * vpr); i += NT) {   // ablate 256: profiling without the HBM read
+        const int r = (int)__umulhi((uint32_t)i, L.vpr_recip), v = i - r * vpr;
+        const ptrdiff_t off = (ptrdiff_t)(y_lo + r) * P.vstep + 16 * v;
+        u32x4 d;
+        if (off + 16 <= lim) {
+          d = *(const u32x4 *)(im + off);
+        } else {
+          uint32_t w4[4] = {0, 0, 0, 0};          // tail of the buffer: byte-wise, zero beyond the end
+#pragma unroll
+          for (int k = 0; k < 16; k++)
+            if (off + k < lim) w4[k >> 2] |= (uint32_t)im[off + k] << (8 * (k & 3));
+          d = (u32x4){w4[0], w4[1], w4[2], w4[3]};
+        }
+        *(lds_u4 *)(tile + r * pitch + 16 * v) = d;
+      }
+    } else {
+      const ptrdiff_t lim = (ptrdiff_t)P.rows * P.vstep - ((ptrdiff_t)L.row0 * P.vstep + L.col0);
+      for (int i = tid; i < nrows * pitch; i += NT) {
+        const int r = i / pitch, cx = i - r * pitch;
+        const ptrdiff_t off = (ptrdiff_t)(y_lo + r) * P.vstep + cx;
+        tile[r * pitch + cx] = off < lim ? im[off] : (uint8_t)0;
+      }
+    }
+    const int nz = ((L.R + 3) * pitch) >> 4;
+    for (int i = tid; i < nz; i += NT) ((lds_u4 *)sc)[i] = (u32x4)(0u);
+  }
+  __syncthreads();
+
+  strip_body(StripArgs{P.border, P.thr, P.ablate, P.dump_score, P.lbs, P.limit, P.vstep, P.slots_per_pyr,
+                       P.strips_per_pyr, P.hthr},
+             L, pyr, s, ys, ye, tile, sc, queues, sh_ctr, stage_kp, strip_count, score_dump, score_stride);
 }
 
 // One workgroup per pyramid: exclusive scan of the strip counts in strip order (= level order,
