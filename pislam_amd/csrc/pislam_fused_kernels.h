@@ -403,6 +403,7 @@ __device__ __forceinline__ void strip_body(const StripArgs A, const FusedLevel L
     }
   }
   // Fallback (a queue overflowed: very dense corners): scan the whole score tile.
+  if (tid == 0) sh_ctr[6] = 1;                      // the fallbacks scribble over the whole image tile
   if (A.lbs != 0) {
     // Bucket mode: one wave per cell, top-`limit` by repeated wave-max over the cell's blocks.
     const int lbs = A.lbs, limit = A.limit, bs = 1 << lbs, hb = bs >> 1;
@@ -604,6 +605,110 @@ __global__ __launch_bounds__(NT) void k_fused_strips(
   strip_body(StripArgs{P.border, P.thr, P.ablate, P.dump_score, P.lbs, P.limit, P.vstep, P.slots_per_pyr,
                        P.strips_per_pyr, P.hthr},
              L, pyr, s, ys, ye, tile, sc, queues, sh_ctr, stage_kp, strip_count, score_dump, score_stride);
+}
+
+// ===========================================================================
+// k_fused_persistent — the same strip phases, but a workgroup walks DOWN a whole level of one
+// pyramid (work item = (level, pyramid), handed out largest-first by an atomic counter):
+//   * the 10 halo rows at the bottom of a strip's tile are the top rows of the next strip: they are
+//     moved inside LDS instead of being re-read (no halo traffic at all);
+//   * the R new rows of the NEXT strip are loaded into registers BEFORE the current strip is
+//     processed and written to LDS after it (async-stage split): the HBM latency hides under ~10 us
+//     of compute, and there is no per-strip workgroup launch / drain.
+// ===========================================================================
+constexpr int PF_VEC = 3;                            // prefetched 16-byte vectors per thread (R * pitch/16 <= 3 * NT)
+
+__global__ __launch_bounds__(NT) void k_fused_persistent(
+    const FusedParams P, const uint8_t *__restrict__ pyramids, size_t pyr_stride,
+    uint32_t *__restrict__ stage_kp, uint32_t *__restrict__ strip_count,
+    uint8_t *__restrict__ score_dump, size_t score_stride, uint32_t *__restrict__ work_counter) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  __shared__ uint32_t sh_ctr[8];
+  __shared__ uint32_t sh_item;
+  const int tid = threadIdx.x;
+  const uint32_t nitems = (uint32_t)P.nlevels * (uint32_t)P.batch;
+  const StripArgs A{P.border, P.thr, P.ablate, P.dump_score, P.lbs, P.limit, P.vstep, P.slots_per_pyr,
+                    P.strips_per_pyr, P.hthr};
+  const int B = P.border;
+  for (;;) {
+    if (tid == 0) sh_item = atomicAdd(work_counter, 1u);
+    __syncthreads();
+    const uint32_t item = sh_item;
+    __syncthreads();
+    if (item >= nitems) break;
+    const int li = (int)(item / (uint32_t)P.batch), pyr = (int)(item - (uint32_t)li * (uint32_t)P.batch);
+    const FusedLevel L = P.lv[li];
+    if (L.nstrips == 0) continue;
+    const int pitch = L.pitch, vpr = pitch >> 4, R = L.R;
+    lds_u8 *tile = (lds_u8 *)smem;
+    lds_u8 *sc = tile + (R + 10) * pitch;
+    lds_u32 *queues = (lds_u32 *)(sc + (R + 3) * pitch);
+    const uint8_t *im = pyramids + (size_t)pyr * pyr_stride + (size_t)L.row0 * P.vstep + L.col0;
+    const ptrdiff_t lim = (ptrdiff_t)P.rows * P.vstep - ((ptrdiff_t)L.row0 * P.vstep + L.col0);
+    auto load_vec = [&](int level_row, int v) {      // 16 bytes of a level row, never past the pyramid buffer
+      const ptrdiff_t off = (ptrdiff_t)level_row * P.vstep + 16 * v;
+      u32x4 d;
+      if (off + 16 <= lim) {
+        d = *(const u32x4 *)(im + off);
+      } else {
+        uint32_t w4[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int k = 0; k < 16; k++)
+          if (off + k < lim) w4[k >> 2] |= (uint32_t)im[off + k] << (8 * (k & 3));
+        d = (u32x4){w4[0], w4[1], w4[2], w4[3]};
+      }
+      return d;
+    };
+    bool full_stage = true;
+    for (int s = 0; s < L.nstrips; s++) {
+      const int ys = B + s * R, ye = min(ys + R, L.h - B);
+      if (full_stage) {                               // first strip of the item (or after a fallback)
+        const int y_lo = ys - 4, nrows = min(ye + 6, L.h) - y_lo;
+        for (int i = tid; i < nrows * vpr; i += NT) {
+          const int r = (int)__umulhi((uint32_t)i, L.vpr_recip), v = i - r * vpr;
+          *(lds_u4 *)(tile + r * pitch + 16 * v) = load_vec(y_lo + r, v);
+        }
+      }
+      {
+        const int nz = ((R + 3) * pitch) >> 4;
+        for (int i = tid; i < nz; i += NT) ((lds_u4 *)sc)[i] = (u32x4)(0u);
+        if (tid < 8) sh_ctr[tid] = tid == 1 ? QH_SHARED : 0;
+      }
+      // issue the loads of the next strip's new rows [ys+R+6, min(ye'+6, h)) now, use them later
+      u32x4 pf[PF_VEC];
+      int pf_rows = 0;
+      if (s + 1 < L.nstrips) {
+        const int ye_n = min(ys + 2 * R, L.h - B);
+        pf_rows = min(ye_n + 6, L.h) - (ys + R + 6);
+#pragma unroll
+        for (int j = 0; j < PF_VEC; j++) {
+          const int i = tid + NT * j;
+          if (i < pf_rows * vpr) {
+            const int r = (int)__umulhi((uint32_t)i, L.vpr_recip), v = i - r * vpr;
+            pf[j] = load_vec(ys + R + 6 + r, v);
+          }
+        }
+      }
+      __syncthreads();
+      strip_body(A, L, pyr, s, ys, ye, tile, sc, queues, sh_ctr, stage_kp, strip_count, score_dump, score_stride);
+      __syncthreads();
+      full_stage = sh_ctr[6] != 0;
+      if (s + 1 < L.nstrips && !full_stage) {
+        // halo rows [R, R+10) of this tile -> rows [0, 10) of the next one (R >= 16: no overlap)
+        for (int i = tid; i < 10 * vpr; i += NT) *(lds_u4 *)(tile + 16 * i) = *(const lds_u4 *)(tile + R * pitch + 16 * i);
+        __syncthreads();                              // the new rows land on top of the rows just moved
+#pragma unroll
+        for (int j = 0; j < PF_VEC; j++) {
+          const int i = tid + NT * j;
+          if (i < pf_rows * vpr) {
+            const int r = (int)__umulhi((uint32_t)i, L.vpr_recip), v = i - r * vpr;
+            *(lds_u4 *)(tile + (10 + r) * pitch + 16 * v) = pf[j];
+          }
+        }
+      }
+      __syncthreads();
+    }
+  }
 }
 
 // One workgroup per pyramid: exclusive scan of the strip counts in strip order (= level order,

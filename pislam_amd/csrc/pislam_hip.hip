@@ -84,8 +84,9 @@ struct pislam_ctx {
   // compaction scratch (shared by extract and the batch pipeline)
   DevBuf w_cnt, w_off, w_total, w_cellkp;
   // batch pipeline workspace
-  DevBuf w_score, w_stage, w_stripcnt;
-  int opt_pipeline = 0;      // 0 auto, 1 staged (one launch group per level), 2 fused strips
+  DevBuf w_score, w_stage, w_stripcnt, w_work;
+  int num_cus = 0;
+  int opt_pipeline = 0;      // 0 auto, 1 staged (one launch group per level), 2 fused strips, 3 fused persistent
   int opt_dump_score = 0;    // fused pipeline: also materialise the score map (parity hook)
   int opt_strip_rows = 0;    // fused pipeline: strip height override (0 = heuristic)
   int opt_ablate = 0;        // profiling only: skip phases of the fused kernel (results invalid)
@@ -360,7 +361,7 @@ PISLAM_EXPORT int pislam_ctx_destroy(pislam_ctx *c) {
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
   for (DevBuf *b : {&c->s_img, &c->s_out, &c->s_pts, &c->s_desc, &c->s_misc, &c->s_rots, &c->s_tmp, &c->w_cnt,
-                    &c->w_off, &c->w_total, &c->w_cellkp, &c->w_score, &c->w_stage, &c->w_stripcnt})
+                    &c->w_off, &c->w_total, &c->w_cellkp, &c->w_score, &c->w_stage, &c->w_stripcnt, &c->w_work})
     b->release();
   for (auto &e : c->ev)
     if (e) (void)hipEventDestroy(e);
@@ -377,7 +378,8 @@ PISLAM_EXPORT int pislam_ctx_set_stream(pislam_ctx *c, void *s) {
 PISLAM_EXPORT int pislam_ctx_set_option(pislam_ctx *c, const char *key, int value) {
   if (!c || !key) return PISLAM_ERR_INVALID;
   if (!strcmp(key, "pipeline")) {
-    if (value < 0 || value > 2) return fail(c, PISLAM_ERR_INVALID, "pipeline must be 0 (auto), 1 (staged) or 2 (fused)");
+    if (value < 0 || value > 3)
+      return fail(c, PISLAM_ERR_INVALID, "pipeline must be 0 (auto), 1 (staged), 2 (fused strips) or 3 (fused persistent)");
     c->opt_pipeline = value;
   } else if (!strcmp(key, "dump_score")) {
     c->opt_dump_score = value != 0;
@@ -864,12 +866,31 @@ int run_fused(pislam_ctx *c, const pislam_frontend_params *p, const pf::FusedPar
   const dim3 grid((unsigned)(groups * F.strips_per_pyr * 8));
   uint8_t *dump = F.dump_score ? c->w_score.as<uint8_t>() : nullptr;
   const size_t dump_stride = (size_t)p->rows * p->vstep;
-  auto kern = vec ? pf::k_fused_strips<true> : pf::k_fused_strips<false>;
-  if (lds > 64 * 1024)
-    HIPCHK(c, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(kern, grid, dim3(pf::NT), lds, c->stream, F, pyramids, stride, c->w_stage.as<uint32_t>(),
-                     c->w_stripcnt.as<uint32_t>(), dump, dump_stride);
-  PCHK(launch_ok(c, "k_fused_strips"));
+  // persistent variant: needs 16-byte rows, R >= 16 (halo move without overlap) and R * pitch/16 <= 3 * NT
+  bool persistent = vec && c->opt_pipeline == 3;
+  for (int l = 0; l < F.nlevels && persistent; l++)
+    if (F.lv[l].nstrips && (F.lv[l].R < 16 || F.lv[l].R * (F.lv[l].pitch / 16) > pf::PF_VEC * pf::NT)) persistent = false;
+  if (c->opt_pipeline == 3 && !persistent)
+    return fail(c, PISLAM_ERR_INVALID, "persistent pipeline unavailable for this layout (alignment / strip size)");
+  if (persistent) {
+    if (c->num_cus == 0) HIPCHK(c, hipDeviceGetAttribute(&c->num_cus, hipDeviceAttributeMultiprocessorCount, c->device));
+    if (c->w_work.ensure(sizeof(uint32_t)) != PISLAM_OK) return fail(c, PISLAM_ERR_NOMEM, "hipMalloc(work counter)");
+    HIPCHK(c, hipMemsetAsync(c->w_work.p, 0, sizeof(uint32_t), c->stream));
+    const int per_cu = std::max(1, std::min(8, (int)(160 * 1024 / std::max<size_t>(lds, 1))));
+    const int nwg = std::min(c->num_cus * per_cu, F.nlevels * batch);
+    if (lds > 64 * 1024)
+      HIPCHK(c, hipFuncSetAttribute((const void *)pf::k_fused_persistent, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(pf::k_fused_persistent, dim3(nwg), dim3(pf::NT), lds, c->stream, F, pyramids, stride,
+                       c->w_stage.as<uint32_t>(), c->w_stripcnt.as<uint32_t>(), dump, dump_stride, c->w_work.as<uint32_t>());
+    PCHK(launch_ok(c, "k_fused_persistent"));
+  } else {
+    auto kern = vec ? pf::k_fused_strips<true> : pf::k_fused_strips<false>;
+    if (lds > 64 * 1024)
+      HIPCHK(c, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, grid, dim3(pf::NT), lds, c->stream, F, pyramids, stride, c->w_stage.as<uint32_t>(),
+                       c->w_stripcnt.as<uint32_t>(), dump, dump_stride);
+    PCHK(launch_ok(c, "k_fused_strips"));
+  }
   HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
   HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
   if (p->vstep % 16 != 0) {
@@ -957,9 +978,9 @@ PISLAM_EXPORT int pislam_orb_frontend_batch(pislam_ctx *c, const pislam_frontend
   pf::FusedParams F;
   size_t lds = 0;
   bool fused = c->opt_pipeline != 1 && build_fused_plan(c, p, lv, batch, &F, &lds);
-  if (c->opt_pipeline == 2 && !fused)
+  if (c->opt_pipeline >= 2 && !fused)
     return fail(c, PISLAM_ERR_INVALID, "fused pipeline unavailable for these parameters (bucket size / LDS size)");
-  c->last_pipeline = fused ? 2 : 1;
+  c->last_pipeline = fused ? 2 : 1;   // (2 also stands for the persistent variant: no HBM score map)
   HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
   if (fused) {
     PCHK(run_fused(c, p, F, lds, pyramids, stride, batch, kp, desc, counts));

@@ -47,7 +47,7 @@ def test_four_call_api_on_reference_demo_pyramid(gpu_ctx, orc, demo):
     assert sha16(desc) == SURVEY_PINS["desc"] and (desc == demo["desc"]).all()
 
 
-@pytest.fixture(params=[1, 2], ids=["staged", "fused"])
+@pytest.fixture(params=[1, 2, 3], ids=["staged", "fused", "persistent"])
 def pipeline(request, gpu_ctx):
     """Run the batch tests on both pipelines; the fused one also dumps its LDS score tiles."""
     gpu_ctx.set_option("pipeline", request.param)
@@ -238,7 +238,7 @@ def test_fused_odd_shapes_and_unaligned_layouts(gpu_ctx, orc):
     d_pyr = torch.from_numpy(pyr).to(dev)
     res = {}
     for lb, lim in [(0, 5), (4, 3), (2, 1), (3, 2), (5, 40)]:
-        for pl in (1, 2):
+        for pl in (1, 2):   # (the persistent variant needs 16-byte aligned level columns: not this layout)
             gpu_ctx.set_option("pipeline", pl)
             try:
                 fe = OrbFrontend(levels, vstep=vstep, rows=rows, max_keypoints=8192, log_bucket_size=lb,
