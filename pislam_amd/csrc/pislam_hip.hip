@@ -86,6 +86,8 @@ struct pislam_ctx {
   // batch pipeline workspace
   DevBuf w_score, w_stage, w_stripcnt, w_work;
   int num_cus = 0;
+  const void *pyr_zeroed = nullptr;   // pyramid buffer whose padding is known to be in its defined state
+  size_t pyr_zeroed_sig = 0;
   int opt_pipeline = 0;      // 0 auto, 1 staged (one launch group per level), 2 fused strips, 3 fused persistent
   int opt_dump_score = 0;    // fused pipeline: also materialise the score map (parity hook)
   int opt_strip_rows = 0;    // fused pipeline: strip height override (0 = heuristic)
@@ -591,6 +593,26 @@ PISLAM_EXPORT int pislam_harris_score_points(pislam_ctx *c, int vstep, const uin
 }
 
 
+
+namespace {
+// launch bilinear N/M for `batch` images; fast 4-block kernel when everything is 16-byte aligned
+template <int N, int M>
+int launch_bilinear(pislam_ctx *c, const uint8_t *src, uint8_t *dst, int vstep_src, int vstep_dst, size_t stride_src,
+                    size_t stride_dst, int batch, int width, int height) {
+  const int nbx = cdiv(width, N), nby = cdiv(height, N);
+  const bool fast = ((uintptr_t)src % 16 == 0) && ((uintptr_t)dst % 4 == 0) && vstep_src % 16 == 0 && vstep_dst % 4 == 0 &&
+                    stride_src % 16 == 0 && stride_dst % 4 == 0 &&
+                    (ptrdiff_t)cdiv(nbx, 4) * 4 * N <= vstep_src;      // the last group's 16-byte loads stay in the row
+  if (fast)
+    hipLaunchKernelGGL((pp::k_bilinear4<N, M>), dim3(cdiv(cdiv(nbx, 4), 64), cdiv(nby * M, 4), batch), dim3(256), 0,
+                       c->stream, src, dst, vstep_src, vstep_dst, stride_src, stride_dst, width, height);
+  else
+    hipLaunchKernelGGL((pp::k_bilinear<N, M>), dim3(cdiv(nbx * M, 256), cdiv(nby * M, 4), batch), dim3(256), 0, c->stream,
+                       src, dst, vstep_src, vstep_dst, stride_src, stride_dst, width, height);
+  return launch_ok(c, "k_bilinear");
+}
+}  // namespace
+
 // ===========================================================================
 // image preparation ("next" tier): gaussian5x5, bilinear7_8, bilinear13_16
 // ===========================================================================
@@ -630,16 +652,12 @@ int prep_common(pislam_ctx *c, int kind, int vstep, int width, int height, const
     dim3 grid(cdiv(width, pp::G_TW), cdiv(height, pp::G_TH), 1);
     hipLaunchKernelGGL(pp::k_gaussian5x5, grid, dim3(256), 0, c->stream, d_src, d_dst, vstep, vstep, (size_t)0,
                        (size_t)0, width, height);
+    PCHK(launch_ok(c, "k_gaussian5x5"));
   } else if (kind == 1) {
-    dim3 grid(cdiv(wpad / 8 * 7, 64), cdiv(hpad / 8 * 7, 4), 1);
-    hipLaunchKernelGGL((pp::k_bilinear<8, 7>), grid, dim3(256), 0, c->stream, d_src, d_dst, vstep, vstep, (size_t)0,
-                       (size_t)0, width, height);
+    PCHK((launch_bilinear<8, 7>(c, d_src, d_dst, vstep, vstep, 0, 0, 1, width, height)));
   } else {
-    dim3 grid(cdiv(wpad / 16 * 13, 64), cdiv(hpad / 16 * 13, 4), 1);
-    hipLaunchKernelGGL((pp::k_bilinear<16, 13>), grid, dim3(256), 0, c->stream, d_src, d_dst, vstep, vstep, (size_t)0,
-                       (size_t)0, width, height);
+    PCHK((launch_bilinear<16, 13>(c, d_src, d_dst, vstep, vstep, 0, 0, 1, width, height)));
   }
-  PCHK(launch_ok(c, "prep kernel"));
   if (so.host) {
     PCHK(stage_out(c, so, out, out_bytes));   // rows the kernels can have written
     PCHK(sync(c));
@@ -729,8 +747,17 @@ PISLAM_EXPORT int pislam_pyramid_build_batch(pislam_ctx *c, int nlevels, const i
   if (levels[0].width > frame_vstep || frame_stride < (size_t)levels[0].height * frame_vstep)
     return fail(c, PISLAM_ERR_INVALID, "frame buffer too small");
   HIPCHK(c, hipSetDevice(c->device));
-  // padding bytes are read by the bilinear steps and by FAST's right-edge columns: define them as zero
-  HIPCHK(c, hipMemsetAsync(pyramids, 0, pyramid_stride * (size_t)batch, c->stream));
+  // Padding bytes are read by the bilinear steps and by FAST's right-edge columns: they are defined as
+  // "the buffer was zero before the first build".  Re-building into the same buffer with the same
+  // layout rewrites exactly the same bytes, so the memset is only needed when either changes.
+  size_t sig = (size_t)vstep * 1315423911u ^ (size_t)rows * 2654435761u ^ pyramid_stride ^ ((size_t)batch << 40) ^ (size_t)blur;
+  for (int l = 0; l < nlevels; l++)
+    sig = sig * 31 + (size_t)levels[l].width * 7 + (size_t)levels[l].height * 13 + (size_t)levels[l].row0 + (l + 1 < nlevels ? steps[l] : 0);
+  if (c->pyr_zeroed != pyramids || c->pyr_zeroed_sig != sig) {
+    HIPCHK(c, hipMemsetAsync(pyramids, 0, pyramid_stride * (size_t)batch, c->stream));
+    c->pyr_zeroed = pyramids;
+    c->pyr_zeroed_sig = sig;
+  }
   const int w0 = levels[0].width, h0 = levels[0].height;
   if (blur) {
     hipLaunchKernelGGL(pp::k_gaussian5x5, dim3(cdiv(w0, pp::G_TW), cdiv(h0, pp::G_TH), batch), dim3(256), 0, c->stream,
@@ -748,16 +775,10 @@ PISLAM_EXPORT int pislam_pyramid_build_batch(pislam_ctx *c, int nlevels, const i
     const uint8_t *src = pyramids + (size_t)levels[l].row0 * vstep;
     uint8_t *dst = pyramids + (size_t)levels[l + 1].row0 * vstep;
     const int w = levels[l].width, h = levels[l].height;
-    if (steps[l] == 1) {
-      const int wp = (w + 7) / 8 * 8, hp = (h + 7) / 8 * 8;
-      hipLaunchKernelGGL((pp::k_bilinear<8, 7>), dim3(cdiv(wp / 8 * 7, 64), cdiv(hp / 8 * 7, 4), batch), dim3(256), 0,
-                         c->stream, src, dst, vstep, vstep, pyramid_stride, pyramid_stride, w, h);
-    } else {
-      const int wp = (w + 15) / 16 * 16, hp = (h + 15) / 16 * 16;
-      hipLaunchKernelGGL((pp::k_bilinear<16, 13>), dim3(cdiv(wp / 16 * 13, 64), cdiv(hp / 16 * 13, 4), batch), dim3(256),
-                         0, c->stream, src, dst, vstep, vstep, pyramid_stride, pyramid_stride, w, h);
-    }
-    PCHK(launch_ok(c, "k_bilinear"));
+    if (steps[l] == 1)
+      PCHK((launch_bilinear<8, 7>(c, src, dst, vstep, vstep, pyramid_stride, pyramid_stride, batch, w, h)));
+    else
+      PCHK((launch_bilinear<16, 13>(c, src, dst, vstep, vstep, pyramid_stride, pyramid_stride, batch, w, h)));
   }
   return PISLAM_OK;
 }

@@ -73,25 +73,17 @@ __global__ __launch_bounds__(256) void k_gaussian5x5(const uint8_t *__restrict__
 // bilinear7_8 / bilinear13_16 — reference Bilinear.h:42 / :165 (behaviour:
 // BilinearTest.cpp:171-196 / :198-233).  One lane per output pixel; every N x N source block
 // (N = 8 or 16) yields M x M outputs (M = 7 or 13); the four taps and two filter weights per axis
-// come from small constant tables.  The reference's fixed-point rounding RSHR(a,8) = (a+128)>>8.
+// come from small constant tables (bilinear_px).  The reference's fixed-point rounding RSHR(a,8) = (a+128)>>8.
 // Writes the same full M x M blocks the scalar reference writes (outputs beyond
 // floor(w*M/N) x floor(h*M/N) depend on the caller's padding, exactly as in the reference).
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ int rshr8(int a) { return (a + 128) >> 8; }
 
 template <int N, int M>
-__global__ __launch_bounds__(256) void k_bilinear(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst,
-                                                  int vstep_src, int vstep_dst, size_t stride_src,
-                                                  size_t stride_dst, int width, int height) {
+__device__ __forceinline__ uint32_t bilinear_px(const uint8_t *__restrict__ s, int vstep_src, int ox, int oy) {
   // filter banks: Bilinear.h:49-52 (7/8) and Bilinear.h:172-180 (13/16; f[10] = 138 as in the reference)
   constexpr int F7[7] = {238, 201, 165, 128, 91, 55, 18};
   constexpr int F13[13] = {226, 167, 108, 49, 246, 187, 128, 69, 10, 207, 138, 89, 30};
-  const int nbx = (width + N - 1) / N, nby = (height + N - 1) / N;
-  const int ow = nbx * M, oh = nby * M;
-  const int ox = blockIdx.x * 64 + (threadIdx.x & 63), oy = blockIdx.y * 4 + (threadIdx.x >> 6);
-  if (ox >= ow || oy >= oh) return;
-  const uint8_t *s = src + (size_t)blockIdx.z * stride_src;
-  uint8_t *d = dst + (size_t)blockIdx.z * stride_dst;
   const int bx = ox / M, x = ox - bx * M, by = oy / M, y = oy - by * M;
   int sx = x, sy = y, fx0, fx1, fy0, fy1;
   if (M == 7) {
@@ -104,7 +96,92 @@ __global__ __launch_bounds__(256) void k_bilinear(const uint8_t *__restrict__ sr
   const uint8_t *p = s + (ptrdiff_t)(by * N + sy) * vstep_src + (bx * N + sx);
   const int h0 = rshr8(p[0] * fx0 + p[1] * fx1);
   const int h1 = rshr8(p[vstep_src] * fx0 + p[vstep_src + 1] * fx1);
-  d[(ptrdiff_t)oy * vstep_dst + ox] = (uint8_t)rshr8(h0 * fy0 + h1 * fy1);
+  return (uint32_t)rshr8(h0 * fy0 + h1 * fy1);
+}
+
+// Fast path: one lane = one output row of FOUR horizontally adjacent source blocks: 2 x (4N) source
+// bytes come in as 16-byte loads, the 4M outputs leave as M aligned dwords (4M = 28 or 52 bytes,
+// and 4 blocks start on a 4-byte boundary); the x loop is unrolled so every filter weight and
+// source column is an immediate.  Needs vstep % 16 == 0 and 16-byte aligned bases.
+template <int N, int M>
+__global__ __launch_bounds__(256) void k_bilinear4(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst,
+                                                   int vstep_src, int vstep_dst, size_t stride_src,
+                                                   size_t stride_dst, int width, int height) {
+  constexpr int F7[7] = {238, 201, 165, 128, 91, 55, 18};
+  constexpr int F13[13] = {226, 167, 108, 49, 246, 187, 128, 69, 10, 207, 138, 89, 30};
+  const int nbx = (width + N - 1) / N, nby = (height + N - 1) / N;
+  const int nq = (nbx + 3) / 4, oh = nby * M;
+  const int q = blockIdx.x * 64 + (threadIdx.x & 63), oy = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (q >= nq || oy >= oh) return;
+  const int by = oy / M, y = oy - by * M;
+  const int sy = (M == 7) ? y : y + (y > 3) + (y > 8);
+  int fy0 = 0, fy1 = 0;
+#pragma unroll
+  for (int k = 0; k < M; k++)
+    if (k == y) {
+      fy0 = (M == 7) ? F7[k] : F13[k];
+      fy1 = (M == 7) ? F7[M - 1 - k] : F13[M - 1 - k];
+    }
+  const uint8_t *s0 = src + (size_t)blockIdx.z * stride_src + (ptrdiff_t)(by * N + sy) * vstep_src + q * 4 * N;
+  uint8_t *d = dst + (size_t)blockIdx.z * stride_dst + (ptrdiff_t)oy * vstep_dst + q * 4 * M;
+  constexpr int NV = 4 * N / 16;                     // 16-byte vectors per source row segment
+  uint32_t r0[NV * 4], r1[NV * 4];
+  const int vmax = ((nbx - 4 * q) * N + 15) / 16;    // vectors that exist (whole blocks only; padding is the caller's)
+#pragma unroll
+  for (int v = 0; v < NV; v++) {
+    uint4 a = make_uint4(0, 0, 0, 0), b = a;
+    if (v < vmax) {
+      a = *(const uint4 *)(s0 + 16 * v);
+      b = *(const uint4 *)(s0 + vstep_src + 16 * v);
+    }
+    r0[4 * v] = a.x; r0[4 * v + 1] = a.y; r0[4 * v + 2] = a.z; r0[4 * v + 3] = a.w;
+    r1[4 * v] = b.x; r1[4 * v + 1] = b.y; r1[4 * v + 2] = b.z; r1[4 * v + 3] = b.w;
+  }
+  auto byte_of = [](const uint32_t *r, int i) { return (int)((r[i >> 2] >> (8 * (i & 3))) & 0xffu); };
+  uint32_t outw[M];
+#pragma unroll
+  for (int k = 0; k < M; k++) outw[k] = 0;
+#pragma unroll
+  for (int b = 0; b < 4; b++) {
+#pragma unroll
+    for (int x = 0; x < M; x++) {
+      const int sx = b * N + ((M == 7) ? x : x + (x > 3) + (x > 8));
+      const int fx0 = (M == 7) ? F7[x] : F13[x], fx1 = (M == 7) ? F7[M - 1 - x] : F13[M - 1 - x];
+      const int h0 = rshr8(byte_of(r0, sx) * fx0 + byte_of(r0, sx + 1) * fx1);
+      const int h1 = rshr8(byte_of(r1, sx) * fx0 + byte_of(r1, sx + 1) * fx1);
+      const uint32_t o = (uint32_t)rshr8(h0 * fy0 + h1 * fy1);
+      const int oi = b * M + x;
+      outw[oi >> 2] |= o << (8 * (oi & 3));
+    }
+  }
+  const int nb_here = min(4, nbx - 4 * q);           // blocks that exist in this group
+  if (nb_here == 4) {
+#pragma unroll
+    for (int k = 0; k < M; k++) *(uint32_t *)(d + 4 * k) = outw[k];
+  } else {
+    for (int i = 0; i < nb_here * M; i++) d[i] = (uint8_t)((outw[i >> 2] >> (8 * (i & 3))) & 0xffu);
+  }
+}
+
+// Generic path (any alignment): one lane = 4 horizontally adjacent outputs.
+template <int N, int M>
+__global__ __launch_bounds__(256) void k_bilinear(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst,
+                                                  int vstep_src, int vstep_dst, size_t stride_src,
+                                                  size_t stride_dst, int width, int height) {
+  const int nbx = (width + N - 1) / N, nby = (height + N - 1) / N;
+  const int ow = nbx * M, oh = nby * M;
+  const int ox = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4, oy = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (ox >= ow || oy >= oh) return;
+  const uint8_t *s = src + (size_t)blockIdx.z * stride_src;
+  uint8_t *d = dst + (size_t)blockIdx.z * stride_dst + (ptrdiff_t)oy * vstep_dst + ox;
+  uint32_t o[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) o[k] = ox + k < ow ? bilinear_px<N, M>(s, vstep_src, ox + k, oy) : 0u;
+  if (ox + 4 <= ow && (((uintptr_t)d) & 3) == 0) {
+    *(uint32_t *)d = o[0] | (o[1] << 8) | (o[2] << 16) | (o[3] << 24);
+  } else {
+    for (int k = 0; k < 4 && ox + k < ow; k++) d[k] = (uint8_t)o[k];
+  }
 }
 
 }  // namespace pp
