@@ -604,7 +604,7 @@ int launch_bilinear(pislam_ctx *c, const uint8_t *src, uint8_t *dst, int vstep_s
                     stride_src % 16 == 0 && stride_dst % 4 == 0 &&
                     (ptrdiff_t)cdiv(nbx, 4) * 4 * N <= vstep_src;      // the last group's 16-byte loads stay in the row
   if (fast)
-    hipLaunchKernelGGL((pp::k_bilinear4<N, M>), dim3(cdiv(cdiv(nbx, 4), 64), cdiv(nby * M, 4), batch), dim3(256), 0,
+    hipLaunchKernelGGL((pp::k_bilinear4<N, M>), dim3(cdiv(cdiv(nbx, 4) * nby * M, 256), 1, batch), dim3(256), 0,
                        c->stream, src, dst, vstep_src, vstep_dst, stride_src, stride_dst, width, height);
   else
     hipLaunchKernelGGL((pp::k_bilinear<N, M>), dim3(cdiv(nbx * M, 256), cdiv(nby * M, 4), batch), dim3(256), 0, c->stream,

@@ -28,43 +28,67 @@ __device__ __forceinline__ int reflect101(int i, int n) {
 // src and dst must not alias (the ABI stages in-place calls through a temporary).
 // ---------------------------------------------------------------------------
 constexpr int G_TW = 128, G_TH = 16;
+constexpr int G_PW = G_TW + 8;                       // LDS row: 4 halo bytes (2 used) on either side, dword aligned
+
+// byte-wise rounding halving add of 4 packed pixels: ceil((a+b)/2) = (a|b) - (((a^b) & 0xfe..) >> 1)
+__device__ __forceinline__ uint32_t rhadd4(uint32_t a, uint32_t b) { return (a | b) - (((a ^ b) & 0xfefefefeu) >> 1); }
+__device__ __forceinline__ uint32_t tap5x4(uint32_t a, uint32_t b, uint32_t c, uint32_t d, uint32_t e) {
+  return rhadd4(rhadd4(rhadd4(rhadd4(a, e), c), c), rhadd4(b, d));
+}
+
+// One workgroup = one 128 x 16 output tile.  Rows are staged as dwords (interior tiles: aligned
+// 4-byte loads; tiles touching the left/right image border or an unaligned source: per-byte with
+// the reflect-101 rule), both passes work on 4 packed pixels per lane (SWAR RHADD), the horizontal
+// taps come from v_alignbyte on aligned LDS dwords, and each lane stores one dword.
 __global__ __launch_bounds__(256) void k_gaussian5x5(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst,
                                                      int vstep_src, int vstep_dst, size_t stride_src,
                                                      size_t stride_dst, int width, int height) {
-  __shared__ uint8_t in[(G_TH + 4) * (G_TW + 4)];
-  __shared__ uint8_t mid[G_TH * (G_TW + 4)];
+  __shared__ __attribute__((aligned(16))) uint32_t in[(G_TH + 4) * (G_PW / 4)];
+  __shared__ __attribute__((aligned(16))) uint32_t mid[G_TH * (G_PW / 4)];
   const uint8_t *s = src + (size_t)blockIdx.z * stride_src;
   uint8_t *d = dst + (size_t)blockIdx.z * stride_dst;
   const int x0 = blockIdx.x * G_TW, y0 = blockIdx.y * G_TH;
-  for (int i = threadIdx.x; i < (G_TH + 4) * (G_TW + 4); i += 256) {
-    const int r = i / (G_TW + 4), c = i - r * (G_TW + 4);
-    const int gy = reflect101(y0 - 2 + r, height), gx = reflect101(x0 - 2 + c, width);
-    // tiles may overhang the image: clamp so that the (unused) reads stay inside it
-    in[i] = s[(ptrdiff_t)min(max(gy, 0), height - 1) * vstep_src + min(max(gx, 0), width - 1)];
+  constexpr int DW = G_PW / 4;                       // 34 dwords per staged row: columns x0-4 .. x0+131
+  const bool interior = x0 >= 4 && x0 + G_TW + 4 <= width && (((uintptr_t)s) & 3) == 0 && (vstep_src & 3) == 0;
+  for (int i = threadIdx.x; i < (G_TH + 4) * DW; i += 256) {
+    const int r = i / DW, q = i - r * DW;
+    const int gy = min(max(reflect101(y0 - 2 + r, height), 0), height - 1);
+    const uint8_t *row = s + (ptrdiff_t)gy * vstep_src;
+    uint32_t w;
+    if (interior) {
+      w = *(const uint32_t *)(row + x0 - 4 + 4 * q);
+    } else {
+      w = 0;
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const int gx = min(max(reflect101(x0 - 4 + 4 * q + k, width), 0), width - 1);
+        w |= (uint32_t)row[gx] << (8 * k);
+      }
+    }
+    in[i] = w;
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < G_TH * (G_TW + 4); i += 256) {
-    const int r = i / (G_TW + 4), c = i - r * (G_TW + 4);
-    const uint8_t *p = in + r * (G_TW + 4) + c;
-    mid[i] = (uint8_t)tap5(p[0], p[G_TW + 4], p[2 * (G_TW + 4)], p[3 * (G_TW + 4)], p[4 * (G_TW + 4)]);
+  for (int i = threadIdx.x; i < G_TH * DW; i += 256) {
+    const int r = i / DW, q = i - r * DW;
+    const uint32_t *p = in + r * DW + q;
+    mid[i] = tap5x4(p[0], p[DW], p[2 * DW], p[3 * DW], p[4 * DW]);
   }
   __syncthreads();
-  // horizontal pass: the reference reflects the VERTICAL RESULT at the left/right image border
-  // (GaussianTest.cpp:189-213); the halo columns of `mid` hold exactly those reflected columns
-  // because reflection commutes with the column-wise vertical pass.
+  // horizontal pass on the vertical result; the staged halo columns already hold the reflected
+  // columns (reflection commutes with the column-wise vertical pass), GaussianTest.cpp:189-213
   for (int i = threadIdx.x; i < G_TH * (G_TW / 4); i += 256) {
     const int r = i / (G_TW / 4), q = i - r * (G_TW / 4);
     const int gy = y0 + r, gx = x0 + 4 * q;
     if (gy >= height || gx >= width) continue;
-    const uint8_t *p = mid + r * (G_TW + 4) + 4 * q;
-    uint32_t o[4];
-#pragma unroll
-    for (int k = 0; k < 4; k++) o[k] = tap5(p[k], p[k + 1], p[k + 2], p[k + 3], p[k + 4]);
+    const uint32_t *p = mid + r * DW + q + 1;          // dword holding columns gx .. gx+3
+    const uint32_t wl = p[-1], wc = p[0], wr = p[1];
+    const uint32_t o = tap5x4(__builtin_amdgcn_alignbyte(wc, wl, 2), __builtin_amdgcn_alignbyte(wc, wl, 3), wc,
+                              __builtin_amdgcn_alignbyte(wr, wc, 1), __builtin_amdgcn_alignbyte(wr, wc, 2));
     uint8_t *out = d + (ptrdiff_t)gy * vstep_dst + gx;
     if (gx + 4 <= width && (((uintptr_t)out) & 3) == 0) {
-      *(uint32_t *)out = o[0] | (o[1] << 8) | (o[2] << 16) | (o[3] << 24);
+      *(uint32_t *)out = o;
     } else {
-      for (int k = 0; k < 4 && gx + k < width; k++) out[k] = (uint8_t)o[k];
+      for (int k = 0; k < 4 && gx + k < width; k++) out[k] = (uint8_t)(o >> (8 * k));
     }
   }
 }
@@ -111,8 +135,9 @@ __global__ __launch_bounds__(256) void k_bilinear4(const uint8_t *__restrict__ s
   constexpr int F13[13] = {226, 167, 108, 49, 246, 187, 128, 69, 10, 207, 138, 89, 30};
   const int nbx = (width + N - 1) / N, nby = (height + N - 1) / N;
   const int nq = (nbx + 3) / 4, oh = nby * M;
-  const int q = blockIdx.x * 64 + (threadIdx.x & 63), oy = blockIdx.y * 4 + (threadIdx.x >> 6);
-  if (q >= nq || oy >= oh) return;
+  const int t = blockIdx.x * 256 + threadIdx.x;       // flattened (output row, block group): no idle lanes
+  const int oy = t / nq, q = t - oy * nq;
+  if (oy >= oh) return;
   const int by = oy / M, y = oy - by * M;
   const int sy = (M == 7) ? y : y + (y > 3) + (y > 8);
   int fy0 = 0, fy1 = 0;
