@@ -432,3 +432,42 @@ def test_fused_unaligned_vstep(gpu_ctx, orc):
         exp = np.concatenate(exp)
         assert c[b] == len(exp) and (k[b, :len(exp)] == exp).all()
         assert (d[b, :len(exp)] == orc.orb_compute(pyr[b], exp)).all()
+
+
+@pytest.mark.parametrize("buckets", [0, 1])
+def test_cpp_dropin_readme_loop_runs_on_gpu(tmp_path, demo, buckets):
+    """The reference README.md:59-82 loop as a C++ program against include/pislam/*.h + libpislam_hip.so
+    (no Python, no torch in the process): outputs equal the reference's recorded results."""
+    import os
+    import subprocess
+    import torch
+    from conftest import ROOT
+    from pislam_amd import build
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    lib = build.build()
+    exe = tmp_path / "readme_loop"
+    r = subprocess.run(["g++", "-std=c++11", "-O1", "-I", os.path.join(ROOT, "include"),
+                        os.path.join(ROOT, "tests", "cpp", "readme_loop.cpp"), "-o", str(exe),
+                        "-L", os.path.dirname(lib), "-lpislam_hip", "-Wl,-rpath," + os.path.dirname(lib), "-lpthread"],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    raw = tmp_path / "pyr.raw"
+    demo["img"].tofile(raw)
+    outp = tmp_path / "out.bin"
+    r = subprocess.run([str(exe), str(raw), str(outp), str(buckets)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, (r.stdout, r.stderr)
+    b = np.fromfile(outp, np.uint32)
+    n, m = int(b[0]), int(b[1])
+    kp, desc = b[2:2 + n], b[2 + n:2 + n + m]
+    if buckets:
+        assert n == 1315 and sha16(kp) == SURVEY_PINS["kp_bucket43"]
+    else:
+        assert n == 1754 and sha16(kp) == SURVEY_PINS["kp"] and sha16(desc) == SURVEY_PINS["desc"]
+        rest = b[2 + n + m:]
+        nc = int(rest[0])
+        cen = rest[1:1 + nc].view(np.int32)
+        assert sha16(cen) == SURVEY_PINS["centroids"]
+        tail = rest[1 + nc:].tobytes()
+        na = int(np.frombuffer(tail[:4], np.uint32)[0])
+        assert sha16(np.frombuffer(tail[4:4 + na], np.uint8)) == SURVEY_PINS["angles"]
