@@ -46,12 +46,15 @@ template <class P>
 __device__ __forceinline__ bool fast9(const P *c, int pitch, int thr) {
   const int v = c[0];
   const int lo = v - thr, hi = v + thr;
+  // The sign bit of (p - lo) / (hi - p) IS the dark / bright flag; v_alignbit_b32 shifts it into the
+  // mask in one instruction ({mask, diff} >> 31).  Positions enter in ring order, so the 16-bit
+  // circular mask is a rotation/reflection-free image of the ring (bit 15-k = position k).
   uint32_t dm = 0, bm = 0;
-#define PISLAM_F(k, dy, dx)                            \
-  {                                                    \
-    const int p = c[(dy) * pitch + (dx)];              \
-    dm |= (uint32_t)(p < lo) << (k);                   \
-    bm |= (uint32_t)(p > hi) << (k);                   \
+#define PISLAM_F(k, dy, dx)                                                  \
+  {                                                                          \
+    const int p = c[(dy) * pitch + (dx)];                                    \
+    dm = __builtin_amdgcn_alignbit(dm, (uint32_t)(p - lo), 31);              \
+    bm = __builtin_amdgcn_alignbit(bm, (uint32_t)(hi - p), 31);              \
   }
   PISLAM_RING16(PISLAM_F)
 #undef PISLAM_F
