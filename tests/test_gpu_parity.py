@@ -471,3 +471,40 @@ def test_cpp_dropin_readme_loop_runs_on_gpu(tmp_path, demo, buckets):
         tail = rest[1 + nc:].tobytes()
         na = int(np.frombuffer(tail[:4], np.uint32)[0])
         assert sha16(np.frombuffer(tail[4:4 + na], np.uint8)) == SURVEY_PINS["angles"]
+
+
+def test_batch_call_is_hipgraph_capturable(gpu_ctx, orc):
+    """After pislam_frontend_reserve the batch call allocates nothing and never synchronises, so it can be
+    captured into a hipGraph (torch.cuda.CUDAGraph) and replayed; replays give identical results."""
+    import torch
+    from pislam_amd import synth
+    from pislam_amd.capi import Context
+    from pislam_amd.frontend import OrbFrontend
+    levels = synth.level_table()
+    pyr = synth.make_batch(40, 4)
+    dev = torch.device("cuda:0")
+    d_pyr = torch.from_numpy(pyr).to(dev)
+    side = torch.cuda.Stream(dev)
+    with torch.cuda.stream(side):
+        ctx = Context(device=0, stream=side.cuda_stream)
+        fe = OrbFrontend(levels, vstep=640, rows=2210, max_keypoints=4096, ctx=ctx)
+        fe.reserve(4)
+        kp, desc, counts = fe.alloc_outputs(4, dev)
+        fe(d_pyr, kp, desc, counts)                     # warm-up outside the capture (module load, option checks)
+        side.synchronize()
+        ref = tuple(t.clone() for t in (kp, desc, counts))
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=side):
+            fe(d_pyr, kp, desc, counts)
+        for t in (kp, desc, counts):
+            t.zero_()
+        g.replay()
+        side.synchronize()
+        for a, b in zip(ref, (kp, desc, counts)):
+            assert torch.equal(a, b)
+        d_pyr.copy_(torch.from_numpy(synth.make_batch(60, 4)).to(dev))   # new input, same graph
+        g.replay()
+        side.synchronize()
+    c = counts.cpu().numpy().view(np.uint32)
+    okp, odesc, _ = orc.pyramid(synth.make_pyramid(61), levels)
+    assert c[1] == len(okp) and (kp.cpu().numpy().view(np.uint32)[1, :len(okp)] == okp).all()
