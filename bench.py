@@ -56,6 +56,9 @@ def main():
                     help="distinct synthetic pyramids generated per GPU (0 = all of the batch)")
     ap.add_argument("--max-keypoints", type=int, default=4096)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dist-backend", default=None,
+                    help="override the torch.distributed backend (default nccl = RCCL); 'gloo' lets the N>1 code "
+                         "path be exercised with several ranks sharing one GPU (testing only)")
     ap.add_argument("--workload", default="vga", choices=["vga", "1280x960", "720p-build"],
                     help="vga = BASELINE configs[1] (default, the headline); 1280x960 = configs[3] (packed layout, "
                          "vstep 1280); 720p-build = configs[4] (gaussian5x5 + bilinear pyramid build on the GPU inside "
@@ -72,7 +75,9 @@ def main():
     from pislam_amd.frontend import OrbFrontend
     from pislam_amd.capi import Context
 
-    rank, local_rank, world = pdist.init()
+    rank, local_rank, world = pdist.init(backend=args.dist_backend)
+    if args.dist_backend == "gloo":
+        local_rank = local_rank % max(1, torch.cuda.device_count())   # ranks may share a GPU in this test mode
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU fallback)"

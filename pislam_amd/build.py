@@ -32,14 +32,28 @@ def _stale() -> bool:
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
-    """Compile the HIP library if missing or older than its sources; returns its path."""
+    """Compile the HIP library if missing or older than its sources; returns its path.
+
+    Safe under concurrent callers (one process per GPU under torchrun): an exclusive file lock
+    serialises builders, the compiler writes to a temporary name and the result is renamed into
+    place atomically, and late arrivals re-check staleness after taking the lock."""
     if not force and not _stale():
         return LIB
+    import fcntl
     os.makedirs(LIBDIR, exist_ok=True)
-    cmd = [hipcc()] + FLAGS + ["-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
+    with open(os.path.join(LIBDIR, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not force and not _stale():
+                return LIB
+            tmp = LIB + f".tmp{os.getpid()}"
+            cmd = [hipcc()] + FLAGS + ["-o", tmp] + [os.path.join(CSRC, s) for s in SOURCES]
+            if verbose:
+                print(" ".join(cmd))
+            subprocess.check_call(cmd)
+            os.replace(tmp, LIB)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
     return LIB
 
 
