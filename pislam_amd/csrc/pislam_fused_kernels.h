@@ -38,7 +38,7 @@ constexpr int MAX_LEVELS = 16;
 constexpr int WAVES = 4;               // waves per strip workgroup
 constexpr int NT = WAVES * 64;         // threads per strip workgroup
 constexpr int QCAP_G = 128;            // 4-pixel groups that passed the SAD prefilter (< 64 before a <= 64 push)
-constexpr int QCAP_F = 320;            // FAST candidates (< 64 before a <= 256 push)
+constexpr int QCAP_F = 192;            // FAST candidates (< 64 before a <= 128 half-push)
 constexpr int QCAP = QCAP_G + QCAP_F;  // dwords of private queue space per wave
 constexpr int QH_SHARED = 512;         // workgroup-shared queue of corners awaiting their Harris score
 constexpr int QN_SHARED = 512;         // workgroup-shared queue of pixels with a non-zero score (NMS candidates)
@@ -240,15 +240,25 @@ __device__ __forceinline__ void strip_body(const StripArgs A, const FusedLevel L
     if (__ballot((fe | fo) != 0) == 0) return;
     const uint64_t m0 = __ballot((fe & 0x8000u) != 0), m1 = __ballot((fo & 0x8000u) != 0);
     const uint64_t m2 = __ballot((int32_t)fe < 0), m3 = __ballot((int32_t)fo < 0);
-    lds_u32 *q = qf + nf;
-    if (fe & 0x8000u) q[ballot_rank(m0)] = key;
-    q += __popcll(m0);
-    if (fo & 0x8000u) q[ballot_rank(m1)] = key + 1;
-    q += __popcll(m1);
-    if ((int32_t)fe < 0) q[ballot_rank(m2)] = key + 2;
-    q += __popcll(m2);
-    if ((int32_t)fo < 0) q[ballot_rank(m3)] = key + 3;
-    nf += __popcll(m0) + __popcll(m1) + __popcll(m2) + __popcll(m3);
+    // two half-pushes (<= 128 each) with a pop in between keep the queue below 64 + 128 entries
+    {
+      lds_u32 *q = qf + nf;
+      if (fe & 0x8000u) q[ballot_rank(m0)] = key;
+      q += __popcll(m0);
+      if (fo & 0x8000u) q[ballot_rank(m1)] = key + 1;
+      nf += __popcll(m0) + __popcll(m1);
+    }
+    while (nf >= 64) {
+      nf -= 64;
+      if (!(ablate & 2)) fast_batch(true, qf[nf + lane]);
+    }
+    {
+      lds_u32 *q = qf + nf;
+      if ((int32_t)fe < 0) q[ballot_rank(m2)] = key + 2;
+      q += __popcll(m2);
+      if ((int32_t)fo < 0) q[ballot_rank(m3)] = key + 3;
+      nf += __popcll(m2) + __popcll(m3);
+    }
     while (nf >= 64) {
       nf -= 64;
       if (!(ablate & 2)) fast_batch(true, qf[nf + lane]);
@@ -303,6 +313,8 @@ __device__ __forceinline__ void strip_body(const StripArgs A, const FusedLevel L
   }
 
   if (ablate & 8) return;
+  if ((ablate & 512) && tid == 0) sh_ctr[3] = 1;    // test hook: force the scan fallbacks
+  if (ablate & 512) __syncthreads();
   // ---- phase D (queue-driven): 2x2-block NMS only where a non-zero score exists ---------------
   // Each queued pixel evaluates the block it lies in (Fast.h:228-312) and emits it iff it is the
   // block's winner, so several corners in one block yield exactly one keypoint.  Survivors are

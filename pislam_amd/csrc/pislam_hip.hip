@@ -93,6 +93,7 @@ struct pislam_ctx {
   int opt_strip_rows = 0;    // fused pipeline: strip height override (0 = heuristic)
   int opt_ablate = 0;        // profiling only: skip phases of the fused kernel (results invalid)
   int opt_orb_chunks = 0;    // fused pipeline: workgroups per pyramid in k_gather_orb (0 = heuristic)
+  int opt_wgs_per_cu = 0;    // fused pipeline: if > 0, size strip heights for this many workgroups per CU
   int last_pipeline = 0;
   size_t score_bytes_valid = 0;   // bytes of w_score known to be in a consistent (zero-border) state
   pislam_frontend_params last_params{};
@@ -385,6 +386,9 @@ PISLAM_EXPORT int pislam_ctx_set_option(pislam_ctx *c, const char *key, int valu
     c->opt_pipeline = value;
   } else if (!strcmp(key, "dump_score")) {
     c->opt_dump_score = value != 0;
+  } else if (!strcmp(key, "wgs_per_cu")) {
+    if (value < 0 || value > 8) return fail(c, PISLAM_ERR_INVALID, "wgs_per_cu must be 0..8");
+    c->opt_wgs_per_cu = value;
   } else if (!strcmp(key, "orb_chunks")) {
     if (value < 0 || value > 1024) return fail(c, PISLAM_ERR_INVALID, "orb_chunks must be 0..1024");
     c->opt_orb_chunks = value;
@@ -850,9 +854,18 @@ bool build_fused_plan(const pislam_ctx *c, const pislam_frontend_params *p, cons
       L.pitch = 16;
       continue;
     }
+    const int xend_l = p->border + 16 * cdiv(nx, 16), pitch_l = (xend_l + 4 + 15) & ~15;
+    const size_t qbytes = (pf::WAVES * pf::QCAP + pf::SHARED_Q) * sizeof(uint32_t);
     int R = c->opt_strip_rows;
-    if (R == 0) {
-      R = (8192 / L.w) & ~1;
+    if (R == 0 && c->opt_wgs_per_cu > 0) {
+      // LDS-budget mode (option "wgs_per_cu"): the largest even R <= 32 whose tiles + queues fit
+      // 160 KiB / wgs_per_cu.  Measured slower than the pixel-budget heuristic below (more halo rows
+      // on the wide levels outweigh the extra resident workgroup), so it is not the default.
+      const size_t budget = (size_t)(160 * 1024) / (size_t)c->opt_wgs_per_cu - qbytes;
+      R = (int)((budget / pitch_l - 13) / 2) & ~1;
+      R = std::min(32, std::max(8, R));
+    } else if (R == 0) {
+      R = (8192 / L.w) & ~1;             // ~8k pixels per strip
       R = std::min(32, std::max(16, R));
     }
     if (p->log_bucket_size) {            // strips hold whole bucket rows
@@ -887,10 +900,10 @@ int run_fused(pislam_ctx *c, const pislam_frontend_params *p, const pf::FusedPar
   const dim3 grid((unsigned)(groups * F.strips_per_pyr * 8));
   uint8_t *dump = F.dump_score ? c->w_score.as<uint8_t>() : nullptr;
   const size_t dump_stride = (size_t)p->rows * p->vstep;
-  // persistent variant: needs 16-byte rows, R >= 16 (halo move without overlap) and R * pitch/16 <= 3 * NT
+  // persistent variant: needs 16-byte rows, R >= 10 (halo move without overlap) and R * pitch/16 <= 3 * NT
   bool persistent = vec && c->opt_pipeline == 3;
   for (int l = 0; l < F.nlevels && persistent; l++)
-    if (F.lv[l].nstrips && (F.lv[l].R < 16 || F.lv[l].R * (F.lv[l].pitch / 16) > pf::PF_VEC * pf::NT)) persistent = false;
+    if (F.lv[l].nstrips && (F.lv[l].R < 10 || F.lv[l].R * (F.lv[l].pitch / 16) > pf::PF_VEC * pf::NT)) persistent = false;
   if (c->opt_pipeline == 3 && !persistent)
     return fail(c, PISLAM_ERR_INVALID, "persistent pipeline unavailable for this layout (alignment / strip size)");
   if (persistent) {
