@@ -93,6 +93,7 @@ struct pislam_ctx {
   int opt_strip_rows = 0;    // fused pipeline: strip height override (0 = heuristic)
   int opt_ablate = 0;        // profiling only: skip phases of the fused kernel (results invalid)
   int opt_orb_chunks = 0;    // fused pipeline: workgroups per pyramid in k_gather_orb (0 = heuristic)
+  int opt_lds_pad = 0;       // profiling only: extra dynamic LDS bytes per strip workgroup
   int opt_wgs_per_cu = 0;    // fused pipeline: if > 0, size strip heights for this many workgroups per CU
   int last_pipeline = 0;
   size_t score_bytes_valid = 0;   // bytes of w_score known to be in a consistent (zero-border) state
@@ -386,6 +387,8 @@ PISLAM_EXPORT int pislam_ctx_set_option(pislam_ctx *c, const char *key, int valu
     c->opt_pipeline = value;
   } else if (!strcmp(key, "dump_score")) {
     c->opt_dump_score = value != 0;
+  } else if (!strcmp(key, "lds_pad")) {
+    c->opt_lds_pad = value < 0 ? 0 : value;
   } else if (!strcmp(key, "wgs_per_cu")) {
     if (value < 0 || value > 8) return fail(c, PISLAM_ERR_INVALID, "wgs_per_cu must be 0..8");
     c->opt_wgs_per_cu = value;
@@ -857,16 +860,16 @@ bool build_fused_plan(const pislam_ctx *c, const pislam_frontend_params *p, cons
     const int xend_l = p->border + 16 * cdiv(nx, 16), pitch_l = (xend_l + 4 + 15) & ~15;
     const size_t qbytes = (pf::WAVES * pf::QCAP + pf::SHARED_Q) * sizeof(uint32_t);
     int R = c->opt_strip_rows;
-    if (R == 0 && c->opt_wgs_per_cu > 0) {
-      // LDS-budget mode (option "wgs_per_cu"): the largest even R <= 32 whose tiles + queues fit
-      // 160 KiB / wgs_per_cu.  Measured slower than the pixel-budget heuristic below (more halo rows
-      // on the wide levels outweigh the extra resident workgroup), so it is not the default.
-      const size_t budget = (size_t)(160 * 1024) / (size_t)c->opt_wgs_per_cu - qbytes;
-      R = (int)((budget / pitch_l - 13) / 2) & ~1;
-      R = std::min(32, std::max(8, R));
-    } else if (R == 0) {
-      R = (8192 / L.w) & ~1;             // ~8k pixels per strip
+    if (R == 0) {
+      R = (8192 / L.w) & ~1;             // ~8k pixels per strip ...
       R = std::min(32, std::max(16, R));
+      if (c->opt_wgs_per_cu > 0) {       // ... capped so that tiles + queues fit 160 KiB / wgs_per_cu
+        const size_t budget = (size_t)(160 * 1024) / (size_t)c->opt_wgs_per_cu;
+        if (budget > qbytes + 13 * (size_t)pitch_l) {
+          const int rcap = (int)(((budget - qbytes) / pitch_l - 13) / 2) & ~1;
+          R = std::max(8, std::min(R, rcap));
+        }
+      }
     }
     if (p->log_bucket_size) {            // strips hold whole bucket rows
       const int bs = 1 << p->log_bucket_size;
@@ -884,7 +887,7 @@ bool build_fused_plan(const pislam_ctx *c, const pislam_frontend_params *p, cons
   }
   F->strips_per_pyr = strips;
   F->slots_per_pyr = slots;
-  *lds_bytes = lds;
+  *lds_bytes = lds + (size_t)c->opt_lds_pad;     // profiling: opt_lds_pad lowers the residency artificially
   return strips > 0 && lds <= 150 * 1024;
 }
 
