@@ -54,8 +54,11 @@ struct FusedLevel {
   int slot0;         // staging slot (in keypoints) of the level's first strip
   int nbx;           // 2x2 blocks per block-row
   int xend;          // one past the last classified column (Fast.h:61,149)
-  int pitch;         // LDS tile pitch in bytes (multiple of 16)
-  uint32_t vpr_recip; // ceil(2^32 / (pitch/16)): row = umulhi(i, vpr_recip) for i < 2^16
+  int pitch;         // LDS SCORE tile pitch in bytes (multiple of 16): the score tile spans the full level width
+  int ntx;           // x-tiles the IMAGE tile is cut into (the image is staged ntx times, tcols classified columns each)
+  int tcols;         // classified columns per x-tile (multiple of 16)
+  int tpitch;        // LDS IMAGE tile pitch in bytes (multiple of 16) = tcols + halo
+  uint32_t vpr_recip; // ceil(2^32 / (tpitch/16)): row = umulhi(i, vpr_recip) for i < 2^16
 };
 
 struct FusedParams {
@@ -104,11 +107,11 @@ __device__ __forceinline__ void pretest_pk(uint32_t c, uint32_t u, uint32_t d, u
 
 // Rare path (shared corner queue full): score the flagged lanes right away.  Kept out of line so
 // that the hot loops of the kernel do not carry a second inlined copy of the Harris arithmetic.
-__device__ __attribute__((noinline)) void harris_overflow(lds_u8 *tile, lds_u8 *sc, int pitch, int32_t hthr,
+__device__ __attribute__((noinline)) void harris_overflow(lds_u8 *tile, lds_u8 *sc, int tpitch, int pitch, int32_t hthr,
                                                           bool valid, uint32_t e) {
   if (valid) {
     const int x = e & 0xffff, r = e >> 16;
-    sc[r * pitch + x] = harris_score_pk(tile + r * pitch + x - 3, pitch, hthr);
+    sc[r * pitch + x] = harris_score_pk(tile + r * tpitch + x - 3, tpitch, hthr);
   }
 }
 
@@ -119,18 +122,29 @@ struct StripArgs {
   int32_t hthr;
 };
 
-// Everything after the image tile is staged and the score tile zeroed: phases A0 .. D of one strip.
-// `sh_ctr` (8 dwords of LDS, [1] = QH_SHARED, others 0) must be initialised and a barrier passed.
-// Shared by the one-strip-per-workgroup kernel and the persistent kernel.
+// All phases of one strip.  The SCORE tile covers the full level width; the IMAGE tile is staged in
+// L.ntx x-tiles of L.tcols classified columns (+ halo), one after the other, so that the workgroup's
+// LDS footprint — and with it the number of resident workgroups, to which this instruction-issue
+// bound kernel is measurably sensitive — does not grow with the level width.  Per x-tile: stage,
+// prefilter / pretest / FAST (scores of over-classified columns and corner queue), Harris for the
+// tile's corners.  NMS runs once per strip on the full-width score tile.
+template <bool VEC16>
 __device__ __forceinline__ void strip_body(const StripArgs A, const FusedLevel L, const int pyr, const int s,
-                                           const int ys, const int ye, lds_u8 *tile, lds_u8 *sc, lds_u32 *queues,
-                                           uint32_t *sh_ctr, uint32_t *__restrict__ stage_kp,
+                                           const int ys, const int ye, lds_u8 *tile0, lds_u8 *sc, lds_u32 *queues,
+                                           uint32_t *sh_ctr, const uint8_t *__restrict__ im, const ptrdiff_t lim,
+                                           uint32_t *__restrict__ stage_kp,
                                            uint32_t *__restrict__ strip_count, uint8_t *__restrict__ score_dump,
                                            size_t score_stride) {
   const int B = A.border;
-  const int pitch = L.pitch;
+  const int pitch = L.pitch, tpitch = L.tpitch;
   const int tid = threadIdx.x;
-  if (A.ablate & 1) return;
+  lds_u8 *tile = tile0;                             // re-based per x-tile: tile + row*tpitch + x with level column x
+  int cxa = B, cxb = L.xend;                        // classified columns [cxa, cxb) of the current x-tile
+  {                                                 // zero the score tile, reset the counters (once per strip)
+    const int nz = ((L.R + 3) * pitch) >> 4;
+    for (int i = tid; i < nz; i += NT) ((lds_u4 *)sc)[i] = (u32x4)(0u);
+    if (tid < 8) sh_ctr[tid] = tid == 1 ? QH_SHARED : 0;
+  }
   const int lane = lane_id();
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform (keeps loops scalar)
   lds_u32 *qg = queues + wave * QCAP;              // 4-pixel groups for the exact pretest
@@ -171,7 +185,7 @@ __device__ __forceinline__ void strip_body(const StripArgs A, const FusedLevel L
     uint8_t score = 0;
     if (valid) {
       const int x = e & 0xffff, r = e >> 16;
-      score = (ablate & 32) ? (uint8_t)200 : harris_score_pk(tile + r * pitch + x - 3, pitch, hthr);
+      score = (ablate & 32) ? (uint8_t)200 : harris_score_pk(tile + r * tpitch + x - 3, tpitch, hthr);
       sc[r * pitch + x] = score;
     }
     push_nonzero(score != 0, e);
@@ -181,7 +195,7 @@ __device__ __forceinline__ void strip_body(const StripArgs A, const FusedLevel L
     const int x = e & 0xffff, r = e >> 16;
     // (a one-sided test keyed on which compass side fired was measured: 16 % of the candidates fire on
     //  both sides, so nearly every 64-lane batch needed the second pass and it was slower)
-    if (valid) corner = fast9(tile + (r + 3) * pitch + x, pitch, thr);
+    if (valid) corner = fast9(tile + (r + 3) * tpitch + x, tpitch, thr);
     // Fast.h:172: only x < w-B is scored; over-classified columns keep 0xff
     const bool toh = corner && x < Lw - B;
     if (corner && !toh) sc[r * pitch + x] = 0xff;
@@ -199,7 +213,7 @@ __device__ __forceinline__ void strip_body(const StripArgs A, const FusedLevel L
           atomicMin(&sh_ctr[1], (uint32_t)base);
           sh_ctr[3] = 1;                           // their scores are not queued for NMS: scan instead
         }
-        harris_overflow(tile, sc, pitch, hthr, toh, e);
+        harris_overflow(tile, sc, tpitch, pitch, hthr, toh, e);
       }
     }
   };
@@ -207,18 +221,17 @@ __device__ __forceinline__ void strip_body(const StripArgs A, const FusedLevel L
   const int r_lo = (ys - 1 < B) ? 1 : 0;                          // rows above B are never classified
   const int r_hi = min(ye + 2, Lh - B) - (ys - 1);               // exclusive
   const uint32_t t2 = (uint32_t)thr * 0x00010001u;
-  const int xs = B & ~3;                                           // dword-aligned start column
-  const bool aligned4 = ((B | Lxend) & 3) == 0;
+  const bool aligned4 = ((B | Lxend | L.tcols) & 3) == 0;    // x-tile edges fall on dword boundaries
 
   // exact compass pretest of the 4 pixels of one group (x0 % 4 == 0), survivors -> qf
   auto pretest_batch = [&](bool valid, uint32_t key) {
     const int x0 = key & 0xffff, r = key >> 16;
-    const lds_u8 *trow = tile + (r + 3) * pitch;
+    const lds_u8 *trow = tile + (r + 3) * tpitch;
     const uint32_t wc = *(const lds_u32 *)(trow + x0);
     const uint32_t wl = *(const lds_u32 *)(trow + x0 - 4);
     const uint32_t wr = *(const lds_u32 *)(trow + x0 + 4);
-    const uint32_t wu = *(const lds_u32 *)(trow + x0 - 3 * pitch);
-    const uint32_t wd = *(const lds_u32 *)(trow + x0 + 3 * pitch);
+    const uint32_t wu = *(const lds_u32 *)(trow + x0 - 3 * tpitch);
+    const uint32_t wd = *(const lds_u32 *)(trow + x0 + 3 * tpitch);
     // even pixels (x0, x0+2) and odd pixels (x0+1, x0+3), zero-extended to 16 bit by v_perm_b32
     uint32_t be, de, bo, dd;
     pretest_pk(__builtin_amdgcn_perm(0, wc, 0x0c020c00u), __builtin_amdgcn_perm(0, wu, 0x0c020c00u),
@@ -231,11 +244,11 @@ __device__ __forceinline__ void strip_body(const StripArgs A, const FusedLevel L
                __builtin_amdgcn_perm(wr, wc, 0x0c060c04u), t2, bo, dd); // x+3: r.b0, r.b2
     const uint32_t re = be | de, ro = bo | dd;
     uint32_t fe = valid ? re & 0x80008000u : 0u, fo = valid ? ro & 0x80008000u : 0u;
-    if (!aligned4) {                     // generic border: mask the pixels outside [B, xend)
-      if (x0 + 0 < B || x0 + 0 >= Lxend) fe &= ~0x00008000u;
-      if (x0 + 1 < B || x0 + 1 >= Lxend) fo &= ~0x00008000u;
-      if (x0 + 2 < B || x0 + 2 >= Lxend) fe &= ~0x80000000u;
-      if (x0 + 3 < B || x0 + 3 >= Lxend) fo &= ~0x80000000u;
+    if (!aligned4) {                     // generic border: mask the pixels outside this x-tile's [cxa, cxb)
+      if (x0 + 0 < cxa || x0 + 0 >= cxb) fe &= ~0x00008000u;
+      if (x0 + 1 < cxa || x0 + 1 >= cxb) fo &= ~0x00008000u;
+      if (x0 + 2 < cxa || x0 + 2 >= cxb) fe &= ~0x80000000u;
+      if (x0 + 3 < cxa || x0 + 3 >= cxb) fo &= ~0x80000000u;
     }
     if (__ballot((fe | fo) != 0) == 0) return;
     const uint64_t m0 = __ballot((fe & 0x8000u) != 0), m1 = __ballot((fo & 0x8000u) != 0);
@@ -265,44 +278,93 @@ __device__ __forceinline__ void strip_body(const StripArgs A, const FusedLevel L
     }
   };
 
-  // Group prefilter on every 4-pixel group: a pixel can only pass the compass test if one of its
-  // vertical compass points AND one of its horizontal ones differ from it by more than t, so the
-  // byte-wise SADs of the group against the rows 3 above/below and the columns 3 left/right must
-  // exceed t on both axes (v_sad_u8 sums |a-b| over the 4 bytes, an upper bound of each term).
-  for (int r = r_lo + wave; r < r_hi; r += WAVES) {
-    const lds_u8 *trow = tile + (r + 3) * pitch;
-    for (int cx = xs; cx < Lxend; cx += 256) {
-      const int x0 = cx + 4 * lane;
-      // aligned dword reads; lanes past the row end read harmless bytes of the next tile row
-      const uint32_t wc = *(const lds_u32 *)(trow + x0);
-      const uint32_t wl = *(const lds_u32 *)(trow + x0 - 4);
-      const uint32_t wr = *(const lds_u32 *)(trow + x0 + 4);
-      const uint32_t wu = *(const lds_u32 *)(trow + x0 - 3 * pitch);
-      const uint32_t wd = *(const lds_u32 *)(trow + x0 + 3 * pitch);
-      const uint32_t sv = max(__builtin_amdgcn_sad_u8(wu, wc, 0u), __builtin_amdgcn_sad_u8(wd, wc, 0u));
-      const uint32_t sh = max(__builtin_amdgcn_sad_u8(__builtin_amdgcn_alignbyte(wc, wl, 1), wc, 0u),
-                              __builtin_amdgcn_sad_u8(__builtin_amdgcn_alignbyte(wr, wc, 3), wc, 0u));
-      const bool g = (min(sv, sh) > (uint32_t)thr) && (x0 < Lxend);
-      const uint64_t m = __ballot(g);
-      if (m == 0) continue;
-      if (g) qg[ng + ballot_rank(m)] = pack_xy(x0, r);
-      ng += __popcll(m);
-      if (ng >= 64) {
-        ng -= 64;
-        if (!(ablate & 16)) pretest_batch(true, qg[ng + lane]);
+  for (int xt = 0; xt < L.ntx; xt++) {
+    cxa = B + xt * L.tcols;
+    cxb = min(cxa + L.tcols, Lxend);
+    const int xbase = (cxa - 4) & ~15;              // first staged column (16-byte aligned)
+    tile = tile0 - xbase;
+    // ---- stage image rows [ys-4, min(ye+6, h)), columns [xbase, xbase + tpitch) -----------------
+    {
+      const int y_lo = ys - 4;
+      const int nrows = min(ye + 6, Lh) - y_lo;
+      if (VEC16) {
+        const int vpr = tpitch >> 4;                // 16-byte vectors per row
+        for (int i = tid; i < nrows * vpr; i += NT) {
+          const int r = (int)__umulhi((uint32_t)i, L.vpr_recip), v = i - r * vpr;
+          // never read past the pyramid buffer (the last tile can overhang the image row: flat
+          // addressing like the reference, clipped at the end of the buffer)
+          const ptrdiff_t off = (ptrdiff_t)(y_lo + r) * A.vstep + xbase + 16 * v;
+          u32x4 d;
+          if (off + 16 <= lim) {
+            d = *(const u32x4 *)(im + off);
+          } else {
+            uint32_t w4[4] = {0, 0, 0, 0};        // tail of the buffer: byte-wise, zero beyond the end
+#pragma unroll
+            for (int k = 0; k < 16; k++)
+              if (off + k < lim) w4[k >> 2] |= (uint32_t)im[off + k] << (8 * (k & 3));
+            d = (u32x4){w4[0], w4[1], w4[2], w4[3]};
+          }
+          *(lds_u4 *)(tile0 + r * tpitch + 16 * v) = d;
+        }
+      } else {
+        for (int i = tid; i < nrows * tpitch; i += NT) {
+          const int r = i / tpitch, cx = i - r * tpitch;
+          const ptrdiff_t off = (ptrdiff_t)(y_lo + r) * A.vstep + xbase + cx;
+          tile0[r * tpitch + cx] = off < lim ? im[off] : (uint8_t)0;
+        }
       }
     }
+    __syncthreads();
+    if (ablate & 1) continue;
+
+    // Group prefilter on every 4-pixel group: a pixel can only pass the compass test if one of its
+    // vertical compass points AND one of its horizontal ones differ from it by more than t, so the
+    // byte-wise SADs of the group against the rows 3 above/below and the columns 3 left/right must
+    // exceed t on both axes (v_sad_u8 sums |a-b| over the 4 bytes, an upper bound of each term).
+    const int xs = cxa & ~3;                        // dword-aligned start column of this x-tile
+    for (int r = r_lo + wave; r < r_hi; r += WAVES) {
+      const lds_u8 *trow = tile + (r + 3) * tpitch;
+      for (int cx = xs; cx < cxb; cx += 256) {
+        const int x0 = cx + 4 * lane;
+        // aligned dword reads; lanes past the tile's columns read harmless bytes of the next tile row
+        const uint32_t wc = *(const lds_u32 *)(trow + x0);
+        const uint32_t wl = *(const lds_u32 *)(trow + x0 - 4);
+        const uint32_t wr = *(const lds_u32 *)(trow + x0 + 4);
+        const uint32_t wu = *(const lds_u32 *)(trow + x0 - 3 * tpitch);
+        const uint32_t wd = *(const lds_u32 *)(trow + x0 + 3 * tpitch);
+        const uint32_t sv = max(__builtin_amdgcn_sad_u8(wu, wc, 0u), __builtin_amdgcn_sad_u8(wd, wc, 0u));
+        const uint32_t sh = max(__builtin_amdgcn_sad_u8(__builtin_amdgcn_alignbyte(wc, wl, 1), wc, 0u),
+                                __builtin_amdgcn_sad_u8(__builtin_amdgcn_alignbyte(wr, wc, 3), wc, 0u));
+        const bool g = (min(sv, sh) > (uint32_t)thr) && (x0 < cxb);
+        const uint64_t m = __ballot(g);
+        if (m == 0) continue;
+        if (g) qg[ng + ballot_rank(m)] = pack_xy(x0, r);
+        ng += __popcll(m);
+        if (ng >= 64) {
+          ng -= 64;
+          if (!(ablate & 16)) pretest_batch(true, qg[ng + lane]);
+        }
+      }
+    }
+    if (ng > 0 && !(ablate & 16)) pretest_batch(lane < ng, lane < ng ? qg[lane] : pack_xy(xs, r_lo));
+    ng = 0;
+    // left-over candidates (< 64): one partial batch per wave — cheaper than a barrier to merge them
+    if (nf > 0 && !(ablate & 2)) fast_batch(lane < nf, qf[min(lane, nf - 1)]);
+    nf = 0;
+    __syncthreads();
+    {
+      const int th = (int)min(sh_ctr[0], sh_ctr[1]);
+      if (!(ablate & 4))
+        for (int c0 = wave * 64; c0 < th; c0 += WAVES * 64) harris_batch(c0 + lane < th, shq_h[min(c0 + lane, th - 1)]);
+    }
+    __syncthreads();
+    if (tid == 0) {                                 // fresh corner queue for the next x-tile
+      sh_ctr[0] = 0;
+      sh_ctr[1] = QH_SHARED;
+    }
   }
-  if (ng > 0 && !(ablate & 16)) pretest_batch(lane < ng, lane < ng ? qg[lane] : pack_xy(xs, r_lo));
-  // left-over candidates (< 64): one partial batch per wave — cheaper than a barrier to merge them
-  if (nf > 0 && !(ablate & 2)) fast_batch(lane < nf, qf[min(lane, nf - 1)]);
-  __syncthreads();
-  {
-    const int th = (int)min(sh_ctr[0], sh_ctr[1]);
-    if (!(ablate & 4))
-      for (int c0 = wave * 64; c0 < th; c0 += WAVES * 64) harris_batch(c0 + lane < th, shq_h[min(c0 + lane, th - 1)]);
-  }
-  __syncthreads();
+  if (ablate & 1) return;
+  tile = tile0;
 
   if (A.dump_score) {   // debug / parity hook: rows this strip owns, [ys, ye)
     uint8_t *dst = score_dump + (size_t)pyr * score_stride + (size_t)L.row0 * A.vstep + L.col0;
@@ -320,7 +382,7 @@ __device__ __forceinline__ void strip_body(const StripArgs A, const FusedLevel L
   // block's winner, so several corners in one block yield exactly one keypoint.  Survivors are
   // ranked by their block-raster key (count of smaller keys) = the reference's push_back order.
   if (sh_ctr[3] == 0) {
-    lds_u32 *shq_s = (lds_u32 *)tile;              // survivors (packed keypoints); image tile is dead now
+    lds_u32 *shq_s = (lds_u32 *)tile0;             // survivors (packed keypoints); image tile is dead now
     lds_u32 *shq_k = shq_s + QS_SHARED;            // their block-raster keys
     const int tn = (int)sh_ctr[2];
     const int own_rows = ye - ys;                   // owned score rows r = 1 .. own_rows
@@ -423,7 +485,7 @@ __device__ __forceinline__ void strip_body(const StripArgs A, const FusedLevel L
     const int ncy = (ye - ys + bs - 1) / bs;
     const int ncell = ncx * ncy, nblk = hb * hb;
     const int capc = min(limit, nblk);                              // survivors a cell can keep
-    lds_u32 *cellres = (lds_u32 *)tile;                             // ncell x capc  (<= #blocks dwords)
+    lds_u32 *cellres = (lds_u32 *)tile0;                            // ncell x capc  (<= #blocks dwords)
     lds_u32 *cellcnt = cellres + ncell * capc;                      // ncell
     lds_u32 *cand = queues + wave * QCAP;                           // per-wave scratch: nblk <= 256 dwords
     const int xlimc = Lw - B;
@@ -475,7 +537,7 @@ __device__ __forceinline__ void strip_body(const StripArgs A, const FusedLevel L
   const int nbr = (ye - ys + 1) >> 1;               // block rows in this strip
   const int xlim = Lw - B;                         // block origins are x = B, B+2, ... < xlim
   const int nbx = L.nbx;
-  lds_u32 *rowbuf = (lds_u32 *)tile;                // nbr x nbx dwords <= R/2 * w/2 * 4 B < the tile
+  lds_u32 *rowbuf = (lds_u32 *)tile0;               // nbr x nbx dwords <= R/2 * w/2 * 4 B < the tile
   // One lane looks at 4 score columns x 2 rows = two horizontally adjacent 2x2 blocks with two
   // aligned dword reads; an all-zero pair (the overwhelmingly common case) is done (Fast.h:237).
   auto nms_pair = [&](const lds_u8 *srow, int x0, int y, uint32_t &ra, uint32_t &rb) {
@@ -551,6 +613,7 @@ __global__ __launch_bounds__(NT) void k_fused_strips(
     uint32_t *__restrict__ stage_kp, uint32_t *__restrict__ strip_count,
     uint8_t *__restrict__ score_dump, size_t score_stride) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  __shared__ uint32_t sh_ctr[8];
   // XCD-aware mapping: workgroup b runs on XCD b%8; keep all strips of one pyramid on one XCD so
   // the halo rows shared by neighbouring strips are served by that XCD's L2.
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
@@ -564,163 +627,16 @@ __global__ __launch_bounds__(NT) void k_fused_strips(
   const int B = P.border;
   const int ys = B + s * L.R;                       // first block-row y of the strip
   const int ye = min(ys + L.R, L.h - B);            // one past the last row owned
-  const int pitch = L.pitch;
-  const int trows = L.R + 10;                       // image tile rows  [ys-4, ys+R+6)
-  lds_u8 *tile = (lds_u8 *)smem;
-  lds_u8 *sc = tile + trows * pitch;                // score tile rows  [ys-1, ys+R+2)
-  lds_u32 *queues = (lds_u32 *)(sc + (L.R + 3) * pitch);
-
+  lds_u8 *tile = (lds_u8 *)smem;                    // image tile rows [ys-4, ys+R+6), one x-tile at a time
+  lds_u8 *sc = tile + (L.R + 10) * L.tpitch;        // score tile rows [ys-1, ys+R+2), full width
+  lds_u32 *queues = (lds_u32 *)(sc + (L.R + 3) * L.pitch);
   const uint8_t *im = pyramids + (size_t)pyr * pyr_stride + (size_t)L.row0 * P.vstep + L.col0;
-  const int tid = threadIdx.x;
-  // [0] corners queued, [1] first overflowed corner slot, [2] non-zero scores queued,
-  // [3] set when a queue overflowed -> NMS falls back to scanning the score tile, [4] survivors
-  __shared__ uint32_t sh_ctr[8];
-  if (tid < 8) sh_ctr[tid] = tid == 1 ? QH_SHARED : 0;
-
-  // ---- stage the image rows [ys-4, min(ye+6, h)) and clear the score tile ---------------
-  {
-    const int y_lo = ys - 4;
-    const int nrows = min(ye + 6, L.h) - y_lo;
-    if (VEC16) {
-      const int vpr = pitch >> 4;                   // 16-byte vectors per row
-      // bytes of this pyramid's buffer that may be read (the tile can overhang the last image row
-      // when col0 + pitch > vstep: flat addressing like the reference, but never past the buffer)
-      const ptrdiff_t lim = (ptrdiff_t)P.rows * P.vstep - ((ptrdiff_t)L.row0 * P.vstep + L.col0);
-      for (int i = tid; i < ((P.ablate & 256) ? 0 : nrows * vpr); i += NT) {   // ablate 256: profiling without the HBM read
-        const int r = (int)__umulhi((uint32_t)i, L.vpr_recip), v = i - r * vpr;
-        const ptrdiff_t off = (ptrdiff_t)(y_lo + r) * P.vstep + 16 * v;
-        u32x4 d;
-        if (off + 16 <= lim) {
-          d = *(const u32x4 *)(im + off);
-        } else {
-          uint32_t w4[4] = {0, 0, 0, 0};          // tail of the buffer: byte-wise, zero beyond the end
-#pragma unroll
-          for (int k = 0; k < 16; k++)
-            if (off + k < lim) w4[k >> 2] |= (uint32_t)im[off + k] << (8 * (k & 3));
-          d = (u32x4){w4[0], w4[1], w4[2], w4[3]};
-        }
-        *(lds_u4 *)(tile + r * pitch + 16 * v) = d;
-      }
-    } else {
-      const ptrdiff_t lim = (ptrdiff_t)P.rows * P.vstep - ((ptrdiff_t)L.row0 * P.vstep + L.col0);
-      for (int i = tid; i < nrows * pitch; i += NT) {
-        const int r = i / pitch, cx = i - r * pitch;
-        const ptrdiff_t off = (ptrdiff_t)(y_lo + r) * P.vstep + cx;
-        tile[r * pitch + cx] = off < lim ? im[off] : (uint8_t)0;
-      }
-    }
-    const int nz = ((L.R + 3) * pitch) >> 4;
-    for (int i = tid; i < nz; i += NT) ((lds_u4 *)sc)[i] = (u32x4)(0u);
-  }
-  __syncthreads();
-
-  strip_body(StripArgs{P.border, P.thr, P.ablate, P.dump_score, P.lbs, P.limit, P.vstep, P.slots_per_pyr,
-                       P.strips_per_pyr, P.hthr},
-             L, pyr, s, ys, ye, tile, sc, queues, sh_ctr, stage_kp, strip_count, score_dump, score_stride);
-}
-
-// ===========================================================================
-// k_fused_persistent — the same strip phases, but a workgroup walks DOWN a whole level of one
-// pyramid (work item = (level, pyramid), handed out largest-first by an atomic counter):
-//   * the 10 halo rows at the bottom of a strip's tile are the top rows of the next strip: they are
-//     moved inside LDS instead of being re-read (no halo traffic at all);
-//   * the R new rows of the NEXT strip are loaded into registers BEFORE the current strip is
-//     processed and written to LDS after it (async-stage split): the HBM latency hides under ~10 us
-//     of compute, and there is no per-strip workgroup launch / drain.
-// ===========================================================================
-constexpr int PF_VEC = 3;                            // prefetched 16-byte vectors per thread (R * pitch/16 <= 3 * NT)
-
-__global__ __launch_bounds__(NT) void k_fused_persistent(
-    const FusedParams P, const uint8_t *__restrict__ pyramids, size_t pyr_stride,
-    uint32_t *__restrict__ stage_kp, uint32_t *__restrict__ strip_count,
-    uint8_t *__restrict__ score_dump, size_t score_stride, uint32_t *__restrict__ work_counter) {
-  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-  __shared__ uint32_t sh_ctr[8];
-  __shared__ uint32_t sh_item;
-  const int tid = threadIdx.x;
-  const uint32_t nitems = (uint32_t)P.nlevels * (uint32_t)P.batch;
-  const StripArgs A{P.border, P.thr, P.ablate, P.dump_score, P.lbs, P.limit, P.vstep, P.slots_per_pyr,
-                    P.strips_per_pyr, P.hthr};
-  const int B = P.border;
-  for (;;) {
-    if (tid == 0) sh_item = atomicAdd(work_counter, 1u);
-    __syncthreads();
-    const uint32_t item = sh_item;
-    __syncthreads();
-    if (item >= nitems) break;
-    const int li = (int)(item / (uint32_t)P.batch), pyr = (int)(item - (uint32_t)li * (uint32_t)P.batch);
-    const FusedLevel L = P.lv[li];
-    if (L.nstrips == 0) continue;
-    const int pitch = L.pitch, vpr = pitch >> 4, R = L.R;
-    lds_u8 *tile = (lds_u8 *)smem;
-    lds_u8 *sc = tile + (R + 10) * pitch;
-    lds_u32 *queues = (lds_u32 *)(sc + (R + 3) * pitch);
-    const uint8_t *im = pyramids + (size_t)pyr * pyr_stride + (size_t)L.row0 * P.vstep + L.col0;
-    const ptrdiff_t lim = (ptrdiff_t)P.rows * P.vstep - ((ptrdiff_t)L.row0 * P.vstep + L.col0);
-    auto load_vec = [&](int level_row, int v) {      // 16 bytes of a level row, never past the pyramid buffer
-      const ptrdiff_t off = (ptrdiff_t)level_row * P.vstep + 16 * v;
-      u32x4 d;
-      if (off + 16 <= lim) {
-        d = *(const u32x4 *)(im + off);
-      } else {
-        uint32_t w4[4] = {0, 0, 0, 0};
-#pragma unroll
-        for (int k = 0; k < 16; k++)
-          if (off + k < lim) w4[k >> 2] |= (uint32_t)im[off + k] << (8 * (k & 3));
-        d = (u32x4){w4[0], w4[1], w4[2], w4[3]};
-      }
-      return d;
-    };
-    bool full_stage = true;
-    for (int s = 0; s < L.nstrips; s++) {
-      const int ys = B + s * R, ye = min(ys + R, L.h - B);
-      if (full_stage) {                               // first strip of the item (or after a fallback)
-        const int y_lo = ys - 4, nrows = min(ye + 6, L.h) - y_lo;
-        for (int i = tid; i < nrows * vpr; i += NT) {
-          const int r = (int)__umulhi((uint32_t)i, L.vpr_recip), v = i - r * vpr;
-          *(lds_u4 *)(tile + r * pitch + 16 * v) = load_vec(y_lo + r, v);
-        }
-      }
-      {
-        const int nz = ((R + 3) * pitch) >> 4;
-        for (int i = tid; i < nz; i += NT) ((lds_u4 *)sc)[i] = (u32x4)(0u);
-        if (tid < 8) sh_ctr[tid] = tid == 1 ? QH_SHARED : 0;
-      }
-      // issue the loads of the next strip's new rows [ys+R+6, min(ye'+6, h)) now, use them later
-      u32x4 pf[PF_VEC];
-      int pf_rows = 0;
-      if (s + 1 < L.nstrips) {
-        const int ye_n = min(ys + 2 * R, L.h - B);
-        pf_rows = min(ye_n + 6, L.h) - (ys + R + 6);
-#pragma unroll
-        for (int j = 0; j < PF_VEC; j++) {
-          const int i = tid + NT * j;
-          if (i < pf_rows * vpr) {
-            const int r = (int)__umulhi((uint32_t)i, L.vpr_recip), v = i - r * vpr;
-            pf[j] = load_vec(ys + R + 6 + r, v);
-          }
-        }
-      }
-      __syncthreads();
-      strip_body(A, L, pyr, s, ys, ye, tile, sc, queues, sh_ctr, stage_kp, strip_count, score_dump, score_stride);
-      __syncthreads();
-      full_stage = sh_ctr[6] != 0;
-      if (s + 1 < L.nstrips && !full_stage) {
-        // halo rows [R, R+10) of this tile -> rows [0, 10) of the next one (R >= 16: no overlap)
-        for (int i = tid; i < 10 * vpr; i += NT) *(lds_u4 *)(tile + 16 * i) = *(const lds_u4 *)(tile + R * pitch + 16 * i);
-        __syncthreads();                              // the new rows land on top of the rows just moved
-#pragma unroll
-        for (int j = 0; j < PF_VEC; j++) {
-          const int i = tid + NT * j;
-          if (i < pf_rows * vpr) {
-            const int r = (int)__umulhi((uint32_t)i, L.vpr_recip), v = i - r * vpr;
-            *(lds_u4 *)(tile + (10 + r) * pitch + 16 * v) = pf[j];
-          }
-        }
-      }
-      __syncthreads();
-    }
-  }
+  // bytes of this pyramid's buffer that may be read from the level's origin
+  const ptrdiff_t lim = (ptrdiff_t)P.rows * P.vstep - ((ptrdiff_t)L.row0 * P.vstep + L.col0);
+  strip_body<VEC16>(StripArgs{P.border, P.thr, P.ablate, P.dump_score, P.lbs, P.limit, P.vstep, P.slots_per_pyr,
+                              P.strips_per_pyr, P.hthr},
+                    L, pyr, s, ys, ye, tile, sc, queues, sh_ctr, im, lim, stage_kp, strip_count, score_dump,
+                    score_stride);
 }
 
 // One workgroup per pyramid: exclusive scan of the strip counts in strip order (= level order,

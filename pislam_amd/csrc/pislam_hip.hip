@@ -88,11 +88,12 @@ struct pislam_ctx {
   int num_cus = 0;
   const void *pyr_zeroed = nullptr;   // pyramid buffer whose padding is known to be in its defined state
   size_t pyr_zeroed_sig = 0;
-  int opt_pipeline = 0;      // 0 auto, 1 staged (one launch group per level), 2 fused strips, 3 fused persistent
+  int opt_pipeline = 0;      // 0 auto, 1 staged (one launch group per level), 2 fused strips
   int opt_dump_score = 0;    // fused pipeline: also materialise the score map (parity hook)
   int opt_strip_rows = 0;    // fused pipeline: strip height override (0 = heuristic)
   int opt_ablate = 0;        // profiling only: skip phases of the fused kernel (results invalid)
   int opt_orb_chunks = 0;    // fused pipeline: workgroups per pyramid in k_gather_orb (0 = heuristic)
+  int opt_xtile_cols = 0;    // fused pipeline: max classified columns per image x-tile (0 = full width)
   int opt_lds_pad = 0;       // profiling only: extra dynamic LDS bytes per strip workgroup
   int opt_wgs_per_cu = 0;    // fused pipeline: if > 0, size strip heights for this many workgroups per CU
   int last_pipeline = 0;
@@ -382,11 +383,13 @@ PISLAM_EXPORT int pislam_ctx_set_stream(pislam_ctx *c, void *s) {
 PISLAM_EXPORT int pislam_ctx_set_option(pislam_ctx *c, const char *key, int value) {
   if (!c || !key) return PISLAM_ERR_INVALID;
   if (!strcmp(key, "pipeline")) {
-    if (value < 0 || value > 3)
-      return fail(c, PISLAM_ERR_INVALID, "pipeline must be 0 (auto), 1 (staged), 2 (fused strips) or 3 (fused persistent)");
+    if (value < 0 || value > 2) return fail(c, PISLAM_ERR_INVALID, "pipeline must be 0 (auto), 1 (staged) or 2 (fused)");
     c->opt_pipeline = value;
   } else if (!strcmp(key, "dump_score")) {
     c->opt_dump_score = value != 0;
+  } else if (!strcmp(key, "xtile_cols")) {
+    if (value > 0 && value < 64) return fail(c, PISLAM_ERR_INVALID, "xtile_cols must be 0 (full width), >= 64, or negative (default)");
+    c->opt_xtile_cols = value < 0 ? 0 : value;   // (the default is set in one place: here)
   } else if (!strcmp(key, "lds_pad")) {
     c->opt_lds_pad = value < 0 ? 0 : value;
   } else if (!strcmp(key, "wgs_per_cu")) {
@@ -880,10 +883,21 @@ bool build_fused_plan(const pislam_ctx *c, const pislam_frontend_params *p, cons
     L.nbx = (nx + 1) / 2;
     L.xend = p->border + 16 * cdiv(nx, 16);
     L.pitch = (L.xend + 4 + 15) & ~15;
-    L.vpr_recip = (uint32_t)(((1ull << 32) + (L.pitch / 16) - 1) / (L.pitch / 16));
+    // image x-tiles: at most opt_xtile_cols classified columns each (0 = one full-width tile)
+    const int ncols = L.xend - p->border;
+    L.ntx = c->opt_xtile_cols > 0 ? std::max(1, cdiv(ncols, c->opt_xtile_cols)) : 1;
+    L.tcols = (cdiv(ncols, L.ntx) + 15) & ~15;
+    L.ntx = cdiv(ncols, L.tcols);
+    {
+      // staged columns [xbase, xbase+tpitch) with xbase = (cxa-4) & ~15 must reach column cxb+8
+      const int worst_lead = ((p->border - 4) & 15) + 4;      // cxa - xbase for cxa = border (mod 16)
+      L.tpitch = (L.tcols + worst_lead + 8 + 15) & ~15;
+    }
+    L.vpr_recip = (uint32_t)(((1ull << 32) + (L.tpitch / 16) - 1) / (L.tpitch / 16));
     strips += L.nstrips;
     slots += L.nstrips * (R / 2) * L.nbx;
-    lds = std::max(lds, (size_t)(2 * R + 13) * L.pitch + (pf::WAVES * pf::QCAP + pf::SHARED_Q) * sizeof(uint32_t));
+    lds = std::max(lds, (size_t)(R + 10) * L.tpitch + (size_t)(R + 3) * L.pitch +
+                            (pf::WAVES * pf::QCAP + pf::SHARED_Q) * sizeof(uint32_t));
   }
   F->strips_per_pyr = strips;
   F->slots_per_pyr = slots;
@@ -903,24 +917,7 @@ int run_fused(pislam_ctx *c, const pislam_frontend_params *p, const pf::FusedPar
   const dim3 grid((unsigned)(groups * F.strips_per_pyr * 8));
   uint8_t *dump = F.dump_score ? c->w_score.as<uint8_t>() : nullptr;
   const size_t dump_stride = (size_t)p->rows * p->vstep;
-  // persistent variant: needs 16-byte rows, R >= 10 (halo move without overlap) and R * pitch/16 <= 3 * NT
-  bool persistent = vec && c->opt_pipeline == 3;
-  for (int l = 0; l < F.nlevels && persistent; l++)
-    if (F.lv[l].nstrips && (F.lv[l].R < 10 || F.lv[l].R * (F.lv[l].pitch / 16) > pf::PF_VEC * pf::NT)) persistent = false;
-  if (c->opt_pipeline == 3 && !persistent)
-    return fail(c, PISLAM_ERR_INVALID, "persistent pipeline unavailable for this layout (alignment / strip size)");
-  if (persistent) {
-    if (c->num_cus == 0) HIPCHK(c, hipDeviceGetAttribute(&c->num_cus, hipDeviceAttributeMultiprocessorCount, c->device));
-    if (c->w_work.ensure(sizeof(uint32_t)) != PISLAM_OK) return fail(c, PISLAM_ERR_NOMEM, "hipMalloc(work counter)");
-    HIPCHK(c, hipMemsetAsync(c->w_work.p, 0, sizeof(uint32_t), c->stream));
-    const int per_cu = std::max(1, std::min(8, (int)(160 * 1024 / std::max<size_t>(lds, 1))));
-    const int nwg = std::min(c->num_cus * per_cu, F.nlevels * batch);
-    if (lds > 64 * 1024)
-      HIPCHK(c, hipFuncSetAttribute((const void *)pf::k_fused_persistent, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(pf::k_fused_persistent, dim3(nwg), dim3(pf::NT), lds, c->stream, F, pyramids, stride,
-                       c->w_stage.as<uint32_t>(), c->w_stripcnt.as<uint32_t>(), dump, dump_stride, c->w_work.as<uint32_t>());
-    PCHK(launch_ok(c, "k_fused_persistent"));
-  } else {
+  {
     auto kern = vec ? pf::k_fused_strips<true> : pf::k_fused_strips<false>;
     if (lds > 64 * 1024)
       HIPCHK(c, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -1017,7 +1014,7 @@ PISLAM_EXPORT int pislam_orb_frontend_batch(pislam_ctx *c, const pislam_frontend
   bool fused = c->opt_pipeline != 1 && build_fused_plan(c, p, lv, batch, &F, &lds);
   if (c->opt_pipeline >= 2 && !fused)
     return fail(c, PISLAM_ERR_INVALID, "fused pipeline unavailable for these parameters (bucket size / LDS size)");
-  c->last_pipeline = fused ? 2 : 1;   // (2 also stands for the persistent variant: no HBM score map)
+  c->last_pipeline = fused ? 2 : 1;
   HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
   if (fused) {
     PCHK(run_fused(c, p, F, lds, pyramids, stride, batch, kp, desc, counts));

@@ -47,7 +47,7 @@ def test_four_call_api_on_reference_demo_pyramid(gpu_ctx, orc, demo):
     assert sha16(desc) == SURVEY_PINS["desc"] and (desc == demo["desc"]).all()
 
 
-@pytest.fixture(params=[1, 2, 3], ids=["staged", "fused", "persistent"])
+@pytest.fixture(params=[1, 2], ids=["staged", "fused"])
 def pipeline(request, gpu_ctx):
     """Run the batch tests on both pipelines; the fused one also dumps its LDS score tiles."""
     gpu_ctx.set_option("pipeline", request.param)
@@ -191,9 +191,10 @@ def test_brief_describe_all_rotations(gpu_ctx, orc, demo):
         assert (g[i] == exp).all(), (i, rots[i])
 
 
-@pytest.mark.parametrize("strip_rows", [0, 16, 32, 2, 64])
-def test_fused_strip_heights(gpu_ctx, orc, strip_rows):
-    """The fused pipeline's result must not depend on how levels are cut into strips."""
+@pytest.mark.parametrize("strip_rows,xtile_cols", [(0, 0), (16, 0), (32, 0), (2, 0), (64, 0), (0, 320), (0, 224), (16, 64),
+                                                   (32, 100), (0, 4096)])
+def test_fused_strip_heights(gpu_ctx, orc, strip_rows, xtile_cols):
+    """The fused pipeline's result must not depend on how levels are cut into strips and x-tiles."""
     import torch
     from pislam_amd import synth
     from pislam_amd.frontend import OrbFrontend
@@ -203,6 +204,7 @@ def test_fused_strip_heights(gpu_ctx, orc, strip_rows):
     gpu_ctx.set_option("pipeline", 2)
     gpu_ctx.set_option("dump_score", 1)
     gpu_ctx.set_option("strip_rows", strip_rows)
+    gpu_ctx.set_option("xtile_cols", xtile_cols)
     try:
         fe = OrbFrontend(levels, vstep=640, rows=2210, max_keypoints=4096, ctx=gpu_ctx)
         kp, desc, counts = fe.alloc_outputs(3, dev)
@@ -220,6 +222,7 @@ def test_fused_strip_heights(gpu_ctx, orc, strip_rows):
         gpu_ctx.set_option("pipeline", 0)
         gpu_ctx.set_option("dump_score", 0)
         gpu_ctx.set_option("strip_rows", 0)
+        gpu_ctx.set_option("xtile_cols", -1)
 
 
 def test_fused_odd_shapes_and_unaligned_layouts(gpu_ctx, orc):
