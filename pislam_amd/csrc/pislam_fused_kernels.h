@@ -289,22 +289,43 @@ __device__ __forceinline__ void strip_body(const StripArgs A, const FusedLevel L
       const int nrows = min(ye + 6, Lh) - y_lo;
       if (VEC16) {
         const int vpr = tpitch >> 4;                // 16-byte vectors per row
-        for (int i = tid; i < nrows * vpr; i += NT) {
-          const int r = (int)__umulhi((uint32_t)i, L.vpr_recip), v = i - r * vpr;
-          // never read past the pyramid buffer (the last tile can overhang the image row: flat
-          // addressing like the reference, clipped at the end of the buffer)
-          const ptrdiff_t off = (ptrdiff_t)(y_lo + r) * A.vstep + xbase + 16 * v;
-          u32x4 d;
-          if (off + 16 <= lim) {
-            d = *(const u32x4 *)(im + off);
-          } else {
-            uint32_t w4[4] = {0, 0, 0, 0};        // tail of the buffer: byte-wise, zero beyond the end
-#pragma unroll
-            for (int k = 0; k < 16; k++)
-              if (off + k < lim) w4[k >> 2] |= (uint32_t)im[off + k] << (8 * (k & 3));
-            d = (u32x4){w4[0], w4[1], w4[2], w4[3]};
+        // (row, vector) of this thread's first element, then stepped incrementally: no per-element
+        // division, and the end-of-buffer clipping is only compiled into the (wave-uniform) tail case
+        int r = (int)__umulhi((uint32_t)tid, L.vpr_recip), v = tid - r * vpr;
+        const int dr = NT / vpr, dv = NT - dr * vpr;
+        const uint8_t *src0 = im + (ptrdiff_t)y_lo * A.vstep + xbase;
+        const bool tail = (ptrdiff_t)(y_lo + nrows - 1) * A.vstep + xbase + tpitch > lim;
+        if (!tail) {
+          for (; r < nrows; r += dr) {
+            *(lds_u4 *)(tile0 + r * tpitch + 16 * v) = *(const u32x4 *)(src0 + (ptrdiff_t)r * A.vstep + 16 * v);
+            v += dv;
+            if (v >= vpr) {
+              v -= vpr;
+              r++;
+            }
           }
-          *(lds_u4 *)(tile0 + r * tpitch + 16 * v) = d;
+        } else {
+          for (; r < nrows; r += dr) {
+            // never read past the pyramid buffer (the last tile can overhang the image row: flat
+            // addressing like the reference, clipped at the end of the buffer)
+            const ptrdiff_t off = (ptrdiff_t)(y_lo + r) * A.vstep + xbase + 16 * v;
+            u32x4 d;
+            if (off + 16 <= lim) {
+              d = *(const u32x4 *)(im + off);
+            } else {
+              uint32_t w4[4] = {0, 0, 0, 0};      // byte-wise, zero beyond the end
+#pragma unroll
+              for (int k = 0; k < 16; k++)
+                if (off + k < lim) w4[k >> 2] |= (uint32_t)im[off + k] << (8 * (k & 3));
+              d = (u32x4){w4[0], w4[1], w4[2], w4[3]};
+            }
+            *(lds_u4 *)(tile0 + r * tpitch + 16 * v) = d;
+            v += dv;
+            if (v >= vpr) {
+              v -= vpr;
+              r++;
+            }
+          }
         }
       } else {
         for (int i = tid; i < nrows * tpitch; i += NT) {
