@@ -68,6 +68,7 @@ def main():
     ap.add_argument("--orb-chunks", type=int, default=0)
     ap.add_argument("--wgs-per-cu", type=int, default=0)
     ap.add_argument("--xtile-cols", type=int, default=-1)
+    ap.add_argument("--run-len", type=int, default=0)
     ap.add_argument("--lds-pad", type=int, default=0, help="profiling only: extra LDS per strip workgroup")
     ap.add_argument("--log-bucket-size", type=int, default=0, help="fastExtract logBucketSize (README uses 4)")
     ap.add_argument("--bucket-limit", type=int, default=5, help="fastExtract bucketLimit (README uses 3)")
@@ -107,6 +108,8 @@ def main():
     ctx.set_option("strip_rows", args.strip_rows)
     ctx.set_option("orb_chunks", args.orb_chunks)
     ctx.set_option("lds_pad", args.lds_pad)
+    if args.run_len:
+        ctx.set_option("run_len", args.run_len)
     if args.xtile_cols >= 0:
         ctx.set_option("xtile_cols", args.xtile_cols)
     if args.wgs_per_cu:

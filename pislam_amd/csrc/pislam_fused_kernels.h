@@ -58,11 +58,13 @@ struct FusedLevel {
   int ntx;           // x-tiles the IMAGE tile is cut into (the image is staged ntx times, tcols classified columns each)
   int tcols;         // classified columns per x-tile (multiple of 16)
   int tpitch;        // LDS IMAGE tile pitch in bytes (multiple of 16) = tcols + halo
+  int nruns, run0;   // runs (= workgroups) of this level: run_len consecutive strips each
   uint32_t vpr_recip; // ceil(2^32 / (tpitch/16)): row = umulhi(i, vpr_recip) for i < 2^16
 };
 
 struct FusedParams {
   int nlevels, strips_per_pyr, slots_per_pyr;
+  int runs_per_pyr, run_len;   // a workgroup walks run_len consecutive strips of one level (see k_fused_strips)
   int vstep, rows, border, thr;
   int32_t hthr;
   int batch;
@@ -128,25 +130,53 @@ struct StripArgs {
 // bound kernel is measurably sensitive — does not grow with the level width.  Per x-tile: stage,
 // prefilter / pretest / FAST (scores of over-classified columns and corner queue), Harris for the
 // tile's corners.  NMS runs once per strip on the full-width score tile.
-template <bool VEC16>
+template <bool VEC16, bool HOOKS>
 __device__ __forceinline__ void strip_body(const StripArgs A, const FusedLevel L, const int pyr, const int s,
                                            const int ys, const int ye, lds_u8 *tile0, lds_u8 *sc, lds_u32 *queues,
                                            uint32_t *sh_ctr, const uint8_t *__restrict__ im, const ptrdiff_t lim,
                                            uint32_t *__restrict__ stage_kp,
                                            uint32_t *__restrict__ strip_count, uint8_t *__restrict__ score_dump,
-                                           size_t score_stride) {
+                                           size_t score_stride, const bool carry, const int tid) {
   const int B = A.border;
   const int pitch = L.pitch, tpitch = L.tpitch;
-  const int tid = threadIdx.x;
   lds_u8 *tile = tile0;                             // re-based per x-tile: tile + row*tpitch + x with level column x
   int cxa = B, cxb = L.xend;                        // classified columns [cxa, cxb) of the current x-tile
-  {                                                 // zero the score tile, reset the counters (once per strip)
+  const int lane = tid & 63;                        // (== lane_id() for the 1-D workgroup)
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform (keeps loops scalar)
+  // `carry`: the workgroup has just finished the strip above this one (same level, full height R) and
+  // its tiles are intact.  The image rows [ys-4, ys+6) are that strip's tile rows R..R+9 and the
+  // score rows [ys-1, ys+2) its score rows R..R+2, so they are moved up inside LDS instead of being
+  // staged / classified / scored a second time; the NMS candidates queued for those rows move too.
+  const bool carry_img = carry && L.ntx == 1;
+  if (carry) {
+    const int R = L.R;
+    if (carry_img) {
+      const int nv = (10 * tpitch) >> 4;            // source rows R.. and destination rows 0..9 are disjoint (R >= 10)
+      for (int i = tid; i < nv; i += NT) ((lds_u4 *)tile0)[i] = ((const lds_u4 *)(tile0 + R * tpitch))[i];
+    }
+    const int nvs = (3 * pitch) >> 4;
+    for (int i = tid; i < nvs; i += NT) ((lds_u4 *)sc)[i] = ((const lds_u4 *)(sc + R * pitch))[i];
+    if (wave == 0) {                                // in-place compaction of the candidate queue (front to back)
+      lds_u32 *qn = queues + WAVES * QCAP + QH_SHARED;
+      const int tn = (int)sh_ctr[2];
+      int kept = 0;
+      for (int c0 = 0; c0 < tn; c0 += 64) {
+        const uint32_t e = qn[min(c0 + lane, tn - 1)];
+        const bool k = c0 + lane < tn && (int)(e >> 16) >= R;
+        const uint64_t m = __ballot(k);
+        if (k) qn[kept + ballot_rank(m)] = e - ((uint32_t)R << 16);
+        kept += __popcll(m);
+      }
+      if (lane < 8) sh_ctr[lane] = lane == 1 ? QH_SHARED : lane == 2 ? (uint32_t)kept : 0u;
+    }
+    __syncthreads();
+    const int nz = (L.R * pitch) >> 4;              // fresh score rows 3 .. R+2
+    for (int i = tid; i < nz; i += NT) ((lds_u4 *)(sc + 3 * pitch))[i] = (u32x4)(0u);
+  } else {                                          // zero the score tile, reset the counters
     const int nz = ((L.R + 3) * pitch) >> 4;
     for (int i = tid; i < nz; i += NT) ((lds_u4 *)sc)[i] = (u32x4)(0u);
     if (tid < 8) sh_ctr[tid] = tid == 1 ? QH_SHARED : 0;
   }
-  const int lane = lane_id();
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform (keeps loops scalar)
   lds_u32 *qg = queues + wave * QCAP;              // 4-pixel groups for the exact pretest
   lds_u32 *qf = qg + QCAP_G;                       // FAST candidates
   // Corners are rare (~1 % of the pixels): a private queue per wave would end in a mostly empty
@@ -160,7 +190,9 @@ __device__ __forceinline__ void strip_body(const StripArgs A, const FusedLevel L
   // arguments — capturing `P` itself makes the compiler spill the whole 800-byte struct to scratch.
   const int thr = A.thr;
   const int32_t hthr = A.hthr;
-  const int ablate = A.ablate;
+  // the profiling / debug hooks only exist in the HOOKS instantiation: in the product kernel they
+  // fold away instead of costing a dozen live scalar registers
+  const int ablate = HOOKS ? A.ablate : 0;
   const int Lw = L.w, Lxend = L.xend, Lh = L.h;
   const bool wmod = (Lw & 15) != 0;
 
@@ -218,7 +250,7 @@ __device__ __forceinline__ void strip_body(const StripArgs A, const FusedLevel L
     }
   };
 
-  const int r_lo = (ys - 1 < B) ? 1 : 0;                          // rows above B are never classified
+  const int r_lo = carry ? 3 : (ys - 1 < B) ? 1 : 0;              // rows above B are never classified
   const int r_hi = min(ye + 2, Lh - B) - (ys - 1);               // exclusive
   const uint32_t t2 = (uint32_t)thr * 0x00010001u;
   const bool aligned4 = ((B | Lxend | L.tcols) & 3) == 0;    // x-tile edges fall on dword boundaries
@@ -287,11 +319,14 @@ __device__ __forceinline__ void strip_body(const StripArgs A, const FusedLevel L
     {
       const int y_lo = ys - 4;
       const int nrows = min(ye + 6, Lh) - y_lo;
-      if (VEC16) {
+      const int r_st0 = carry_img ? 10 : 0;         // the first 10 rows were carried over
+      if (carry_img && (ablate & 2048)) {           // profiling only: no global loads on carried strips
+      } else if (VEC16) {
         const int vpr = tpitch >> 4;                // 16-byte vectors per row
         // (row, vector) of this thread's first element, then stepped incrementally: no per-element
         // division, and the end-of-buffer clipping is only compiled into the (wave-uniform) tail case
         int r = (int)__umulhi((uint32_t)tid, L.vpr_recip), v = tid - r * vpr;
+        r += r_st0;
         const int dr = NT / vpr, dv = NT - dr * vpr;
         const uint8_t *src0 = im + (ptrdiff_t)y_lo * A.vstep + xbase;
         const bool tail = (ptrdiff_t)(y_lo + nrows - 1) * A.vstep + xbase + tpitch > lim;
@@ -328,7 +363,7 @@ __device__ __forceinline__ void strip_body(const StripArgs A, const FusedLevel L
           }
         }
       } else {
-        for (int i = tid; i < nrows * tpitch; i += NT) {
+        for (int i = r_st0 * tpitch + tid; i < nrows * tpitch; i += NT) {
           const int r = i / tpitch, cx = i - r * tpitch;
           const ptrdiff_t off = (ptrdiff_t)(y_lo + r) * A.vstep + xbase + cx;
           tile0[r * tpitch + cx] = off < lim ? im[off] : (uint8_t)0;
@@ -387,7 +422,7 @@ __device__ __forceinline__ void strip_body(const StripArgs A, const FusedLevel L
   if (ablate & 1) return;
   tile = tile0;
 
-  if (A.dump_score) {   // debug / parity hook: rows this strip owns, [ys, ye)
+  if (HOOKS && A.dump_score) {   // debug / parity hook: rows this strip owns, [ys, ye)
     uint8_t *dst = score_dump + (size_t)pyr * score_stride + (size_t)L.row0 * A.vstep + L.col0;
     for (int i = tid; i < (ye - ys) * pitch; i += NT) {
       const int r = i / pitch, x = i - r * pitch;
@@ -403,7 +438,8 @@ __device__ __forceinline__ void strip_body(const StripArgs A, const FusedLevel L
   // block's winner, so several corners in one block yield exactly one keypoint.  Survivors are
   // ranked by their block-raster key (count of smaller keys) = the reference's push_back order.
   if (sh_ctr[3] == 0) {
-    lds_u32 *shq_s = (lds_u32 *)tile0;             // survivors (packed keypoints); image tile is dead now
+    lds_u32 *shq_s = queues;                        // survivors (packed keypoints) in the idle per-wave queues
+                                                    // (the tiles stay intact for the next strip of the run)
     lds_u32 *shq_k = shq_s + QS_SHARED;            // their block-raster keys
     const int tn = (int)sh_ctr[2];
     const int own_rows = ye - ys;                   // owned score rows r = 1 .. own_rows
@@ -628,7 +664,7 @@ __device__ __forceinline__ void strip_body(const StripArgs A, const FusedLevel L
   }
 }
 
-template <bool VEC16>
+template <bool VEC16, bool HOOKS>
 __global__ __launch_bounds__(NT) void k_fused_strips(
     const FusedParams P, const uint8_t *__restrict__ pyramids, size_t pyr_stride,
     uint32_t *__restrict__ stage_kp, uint32_t *__restrict__ strip_count,
@@ -636,28 +672,54 @@ __global__ __launch_bounds__(NT) void k_fused_strips(
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   __shared__ uint32_t sh_ctr[8];
   // XCD-aware mapping: workgroup b runs on XCD b%8; keep all strips of one pyramid on one XCD so
-  // the halo rows shared by neighbouring strips are served by that XCD's L2.
+  // the halo rows shared by neighbouring runs are served by that XCD's L2.
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-  const int pyr = (slot / P.strips_per_pyr) * 8 + xcd;
+  // Run-major order: all pyramids' run 0 first, ... the short runs of the small levels last, so the
+  // tail of the grid consists of short workgroups (a run is up to run_len strips long).
+  // (A resident grid pulling runs from per-XCD atomic counters was measured: no gain at any batch.)
+  const int groups = (P.batch + 7) >> 3;
+  const int pyr = (slot % groups) * 8 + xcd;
   if (pyr >= P.batch) return;
-  int s = slot % P.strips_per_pyr;
+  int run = slot / groups;
   int li = 0;
-  while (li + 1 < P.nlevels && s >= P.lv[li + 1].strip0) li++;
-  const FusedLevel L = P.lv[li];
-  s -= L.strip0;
-  const int B = P.border;
-  const int ys = B + s * L.R;                       // first block-row y of the strip
-  const int ye = min(ys + L.R, L.h - B);            // one past the last row owned
-  lds_u8 *tile = (lds_u8 *)smem;                    // image tile rows [ys-4, ys+R+6), one x-tile at a time
-  lds_u8 *sc = tile + (L.R + 10) * L.tpitch;        // score tile rows [ys-1, ys+R+2), full width
-  lds_u32 *queues = (lds_u32 *)(sc + (L.R + 3) * L.pitch);
-  const uint8_t *im = pyramids + (size_t)pyr * pyr_stride + (size_t)L.row0 * P.vstep + L.col0;
-  // bytes of this pyramid's buffer that may be read from the level's origin
-  const ptrdiff_t lim = (ptrdiff_t)P.rows * P.vstep - ((ptrdiff_t)L.row0 * P.vstep + L.col0);
-  strip_body<VEC16>(StripArgs{P.border, P.thr, P.ablate, P.dump_score, P.lbs, P.limit, P.vstep, P.slots_per_pyr,
-                              P.strips_per_pyr, P.hthr},
-                    L, pyr, s, ys, ye, tile, sc, queues, sh_ctr, im, lim, stage_kp, strip_count, score_dump,
-                    score_stride);
+  while (li + 1 < P.nlevels && run >= P.lv[li + 1].run0) li++;
+  run -= P.lv[li].run0;
+  // A workgroup walks a RUN of consecutive strips of one level, top to bottom.  From the second strip
+  // on, the 10 halo image rows and the 3 halo score rows it shares with the strip above are carried
+  // over inside LDS (strip_body `carry`), so a run behaves like one strip of run_len * R rows at the
+  // LDS footprint of R rows: the halo is staged, classified and scored once per run, not per strip.
+  const int s0 = run * P.run_len, s1 = min(s0 + P.run_len, P.lv[li].nstrips);
+  bool carry = false;
+  for (int s = s0; s < s1; s++) {
+    // Opaque copies of the level index, the thread id and the scalar arguments: without them the
+    // compiler hoists every strip-invariant address and constant out of this loop and keeps them live
+    // across the whole strip body (+38 VGPRs, +90 spilled SGPRs measured); recomputing them per
+    // strip costs nothing.
+    int li_o = li, tid_o = (int)threadIdx.x;
+    asm volatile("" : "+s"(li_o));
+    asm volatile("" : "+v"(tid_o));
+    const FusedLevel L = P.lv[li_o];
+    lds_u8 *tile = (lds_u8 *)smem;                  // image tile rows [ys-4, ys+R+6), one x-tile at a time
+    lds_u8 *sc = tile + (L.R + 10) * L.tpitch;      // score tile rows [ys-1, ys+R+2), full width
+    lds_u32 *queues = (lds_u32 *)(sc + (L.R + 3) * L.pitch);
+    const uint8_t *im = pyramids + (size_t)pyr * pyr_stride + (size_t)L.row0 * P.vstep + L.col0;
+    // bytes of this pyramid's buffer that may be read from the level's origin
+    const ptrdiff_t lim = (ptrdiff_t)P.rows * P.vstep - ((ptrdiff_t)L.row0 * P.vstep + L.col0);
+    StripArgs A{P.border, P.thr, P.ablate, P.dump_score, P.lbs, P.limit, P.vstep, P.slots_per_pyr,
+                P.strips_per_pyr, P.hthr};
+    asm volatile("" : "+s"(A.border), "+s"(A.thr), "+s"(A.lbs), "+s"(A.limit), "+s"(A.vstep), "+s"(A.slots_per_pyr),
+                 "+s"(A.strips_per_pyr), "+s"(A.hthr));
+    const int ys = A.border + s * L.R;              // first block-row y of the strip
+    const int ye = min(ys + L.R, L.h - A.border);   // one past the last row owned
+    strip_body<VEC16, HOOKS>(A, L, pyr, s, ys, ye, tile, sc, queues, sh_ctr, im, lim, stage_kp, strip_count,
+                             score_dump, score_stride, carry, tid_o);
+    if (s + 1 < s1) {
+      __syncthreads();                              // every read of this strip's LDS state is done
+      // (a scan fallback scribbles over the tiles: the next strip then starts afresh)
+      carry = sh_ctr[6] == 0 && L.R >= 10 && !(HOOKS && (P.ablate & 1024));
+      __syncthreads();
+    }
+  }
 }
 
 // One workgroup per pyramid: exclusive scan of the strip counts in strip order (= level order,

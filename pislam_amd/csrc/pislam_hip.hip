@@ -93,6 +93,7 @@ struct pislam_ctx {
   int opt_strip_rows = 0;    // fused pipeline: strip height override (0 = heuristic)
   int opt_ablate = 0;        // profiling only: skip phases of the fused kernel (results invalid)
   int opt_orb_chunks = 0;    // fused pipeline: workgroups per pyramid in k_gather_orb (0 = heuristic)
+  int opt_run_len = 0;       // fused pipeline: strips per workgroup run (0 = default, 1 = independent strips)
   int opt_xtile_cols = 0;    // fused pipeline: max classified columns per image x-tile (0 = full width)
   int opt_lds_pad = 0;       // profiling only: extra dynamic LDS bytes per strip workgroup
   int opt_wgs_per_cu = 0;    // fused pipeline: if > 0, size strip heights for this many workgroups per CU
@@ -348,6 +349,8 @@ PISLAM_EXPORT int pislam_ctx_create(int device, pislam_ctx **out) {
   CREATE_CHK(hipSetDevice(device));
   pislam_ctx *c = new pislam_ctx();
   c->device = device;
+  if (hipDeviceGetAttribute(&c->num_cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || c->num_cus <= 0)
+    c->num_cus = 256;
   for (auto &e : c->ev) {
     hipError_t r = hipEventCreate(&e);
     if (r != hipSuccess) {
@@ -390,6 +393,9 @@ PISLAM_EXPORT int pislam_ctx_set_option(pislam_ctx *c, const char *key, int valu
   } else if (!strcmp(key, "xtile_cols")) {
     if (value > 0 && value < 64) return fail(c, PISLAM_ERR_INVALID, "xtile_cols must be 0 (full width), >= 64, or negative (default)");
     c->opt_xtile_cols = value < 0 ? 0 : value;   // (the default is set in one place: here)
+  } else if (!strcmp(key, "run_len")) {
+    if (value < 0 || value > 64) return fail(c, PISLAM_ERR_INVALID, "run_len must be 0 (default) .. 64");
+    c->opt_run_len = value;
   } else if (!strcmp(key, "lds_pad")) {
     c->opt_lds_pad = value < 0 ? 0 : value;
   } else if (!strcmp(key, "wgs_per_cu")) {
@@ -841,7 +847,7 @@ bool build_fused_plan(const pislam_ctx *c, const pislam_frontend_params *p, cons
   // fused bucket mode: cells of 4..32 px (they must fit a strip and the per-wave scratch)
   if (p->log_bucket_size != 0 && (p->log_bucket_size < 2 || p->log_bucket_size > 5)) return false;
   F->ablate = c->opt_ablate;
-  int strips = 0, slots = 0;
+  int strips = 0, slots = 0, runs = 0;
   size_t lds = 0;
   for (int l = 0; l < p->nlevels; l++) {
     pf::FusedLevel &L = F->lv[l];
@@ -899,7 +905,19 @@ bool build_fused_plan(const pislam_ctx *c, const pislam_frontend_params *p, cons
     lds = std::max(lds, (size_t)(R + 10) * L.tpitch + (size_t)(R + 3) * L.pitch +
                             (pf::WAVES * pf::QCAP + pf::SHARED_Q) * sizeof(uint32_t));
   }
+  // Runs: a workgroup walks run_len consecutive strips of a level (halo carried in LDS).  Longer runs
+  // save the duplicated halo work but leave fewer workgroups; keep >= ~3 per resident slot
+  // (4 workgroups x CUs), at most 8 strips per run (batch 256 VGA: 8; batch 32: 1).
+  F->run_len = c->opt_run_len > 0 ? c->opt_run_len
+                                  : (int)std::min<long long>(8, std::max<long long>(1, (long long)strips * batch /
+                                                                                      (12LL * std::max(1, c->num_cus))));
+  for (int l = 0; l < p->nlevels; l++) {
+    F->lv[l].run0 = runs;
+    F->lv[l].nruns = cdiv(F->lv[l].nstrips, F->run_len);
+    runs += F->lv[l].nruns;
+  }
   F->strips_per_pyr = strips;
+  F->runs_per_pyr = runs;
   F->slots_per_pyr = slots;
   *lds_bytes = lds + (size_t)c->opt_lds_pad;     // profiling: opt_lds_pad lowers the residency artificially
   return strips > 0 && lds <= 150 * 1024;
@@ -914,13 +932,16 @@ int run_fused(pislam_ctx *c, const pislam_frontend_params *p, const pf::FusedPar
   bool vec = ((uintptr_t)pyramids % 16 == 0) && (stride % 16 == 0) && (p->vstep % 16 == 0);
   for (int l = 0; l < F.nlevels; l++) vec = vec && (F.lv[l].col0 % 16 == 0);
   const int groups = cdiv(batch, 8);
-  const dim3 grid((unsigned)(groups * F.strips_per_pyr * 8));
   uint8_t *dump = F.dump_score ? c->w_score.as<uint8_t>() : nullptr;
   const size_t dump_stride = (size_t)p->rows * p->vstep;
   {
-    auto kern = vec ? pf::k_fused_strips<true> : pf::k_fused_strips<false>;
+    // HOOKS instantiation: score-map dump (debug / parity hook) and the profiling ablations
+    const bool hooks = F.dump_score || F.ablate;
+    auto kern = vec ? (hooks ? pf::k_fused_strips<true, true> : pf::k_fused_strips<true, false>)
+                    : (hooks ? pf::k_fused_strips<false, true> : pf::k_fused_strips<false, false>);
     if (lds > 64 * 1024)
       HIPCHK(c, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const dim3 grid((unsigned)(groups * F.runs_per_pyr * 8));
     hipLaunchKernelGGL(kern, grid, dim3(pf::NT), lds, c->stream, F, pyramids, stride, c->w_stage.as<uint32_t>(),
                        c->w_stripcnt.as<uint32_t>(), dump, dump_stride);
     PCHK(launch_ok(c, "k_fused_strips"));

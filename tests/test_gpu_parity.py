@@ -191,10 +191,12 @@ def test_brief_describe_all_rotations(gpu_ctx, orc, demo):
         assert (g[i] == exp).all(), (i, rots[i])
 
 
-@pytest.mark.parametrize("strip_rows,xtile_cols", [(0, 0), (16, 0), (32, 0), (2, 0), (64, 0), (0, 320), (0, 224), (16, 64),
-                                                   (32, 100), (0, 4096)])
-def test_fused_strip_heights(gpu_ctx, orc, strip_rows, xtile_cols):
-    """The fused pipeline's result must not depend on how levels are cut into strips and x-tiles."""
+@pytest.mark.parametrize("strip_rows,xtile_cols,run_len",
+                         [(0, 0, 0), (16, 0, 1), (16, 0, 3), (32, 0, 2), (2, 0, 0), (64, 0, 64), (0, 320, 0), (0, 224, 1),
+                          (16, 64, 5), (32, 100, 0), (0, 4096, 0), (10, 0, 64), (12, 0, 7), (8, 0, 4)])
+def test_fused_strip_heights(gpu_ctx, orc, strip_rows, xtile_cols, run_len):
+    """The fused pipeline's result must not depend on how levels are cut into strips, x-tiles and
+    runs of strips (halo rows carried over in LDS between the strips of a run)."""
     import torch
     from pislam_amd import synth
     from pislam_amd.frontend import OrbFrontend
@@ -205,6 +207,7 @@ def test_fused_strip_heights(gpu_ctx, orc, strip_rows, xtile_cols):
     gpu_ctx.set_option("dump_score", 1)
     gpu_ctx.set_option("strip_rows", strip_rows)
     gpu_ctx.set_option("xtile_cols", xtile_cols)
+    gpu_ctx.set_option("run_len", run_len)
     try:
         fe = OrbFrontend(levels, vstep=640, rows=2210, max_keypoints=4096, ctx=gpu_ctx)
         kp, desc, counts = fe.alloc_outputs(3, dev)
@@ -223,6 +226,7 @@ def test_fused_strip_heights(gpu_ctx, orc, strip_rows, xtile_cols):
         gpu_ctx.set_option("dump_score", 0)
         gpu_ctx.set_option("strip_rows", 0)
         gpu_ctx.set_option("xtile_cols", -1)
+        gpu_ctx.set_option("run_len", 0)
 
 
 def test_fused_odd_shapes_and_unaligned_layouts(gpu_ctx, orc):
