@@ -74,6 +74,18 @@ struct FusedParams {
   FusedLevel lv[MAX_LEVELS];
 };
 
+// Workgroup barrier that orders LDS traffic only (s_waitcnt lgkmcnt(0); s_barrier).  __syncthreads()
+// also waits for every outstanding GLOBAL load (vmcnt(0)), which would serialise the next strip's
+// prefetch with the first barrier of the current strip.  Nothing in the strip kernel communicates
+// through global memory inside a workgroup.
+__device__ __forceinline__ void lds_barrier() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
+constexpr int PF_MAX = 3;              // 16-byte vectors a thread can hold for the next strip's prefetch
+
 // candidate coordinates packed as x | (tile_row << 16)
 __device__ __forceinline__ uint32_t pack_xy(int x, int r) { return (uint32_t)x | ((uint32_t)r << 16); }
 
@@ -136,11 +148,23 @@ __device__ __forceinline__ void strip_body(const StripArgs A, const FusedLevel L
                                            uint32_t *sh_ctr, const uint8_t *__restrict__ im, const ptrdiff_t lim,
                                            uint32_t *__restrict__ stage_kp,
                                            uint32_t *__restrict__ strip_count, uint8_t *__restrict__ score_dump,
-                                           size_t score_stride, const bool carry, const int tid) {
+                                           size_t score_stride, const bool carry, const int tid,
+                                           unsigned long long *__restrict__ prof, u32x4 (&pf)[PF_MAX],
+                                           const bool pf_have, const bool pf_want, bool &pf_issued) {
   const int B = A.border;
   const int pitch = L.pitch, tpitch = L.tpitch;
   lds_u8 *tile = tile0;                             // re-based per x-tile: tile + row*tpitch + x with level column x
   int cxa = B, cxb = L.xend;                        // classified columns [cxa, cxb) of the current x-tile
+  // profiling hook (HOOKS kernels only, ablate bit 8192): workgroup wall-clock cycles per phase
+  long long t_last = 0;
+  if (HOOKS && prof) t_last = clock64();
+  auto mark = [&](int phase) {
+    if (HOOKS && prof && tid == 0) {
+      const long long t = clock64();
+      prof[phase] += (unsigned long long)(t - t_last);
+      t_last = t;
+    }
+  };
   const int lane = tid & 63;                        // (== lane_id() for the 1-D workgroup)
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform (keeps loops scalar)
   // `carry`: the workgroup has just finished the strip above this one (same level, full height R) and
@@ -169,7 +193,7 @@ __device__ __forceinline__ void strip_body(const StripArgs A, const FusedLevel L
       }
       if (lane < 8) sh_ctr[lane] = lane == 1 ? QH_SHARED : lane == 2 ? (uint32_t)kept : 0u;
     }
-    __syncthreads();
+    lds_barrier();
     const int nz = (L.R * pitch) >> 4;              // fresh score rows 3 .. R+2
     for (int i = tid; i < nz; i += NT) ((lds_u4 *)(sc + 3 * pitch))[i] = (u32x4)(0u);
   } else {                                          // zero the score tile, reset the counters
@@ -321,6 +345,21 @@ __device__ __forceinline__ void strip_body(const StripArgs A, const FusedLevel L
       const int nrows = min(ye + 6, Lh) - y_lo;
       const int r_st0 = carry_img ? 10 : 0;         // the first 10 rows were carried over
       if (carry_img && (ablate & 2048)) {           // profiling only: no global loads on carried strips
+      } else if (VEC16 && carry_img && pf_have) {   // the new rows were prefetched while the strip above ran
+        const int vpr = tpitch >> 4;
+        int r = (int)__umulhi((uint32_t)tid, L.vpr_recip), v = tid - r * vpr;
+        r += 10;
+        const int dr = NT / vpr, dv = NT - dr * vpr;
+#pragma unroll
+        for (int k = 0; k < PF_MAX; k++) {
+          if (r < nrows) *(lds_u4 *)(tile0 + r * tpitch + 16 * v) = pf[k];
+          v += dv;
+          if (v >= vpr) {
+            v -= vpr;
+            r++;
+          }
+          r += dr;
+        }
       } else if (VEC16) {
         const int vpr = tpitch >> 4;                // 16-byte vectors per row
         // (row, vector) of this thread's first element, then stepped incrementally: no per-element
@@ -370,7 +409,34 @@ __device__ __forceinline__ void strip_body(const StripArgs A, const FusedLevel L
         }
       }
     }
-    __syncthreads();
+    lds_barrier();
+    mark(0);
+    // Prefetch the next strip's R new image rows (level rows ye+6 ..) into registers now: the loads are
+    // in flight during this strip's classification and are only waited for when the next strip stores
+    // them (lds_barrier does not wait for global loads).
+    pf_issued = false;
+    if (VEC16 && pf_want && L.ntx == 1 && L.R >= 10 && L.R * (tpitch >> 4) <= PF_MAX * NT) {
+      const int vpr = tpitch >> 4;
+      const int ylo_n = ye - 4, ye_n = min(ye + L.R, Lh - B);
+      const int nrows_n = min(ye_n + 6, Lh) - ylo_n;
+      if ((ptrdiff_t)(ylo_n + nrows_n - 1) * A.vstep + xbase + tpitch <= lim) {
+        const uint8_t *src_n = im + (ptrdiff_t)ylo_n * A.vstep + xbase;
+        int r = (int)__umulhi((uint32_t)tid, L.vpr_recip), v = tid - r * vpr;
+        r += 10;
+        const int dr = NT / vpr, dv = NT - dr * vpr;
+#pragma unroll
+        for (int k = 0; k < PF_MAX; k++) {
+          if (r < nrows_n) pf[k] = *(const u32x4 *)(src_n + (ptrdiff_t)r * A.vstep + 16 * v);
+          v += dv;
+          if (v >= vpr) {
+            v -= vpr;
+            r++;
+          }
+          r += dr;
+        }
+        pf_issued = true;
+      }
+    }
     if (ablate & 1) continue;
 
     // Group prefilter on every 4-pixel group: a pixel can only pass the compass test if one of its
@@ -407,13 +473,15 @@ __device__ __forceinline__ void strip_body(const StripArgs A, const FusedLevel L
     // left-over candidates (< 64): one partial batch per wave — cheaper than a barrier to merge them
     if (nf > 0 && !(ablate & 2)) fast_batch(lane < nf, qf[min(lane, nf - 1)]);
     nf = 0;
-    __syncthreads();
+    lds_barrier();
+    mark(1);
     {
       const int th = (int)min(sh_ctr[0], sh_ctr[1]);
       if (!(ablate & 4))
         for (int c0 = wave * 64; c0 < th; c0 += WAVES * 64) harris_batch(c0 + lane < th, shq_h[min(c0 + lane, th - 1)]);
     }
-    __syncthreads();
+    lds_barrier();
+    mark(2);
     if (tid == 0) {                                 // fresh corner queue for the next x-tile
       sh_ctr[0] = 0;
       sh_ctr[1] = QH_SHARED;
@@ -432,7 +500,7 @@ __device__ __forceinline__ void strip_body(const StripArgs A, const FusedLevel L
 
   if (ablate & 8) return;
   if ((ablate & 512) && tid == 0) sh_ctr[3] = 1;    // test hook: force the scan fallbacks
-  if (ablate & 512) __syncthreads();
+  if (ablate & 512) lds_barrier();
   // ---- phase D (queue-driven): 2x2-block NMS only where a non-zero score exists ---------------
   // Each queued pixel evaluates the block it lies in (Fast.h:228-312) and emits it iff it is the
   // block's winner, so several corners in one block yield exactly one keypoint.  Survivors are
@@ -481,7 +549,8 @@ __device__ __forceinline__ void strip_body(const StripArgs A, const FusedLevel L
         }
       }
     }
-    __syncthreads();
+    lds_barrier();
+    mark(3);
     if (sh_ctr[3] == 0) {
       if (ablate & 128) return;
       const int ns = (int)sh_ctr[4];
@@ -495,6 +564,7 @@ __device__ __forceinline__ void strip_body(const StripArgs A, const FusedLevel L
           stage_kp[strip_slot + rank] = shq_s[i] + add_xy;
         }
         if (tid == 0) strip_count[(size_t)pyr * A.strips_per_pyr + L.strip0 + s] = (uint32_t)ns;
+        mark(4);
         return;
       }
       // Buckets (Fast.h:314-352): a cell = one bucket x one flush interval = 2^lbs x 2^lbs pixels of
@@ -508,7 +578,7 @@ __device__ __forceinline__ void strip_body(const StripArgs A, const FusedLevel L
         const uint32_t cell = (((uint32_t)(decode_y(v) - B) >> lbs) << 12) | ((uint32_t)(decode_x(v) - B) >> lbs);
         shq_k[i] = cell;
       }
-      __syncthreads();
+      lds_barrier();
       lds_u32 *keep = shq_k + QS_SHARED;
       for (int i = tid; i < ns; i += NT) {
         const uint32_t v = shq_s[i], cell = shq_k[i];
@@ -516,7 +586,7 @@ __device__ __forceinline__ void strip_body(const StripArgs A, const FusedLevel L
         for (int j = 0; j < ns; j++) greater += (shq_k[j] == cell) & (shq_s[j] > v);
         keep[i] = greater < limit;
       }
-      __syncthreads();
+      lds_barrier();
       int kept_here = 0;
       for (int i = tid; i < ns; i += NT) {
         if (!keep[i]) continue;
@@ -528,7 +598,7 @@ __device__ __forceinline__ void strip_body(const StripArgs A, const FusedLevel L
         kept_here++;
       }
       if (kept_here) atomicAdd(&sh_ctr[5], (uint32_t)kept_here);
-      __syncthreads();
+      lds_barrier();
       if (tid == 0) strip_count[(size_t)pyr * A.strips_per_pyr + L.strip0 + s] = sh_ctr[5];
       return;
     }
@@ -568,7 +638,7 @@ __device__ __forceinline__ void strip_body(const StripArgs A, const FusedLevel L
       }
       if (lane == 0) cellcnt[cell] = (uint32_t)nf_c;
     }
-    __syncthreads();
+    lds_barrier();
     const size_t strip_slot = (size_t)pyr * A.slots_per_pyr + L.slot0 + (size_t)s * (L.R >> 1) * L.nbx;
     const uint32_t add_xy = ((uint32_t)L.col0 << 12) | (uint32_t)L.row0;
     for (int cell = wave; cell < ncell; cell += WAVES) {
@@ -646,7 +716,7 @@ __device__ __forceinline__ void strip_body(const StripArgs A, const FusedLevel L
     }
     if (lane == 0) rowcnt[br] = cnt;
   }
-  __syncthreads();
+  lds_barrier();
   if (ablate & 128) return;                         // profiling only: NMS compute without the copy-out
   const size_t strip_slot = (size_t)pyr * A.slots_per_pyr + L.slot0 + (size_t)s * (L.R >> 1) * nbx;
   const uint32_t add_xy = ((uint32_t)L.col0 << 12) | (uint32_t)L.row0;      // README.md:78
@@ -668,7 +738,7 @@ template <bool VEC16, bool HOOKS>
 __global__ __launch_bounds__(NT) void k_fused_strips(
     const FusedParams P, const uint8_t *__restrict__ pyramids, size_t pyr_stride,
     uint32_t *__restrict__ stage_kp, uint32_t *__restrict__ strip_count,
-    uint8_t *__restrict__ score_dump, size_t score_stride) {
+    uint8_t *__restrict__ score_dump, size_t score_stride, unsigned long long *__restrict__ prof) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   __shared__ uint32_t sh_ctr[8];
   // XCD-aware mapping: workgroup b runs on XCD b%8; keep all strips of one pyramid on one XCD so
@@ -689,7 +759,15 @@ __global__ __launch_bounds__(NT) void k_fused_strips(
   // over inside LDS (strip_body `carry`), so a run behaves like one strip of run_len * R rows at the
   // LDS footprint of R rows: the halo is staged, classified and scored once per run, not per strip.
   const int s0 = run * P.run_len, s1 = min(s0 + P.run_len, P.lv[li].nstrips);
-  bool carry = false;
+  long long t_wg = 0;
+  if (HOOKS && prof) {
+    prof += (size_t)blockIdx.x * 8;                 // one private row of counters per workgroup (zeroed by the host)
+    t_wg = clock64();
+  }
+  bool carry = false, pf_have = false;
+  u32x4 pf[PF_MAX];
+#pragma unroll
+  for (int k = 0; k < PF_MAX; k++) pf[k] = (u32x4)(0u);
   for (int s = s0; s < s1; s++) {
     // Opaque copies of the level index, the thread id and the scalar arguments: without them the
     // compiler hoists every strip-invariant address and constant out of this loop and keeps them live
@@ -712,14 +790,16 @@ __global__ __launch_bounds__(NT) void k_fused_strips(
     const int ys = A.border + s * L.R;              // first block-row y of the strip
     const int ye = min(ys + L.R, L.h - A.border);   // one past the last row owned
     strip_body<VEC16, HOOKS>(A, L, pyr, s, ys, ye, tile, sc, queues, sh_ctr, im, lim, stage_kp, strip_count,
-                             score_dump, score_stride, carry, tid_o);
+                             score_dump, score_stride, carry, tid_o, prof, pf, pf_have, s + 1 < s1, pf_have);
     if (s + 1 < s1) {
-      __syncthreads();                              // every read of this strip's LDS state is done
+      lds_barrier();                              // every read of this strip's LDS state is done
       // (a scan fallback scribbles over the tiles: the next strip then starts afresh)
       carry = sh_ctr[6] == 0 && L.R >= 10 && !(HOOKS && (P.ablate & 1024));
-      __syncthreads();
+      lds_barrier();
+      if (HOOKS && prof && threadIdx.x == 0) prof[6] += 1ull;
     }
   }
+  if (HOOKS && prof && threadIdx.x == 0) prof[7] += (unsigned long long)(clock64() - t_wg);
 }
 
 // One workgroup per pyramid: exclusive scan of the strip counts in strip order (= level order,

@@ -84,7 +84,7 @@ struct pislam_ctx {
   // compaction scratch (shared by extract and the batch pipeline)
   DevBuf w_cnt, w_off, w_total, w_cellkp;
   // batch pipeline workspace
-  DevBuf w_score, w_stage, w_stripcnt, w_work;
+  DevBuf w_score, w_stage, w_stripcnt, w_work, w_prof;
   int num_cus = 0;
   const void *pyr_zeroed = nullptr;   // pyramid buffer whose padding is known to be in its defined state
   size_t pyr_zeroed_sig = 0;
@@ -369,7 +369,7 @@ PISLAM_EXPORT int pislam_ctx_destroy(pislam_ctx *c) {
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
   for (DevBuf *b : {&c->s_img, &c->s_out, &c->s_pts, &c->s_desc, &c->s_misc, &c->s_rots, &c->s_tmp, &c->w_cnt,
-                    &c->w_off, &c->w_total, &c->w_cellkp, &c->w_score, &c->w_stage, &c->w_stripcnt, &c->w_work})
+                    &c->w_off, &c->w_total, &c->w_cellkp, &c->w_score, &c->w_stage, &c->w_stripcnt, &c->w_work, &c->w_prof})
     b->release();
   for (auto &e : c->ev)
     if (e) (void)hipEventDestroy(e);
@@ -942,8 +942,26 @@ int run_fused(pislam_ctx *c, const pislam_frontend_params *p, const pf::FusedPar
     if (lds > 64 * 1024)
       HIPCHK(c, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const dim3 grid((unsigned)(groups * F.runs_per_pyr * 8));
+    unsigned long long *prof = nullptr;
+    const size_t prof_n = (size_t)grid.x * 8;
+    if (F.ablate & 8192) {                         // profiling hook: per-phase workgroup cycles -> stderr
+      if (c->w_prof.ensure(prof_n * sizeof(unsigned long long)) != PISLAM_OK) return fail(c, PISLAM_ERR_NOMEM, "hipMalloc(prof)");
+      prof = c->w_prof.as<unsigned long long>();
+      HIPCHK(c, hipMemsetAsync(prof, 0, prof_n * sizeof(unsigned long long), c->stream));
+    }
     hipLaunchKernelGGL(kern, grid, dim3(pf::NT), lds, c->stream, F, pyramids, stride, c->w_stage.as<uint32_t>(),
-                       c->w_stripcnt.as<uint32_t>(), dump, dump_stride);
+                       c->w_stripcnt.as<uint32_t>(), dump, dump_stride, prof);
+    if (prof) {
+      std::vector<unsigned long long> hv(prof_n);
+      HIPCHK(c, hipMemcpyAsync(hv.data(), prof, prof_n * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(c, hipStreamSynchronize(c->stream));
+      double h[8] = {0};
+      for (size_t i = 0; i < prof_n; i++) h[i & 7] += (double)hv[i];
+      const double n = (double)F.strips_per_pyr * batch;
+      fprintf(stderr, "[pislam prof] cycles/strip: stage %.0f classify %.0f harris %.0f nms %.0f emit %.0f "
+                      "(strips %.0f, carried %.0f, workgroups %u, lifetime %.0f/strip)\n",
+              h[0] / n, h[1] / n, h[2] / n, h[3] / n, h[4] / n, n, h[6], grid.x, h[7] / n);
+    }
     PCHK(launch_ok(c, "k_fused_strips"));
   }
   HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
