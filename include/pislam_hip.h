@@ -210,6 +210,35 @@ int pislam_frontend_get_score_map(pislam_ctx *ctx, int b, uint8_t *dst);
  * Synchronises on the end event. */
 int pislam_frontend_last_timing(pislam_ctx *ctx, float *total_ms, float stage_ms[3]);
 
+/* ---- descriptor matching ---------------------------- */
+
+/* The reference ships no matcher (README.md:125-128 only names matching as
+ * the consumer of these descriptors), so there is no reference interface to
+ * mirror: the semantics below are this library's own.
+ *
+ * Brute-force Hamming matching of `words`-dword binary descriptors
+ * (words in {1,2,4,8}, as orbCompute produces them — Orb.h:396).  For every
+ * query i: idx[i] = the train index with the smallest Hamming distance (ties:
+ * the smallest index; -1 if nt == 0), dist[i] = that distance (0xffffffff if
+ * nt == 0), dist2[i] = the smallest distance among all OTHER train descriptors
+ * (0xffffffff if nt < 2; for a ratio test).  nt <= 65535.  Host or device
+ * pointers. */
+int pislam_match_hamming(pislam_ctx *ctx, int words, const uint32_t *query, size_t nq,
+                         const uint32_t *train, size_t nt, int32_t *idx, uint32_t *dist,
+                         uint32_t *dist2);
+
+/* Batched form on device-resident front-end outputs: pair b matches the first
+ * min(qcounts[b], q_stride) descriptors of query[b] against the first
+ * min(tcounts[b], t_stride) of train[b] (layouts [batch][stride][words], the
+ * descriptor / count arrays of pislam_orb_frontend_batch; strides in
+ * descriptors, t_stride <= 65535).  Outputs are [batch][q_stride]; entries
+ * at and beyond the pair's query count are not written.  Device pointers
+ * only; asynchronous on the context stream. */
+int pislam_match_hamming_batch(pislam_ctx *ctx, int words, const uint32_t *query,
+                               const uint32_t *qcounts, size_t q_stride, const uint32_t *train,
+                               const uint32_t *tcounts, size_t t_stride, int batch, int32_t *idx,
+                               uint32_t *dist, uint32_t *dist2);
+
 #ifdef __cplusplus
 }
 #endif

@@ -66,6 +66,9 @@ def lib():
             getattr(L, name).restype = None
         L.orc_fill_spiral.argtypes = [_i, _i, _i, _i, _i, c_u8p]
         L.orc_fill_spiral.restype = None
+        L.orc_match_hamming.argtypes = [_i, ctypes.c_void_p, _sz, ctypes.c_void_p, _sz, ctypes.c_void_p,
+                                        ctypes.c_void_p, ctypes.c_void_p]
+        L.orc_match_hamming.restype = None
         _LIB = L
     return _LIB
 
@@ -181,3 +184,17 @@ def fill_spiral(vstep, width, height, cx, cy, rows=None):
     buf = np.zeros((rows or height, vstep), np.uint8)
     lib().orc_fill_spiral(vstep, width, height, cx, cy, buf.ctypes.data)
     return buf
+
+
+def match_hamming(query, train):
+    """Library-defined brute-force matcher (no reference counterpart): (idx int32, dist, dist2 uint32)."""
+    query = np.ascontiguousarray(query, np.uint32)
+    train = np.ascontiguousarray(train, np.uint32)
+    words = query.shape[1] if query.ndim == 2 else train.shape[1]
+    nq, nt = len(query), len(train)
+    idx = np.zeros(nq, np.int32)
+    dist = np.zeros(nq, np.uint32)
+    dist2 = np.zeros(nq, np.uint32)
+    lib().orc_match_hamming(words, query.ctypes.data, nq, train.ctypes.data, nt, idx.ctypes.data, dist.ctypes.data,
+                            dist2.ctypes.data)
+    return idx, dist, dist2

@@ -596,3 +596,31 @@ ORC_API void orc_fill_spiral(int vstep, int width, int height, int cx, int cy, u
     if (0 <= i && i < vstep && 0 <= j && j < vstep && i < height) buffer[i * vstep + j] = 0xff;
   }
 }
+
+/* Brute-force Hamming matcher.  NOT a restatement of reference code: the
+ * reference ships no matcher (README.md:125-128 only names matching as the consumer of the
+ * descriptors), so this function DEFINES the semantics that pislam_match_hamming (include/
+ * pislam_hip.h) implements on the GPU: per query the train index of minimum Hamming distance (ties
+ * -> smallest index; -1 when nt == 0), that distance, and the minimum distance among the other
+ * train descriptors (0xffffffff when there is none). */
+ORC_API void orc_match_hamming(int words, const uint32_t *query, size_t nq, const uint32_t *train, size_t nt,
+                               int32_t *idx, uint32_t *dist, uint32_t *dist2) {
+  for (size_t i = 0; i < nq; i++) {
+    int32_t bi = -1;
+    uint32_t bd = 0xffffffffu, sd = 0xffffffffu;
+    for (size_t j = 0; j < nt; j++) {
+      uint32_t d = 0;
+      for (int k = 0; k < words; k++) d += (uint32_t)__builtin_popcount(query[i * words + k] ^ train[j * words + k]);
+      if (d < bd) {
+        sd = bd;
+        bd = d;
+        bi = (int32_t)j;
+      } else if (d < sd) {
+        sd = d;
+      }
+    }
+    idx[i] = bi;
+    dist[i] = bd;
+    dist2[i] = sd;
+  }
+}

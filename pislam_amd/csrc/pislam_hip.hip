@@ -40,6 +40,7 @@ __device__ const BriefOfsTab g_brief_ofs = make_brief_ofs();
 #include "pislam_stage_kernels.h"
 #include "pislam_fused_kernels.h"
 #include "pislam_prep_kernels.h"
+#include "pislam_match_kernels.h"
 
 #define PISLAM_EXPORT extern "C" __attribute__((visibility("default")))
 
@@ -1121,4 +1122,72 @@ PISLAM_EXPORT int pislam_frontend_last_timing(pislam_ctx *c, float *total_ms, fl
   if (stage_ms)
     for (int i = 0; i < 3; i++) HIPCHK(c, hipEventElapsedTime(&stage_ms[i], c->ev[i], c->ev[i + 1]));
   return PISLAM_OK;
+}
+
+// ---- descriptor matching --------------------------------------------------
+
+namespace {
+
+int launch_match(pislam_ctx *c, int words, const uint32_t *q, const uint32_t *qc, size_t q_stride, uint32_t nq,
+                 const uint32_t *t, const uint32_t *tc, size_t t_stride, uint32_t nt, int batch, uint32_t max_q,
+                 int32_t *idx, uint32_t *dist, uint32_t *dist2, size_t out_stride) {
+  const dim3 grid((unsigned)cdiv((int)max_q, 256), (unsigned)batch);
+#define PISLAM_MATCH(W)                                                                                       \
+  hipLaunchKernelGGL(pm::k_match<W>, grid, dim3(256), 0, c->stream, q, qc, q_stride * W, nq, t, tc, t_stride * W, \
+                     nt, (uint32_t)std::min<size_t>(q_stride, 0xffffffffu), (uint32_t)std::min<size_t>(t_stride, 65535), \
+                     idx, dist, dist2, out_stride)
+  switch (words) {
+    case 1: PISLAM_MATCH(1); break;
+    case 2: PISLAM_MATCH(2); break;
+    case 4: PISLAM_MATCH(4); break;
+    case 8: PISLAM_MATCH(8); break;
+    default: return fail(c, PISLAM_ERR_INVALID, "words must be 1, 2, 4 or 8");
+  }
+#undef PISLAM_MATCH
+  return launch_ok(c, "k_match");
+}
+
+}  // namespace
+
+PISLAM_EXPORT int pislam_match_hamming(pislam_ctx *c, int words, const uint32_t *query, size_t nq,
+                                       const uint32_t *train, size_t nt, int32_t *idx, uint32_t *dist,
+                                       uint32_t *dist2) {
+  if (!c) return PISLAM_ERR_INVALID;
+  if (words != 1 && words != 2 && words != 4 && words != 8) return fail(c, PISLAM_ERR_INVALID, "words must be 1, 2, 4 or 8");
+  if (nt > 65535) return fail(c, PISLAM_ERR_INVALID, "at most 65535 train descriptors");
+  if (nq > 0x7fffffffu) return fail(c, PISLAM_ERR_INVALID, "too many query descriptors");
+  if (nq == 0) return PISLAM_OK;
+  if (!query || !idx || !dist || !dist2 || (nt && !train)) return fail(c, PISLAM_ERR_INVALID, "null pointer");
+  HIPCHK(c, hipSetDevice(c->device));
+  Staged sq, st, si, sd, s2;
+  PCHK(stage_in(c, c->s_desc, query, nq * words * sizeof(uint32_t), &sq));
+  PCHK(stage_in(c, c->s_tmp, train, nt * words * sizeof(uint32_t), &st));
+  PCHK(stage_in(c, c->s_pts, idx, nq * sizeof(int32_t), &si, false));
+  PCHK(stage_in(c, c->s_misc, dist, nq * sizeof(uint32_t), &sd, false));
+  PCHK(stage_in(c, c->s_out, dist2, nq * sizeof(uint32_t), &s2, false));
+  PCHK(launch_match(c, words, (const uint32_t *)sq.dev, nullptr, nq, (uint32_t)nq, (const uint32_t *)st.dev, nullptr,
+                    std::max<size_t>(nt, 1), (uint32_t)nt, 1, (uint32_t)nq, (int32_t *)si.dev, (uint32_t *)sd.dev,
+                    (uint32_t *)s2.dev, nq));
+  PCHK(stage_out(c, si, idx, nq * sizeof(int32_t)));
+  PCHK(stage_out(c, sd, dist, nq * sizeof(uint32_t)));
+  PCHK(stage_out(c, s2, dist2, nq * sizeof(uint32_t)));
+  return sync(c);
+}
+
+PISLAM_EXPORT int pislam_match_hamming_batch(pislam_ctx *c, int words, const uint32_t *query,
+                                             const uint32_t *qcounts, size_t q_stride, const uint32_t *train,
+                                             const uint32_t *tcounts, size_t t_stride, int batch, int32_t *idx,
+                                             uint32_t *dist, uint32_t *dist2) {
+  if (!c) return PISLAM_ERR_INVALID;
+  if (batch < 0 || batch > 65535) return fail(c, PISLAM_ERR_INVALID, "batch must be 0..65535");
+  if (t_stride > 65535) return fail(c, PISLAM_ERR_INVALID, "at most 65535 train descriptors per pair");
+  if (q_stride > 0x7fffffffu) return fail(c, PISLAM_ERR_INVALID, "q_stride too large");
+  if (batch == 0 || q_stride == 0) return PISLAM_OK;
+  if (!query || !train || !qcounts || !tcounts || !idx || !dist || !dist2) return fail(c, PISLAM_ERR_INVALID, "null pointer");
+  for (const void *ptr : {(const void *)query, (const void *)train, (const void *)qcounts, (const void *)tcounts,
+                          (const void *)idx, (const void *)dist, (const void *)dist2})
+    if (!is_device_ptr(ptr)) return fail(c, PISLAM_ERR_INVALID, "the batch matcher takes device pointers only");
+  HIPCHK(c, hipSetDevice(c->device));
+  return launch_match(c, words, query, qcounts, q_stride, 0, train, tcounts, t_stride, 0, batch, (uint32_t)q_stride,
+                      idx, dist, dist2, q_stride);
 }

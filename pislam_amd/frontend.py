@@ -162,6 +162,44 @@ def orbCompute(img, points, descriptors: list | None = None, *, words=8,
     return desc
 
 
+# ---- descriptor matching (no reference counterpart) -----------------
+def matchHamming(query, train, *, ctx: Context | None = None):
+    """Brute-force Hamming matching of uint32 [n][words] descriptors (numpy or torch): returns
+    (idx int32 [nq], dist uint32 [nq], dist2 uint32 [nq]) — nearest train index (ties: smallest
+    index, -1 without train descriptors), its distance, and the best distance among the others."""
+    ctx = ctx or default_context()
+    query = np.ascontiguousarray(query, np.uint32)
+    train = np.ascontiguousarray(train, np.uint32)
+    words = query.shape[1] if query.ndim == 2 and len(query) else (train.shape[1] if train.ndim == 2 else 8)
+    nq, nt = len(query), len(train)
+    idx = np.zeros(nq, np.int32)
+    dist = np.zeros(nq, np.uint32)
+    dist2 = np.zeros(nq, np.uint32)
+    ctx.check(ctx.lib.pislam_match_hamming(ctx.h, words, ptr(query) if nq else None, nq, ptr(train) if nt else None, nt,
+                                           ptr(idx) if nq else None, ptr(dist) if nq else None,
+                                           ptr(dist2) if nq else None), "pislam_match_hamming")
+    return idx, dist, dist2
+
+
+def matchHammingBatch(qdesc, qcounts, tdesc, tcounts, idx=None, dist=None, dist2=None, *, ctx: Context | None = None):
+    """Batched matcher on device-resident front-end outputs (torch tensors [batch][max_kp][words] and
+    [batch] counts, as OrbFrontend writes them): pair b matches qdesc[b] against tdesc[b].  Returns
+    (idx int32, dist int32, dist2 int32) tensors [batch][max_kp]; asynchronous on the ctx stream."""
+    import torch
+    ctx = ctx or default_context()
+    batch, qs, words = qdesc.shape
+    ts = tdesc.shape[1]
+    if idx is None:
+        idx = torch.empty((batch, qs), dtype=torch.int32, device=qdesc.device)
+    if dist is None:
+        dist = torch.empty((batch, qs), dtype=torch.int32, device=qdesc.device)
+    if dist2 is None:
+        dist2 = torch.empty((batch, qs), dtype=torch.int32, device=qdesc.device)
+    ctx.check(ctx.lib.pislam_match_hamming_batch(ctx.h, words, ptr(qdesc), ptr(qcounts), qs, ptr(tdesc), ptr(tcounts), ts,
+                                                 batch, ptr(idx), ptr(dist), ptr(dist2)), "pislam_match_hamming_batch")
+    return idx, dist, dist2
+
+
 # ---- Gaussian.h:48, Bilinear.h:42, Bilinear.h:165 -------------------------------------
 def gaussian5x5(width, height, img, out, *, ctx: Context | None = None):
     """pislam::gaussian5x5<vstep>(width, height, img, out); img may be out (in place)."""
