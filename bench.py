@@ -69,6 +69,8 @@ def main():
     ap.add_argument("--wgs-per-cu", type=int, default=0)
     ap.add_argument("--xtile-cols", type=int, default=-1)
     ap.add_argument("--run-len", type=int, default=0)
+    ap.add_argument("--match", action="store_true",
+                    help="also match every pyramid's descriptors against its neighbour's inside the step (SURVEY 8f-4)")
     ap.add_argument("--lds-pad", type=int, default=0, help="profiling only: extra LDS per strip workgroup")
     ap.add_argument("--log-bucket-size", type=int, default=0, help="fastExtract logBucketSize (README uses 4)")
     ap.add_argument("--bucket-limit", type=int, default=5, help="fastExtract bucketLimit (README uses 3)")
@@ -139,10 +141,21 @@ def main():
     fe.reserve(B)
     kp, desc, counts = fe.alloc_outputs(B, dev)
 
+    m_out = None
+    if args.match:
+        # train side: the neighbouring pyramid's descriptors (static inputs -> made once, outside the step)
+        from pislam_amd.frontend import matchHammingBatch
+        fe(d_pyr, kp, desc, counts)
+        torch.cuda.synchronize()
+        t_desc, t_counts = torch.roll(desc, 1, 0).contiguous(), torch.roll(counts, 1, 0).contiguous()
+        m_out = [torch.empty((B, args.max_keypoints), dtype=torch.int32, device=dev) for _ in range(3)]
+
     def step():
         if builder is not None:
             builder(d_frames, d_pyr)
         fe(d_pyr, kp, desc, counts)
+        if m_out is not None:
+            matchHammingBatch(desc, counts, t_desc, t_counts, *m_out, ctx=ctx)
         return pdist.gather_counts(counts, world)
 
     for _ in range(args.warmup):
@@ -175,6 +188,22 @@ def main():
         ev.append(fe.last_timing())
     ev_total_ms = float(np.mean([e[0] for e in ev]))
     ev_stage_ms = [float(np.mean([e[1][i] for e in ev])) for i in range(3)]
+
+    match_info = None
+    if m_out is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        for _ in range(5):
+            matchHammingBatch(desc, counts, t_desc, t_counts, *m_out, ctx=ctx)
+        e1.record(stream)
+        torch.cuda.synchronize()
+        cq = torch.clamp(counts.to(torch.int64), max=args.max_keypoints)
+        ct = torch.clamp(t_counts.to(torch.int64), max=args.max_keypoints)
+        pairs = int((cq * ct).sum().item())
+        mm = e0.elapsed_time(e1) / 5
+        match_info = {"ms": mm, "descriptor_pairs": pairs, "pairs_per_s": pairs / (mm * 1e-3),
+                      "matched_within_64_bits": int(((m_out[1] <= 64) & (torch.arange(args.max_keypoints, device=dev)[None, :]
+                                                                          < cq[:, None])).sum().item())}
 
     total_kp_step = int(allc.to(torch.int64).sum().item())          # all ranks, one step
     local_kp = int(counts.to(torch.int64).sum().item())
@@ -218,6 +247,7 @@ def main():
                 "pyramids_per_s": B * world * args.steps / dt,
                 "parallelism": f"pyramid-shard x{world}, RCCL all-gather of counts" if world > 1 else "single GPU",
                 "pipeline": "fused" if fused else "staged",
+                **({"match_inside_step": match_info} if match_info else {}),
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",

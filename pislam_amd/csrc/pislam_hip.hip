@@ -1131,9 +1131,9 @@ namespace {
 int launch_match(pislam_ctx *c, int words, const uint32_t *q, const uint32_t *qc, size_t q_stride, uint32_t nq,
                  const uint32_t *t, const uint32_t *tc, size_t t_stride, uint32_t nt, int batch, uint32_t max_q,
                  int32_t *idx, uint32_t *dist, uint32_t *dist2, size_t out_stride) {
-  const dim3 grid((unsigned)cdiv((int)max_q, 256), (unsigned)batch);
+  const dim3 grid((unsigned)std::min(cdiv((int)max_q, pm::QPW), batch > 1 ? pm::MAX_GRID_X : 65535), (unsigned)batch);
 #define PISLAM_MATCH(W)                                                                                       \
-  hipLaunchKernelGGL(pm::k_match<W>, grid, dim3(256), 0, c->stream, q, qc, q_stride * W, nq, t, tc, t_stride * W, \
+  hipLaunchKernelGGL(pm::k_match<W>, grid, dim3(pm::QPW * pm::SPLIT), 0, c->stream, q, qc, q_stride * W, nq, t, tc, t_stride * W, \
                      nt, (uint32_t)std::min<size_t>(q_stride, 0xffffffffu), (uint32_t)std::min<size_t>(t_stride, 65535), \
                      idx, dist, dist2, out_stride)
   switch (words) {
