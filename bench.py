@@ -69,6 +69,7 @@ def main():
     ap.add_argument("--wgs-per-cu", type=int, default=0)
     ap.add_argument("--xtile-cols", type=int, default=-1)
     ap.add_argument("--run-len", type=int, default=0)
+    ap.add_argument("--alias", type=int, default=-1)
     ap.add_argument("--match", action="store_true",
                     help="also match every pyramid's descriptors against its neighbour's inside the step (SURVEY 8f-4)")
     ap.add_argument("--lds-pad", type=int, default=0, help="profiling only: extra LDS per strip workgroup")
@@ -110,6 +111,8 @@ def main():
     ctx.set_option("strip_rows", args.strip_rows)
     ctx.set_option("orb_chunks", args.orb_chunks)
     ctx.set_option("lds_pad", args.lds_pad)
+    if args.alias >= 0:
+        ctx.set_option("alias", args.alias)
     if args.run_len:
         ctx.set_option("run_len", args.run_len)
     if args.xtile_cols >= 0:

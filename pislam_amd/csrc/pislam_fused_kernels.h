@@ -44,6 +44,8 @@ constexpr int QH_SHARED = 512;         // workgroup-shared queue of corners awai
 constexpr int QN_SHARED = 512;         // workgroup-shared queue of pixels with a non-zero score (NMS candidates)
 constexpr int QS_SHARED = 256;         // survivors of one strip awaiting their rank (lives in the dead image tile)
 constexpr int SHARED_Q = QH_SHARED + QN_SHARED;
+constexpr int NMS_SCRATCH = 3 * QS_SHARED;   // dwords: survivors, their keys, bucket keep flags (in the idle per-wave queues)
+static_assert(NMS_SCRATCH <= WAVES * QCAP, "NMS scratch must fit the per-wave queue area");
 
 struct FusedLevel {
   int w, h;          // level size
@@ -59,6 +61,9 @@ struct FusedLevel {
   int tcols;         // classified columns per x-tile (multiple of 16)
   int tpitch;        // LDS IMAGE tile pitch in bytes (multiple of 16) = tcols + halo
   int nruns, run0;   // runs (= workgroups) of this level: run_len consecutive strips each
+  int apad;          // ALIAS layout: bytes between the per-wave queues and the image tile (multiple of 16)
+  int tbytes;        // plain layout: bytes reserved for the image tile = max((R+10)*tpitch, the scan
+                     // fallbacks' survivor buffers R/2 * nbx dwords — larger only with narrow x-tiles)
   uint32_t vpr_recip; // ceil(2^32 / (tpitch/16)): row = umulhi(i, vpr_recip) for i < 2^16
 };
 
@@ -142,15 +147,16 @@ struct StripArgs {
 // bound kernel is measurably sensitive — does not grow with the level width.  Per x-tile: stage,
 // prefilter / pretest / FAST (scores of over-classified columns and corner queue), Harris for the
 // tile's corners.  NMS runs once per strip on the full-width score tile.
-template <bool VEC16, bool HOOKS>
+template <bool VEC16, bool HOOKS, bool ALIAS>
 __device__ __forceinline__ void strip_body(const StripArgs A, const FusedLevel L, const int pyr, const int s,
                                            const int ys, const int ye, lds_u8 *tile0, lds_u8 *sc, lds_u32 *queues,
-                                           uint32_t *sh_ctr, const uint8_t *__restrict__ im, const ptrdiff_t lim,
+                                           lds_u32 *shq, uint32_t *sh_ctr, const uint8_t *__restrict__ im, const ptrdiff_t lim,
                                            uint32_t *__restrict__ stage_kp,
                                            uint32_t *__restrict__ strip_count, uint8_t *__restrict__ score_dump,
                                            size_t score_stride, const bool carry, const int tid,
                                            unsigned long long *__restrict__ prof, u32x4 (&pf)[PF_MAX],
-                                           const bool pf_have, const bool pf_want, bool &pf_issued) {
+                                           const bool pf_have, const bool pf_want, bool &pf_issued,
+                                           uint32_t *__restrict__ ovf, const uint32_t ovf_id) {
   const int B = A.border;
   const int pitch = L.pitch, tpitch = L.tpitch;
   lds_u8 *tile = tile0;                             // re-based per x-tile: tile + row*tpitch + x with level column x
@@ -178,15 +184,17 @@ __device__ __forceinline__ void strip_body(const StripArgs A, const FusedLevel L
       const int nv = (10 * tpitch) >> 4;            // source rows R.. and destination rows 0..9 are disjoint (R >= 10)
       for (int i = tid; i < nv; i += NT) ((lds_u4 *)tile0)[i] = ((const lds_u4 *)(tile0 + R * tpitch))[i];
     }
-    const int nvs = (3 * pitch) >> 4;
-    for (int i = tid; i < nvs; i += NT) ((lds_u4 *)sc)[i] = ((const lds_u4 *)(sc + R * pitch))[i];
+    if (!ALIAS) {                                   // (ALIAS: the carried scores travel in the queue entries)
+      const int nvs = (3 * pitch) >> 4;
+      for (int i = tid; i < nvs; i += NT) ((lds_u4 *)sc)[i] = ((const lds_u4 *)(sc + R * pitch))[i];
+    }
     if (wave == 0) {                                // in-place compaction of the candidate queue (front to back)
-      lds_u32 *qn = queues + WAVES * QCAP + QH_SHARED;
+      lds_u32 *qn = shq + QH_SHARED;
       const int tn = (int)sh_ctr[2];
       int kept = 0;
       for (int c0 = 0; c0 < tn; c0 += 64) {
         const uint32_t e = qn[min(c0 + lane, tn - 1)];
-        const bool k = c0 + lane < tn && (int)(e >> 16) >= R;
+        const bool k = c0 + lane < tn && (int)((e >> 16) & 0xff) >= R;
         const uint64_t m = __ballot(k);
         if (k) qn[kept + ballot_rank(m)] = e - ((uint32_t)R << 16);
         kept += __popcll(m);
@@ -194,11 +202,15 @@ __device__ __forceinline__ void strip_body(const StripArgs A, const FusedLevel L
       if (lane < 8) sh_ctr[lane] = lane == 1 ? QH_SHARED : lane == 2 ? (uint32_t)kept : 0u;
     }
     lds_barrier();
-    const int nz = (L.R * pitch) >> 4;              // fresh score rows 3 .. R+2
-    for (int i = tid; i < nz; i += NT) ((lds_u4 *)(sc + 3 * pitch))[i] = (u32x4)(0u);
+    if (!ALIAS) {
+      const int nz = (L.R * pitch) >> 4;            // fresh score rows 3 .. R+2
+      for (int i = tid; i < nz; i += NT) ((lds_u4 *)(sc + 3 * pitch))[i] = (u32x4)(0u);
+    }
   } else {                                          // zero the score tile, reset the counters
-    const int nz = ((L.R + 3) * pitch) >> 4;
-    for (int i = tid; i < nz; i += NT) ((lds_u4 *)sc)[i] = (u32x4)(0u);
+    if (!ALIAS) {
+      const int nz = ((L.R + 3) * pitch) >> 4;
+      for (int i = tid; i < nz; i += NT) ((lds_u4 *)sc)[i] = (u32x4)(0u);
+    }
     if (tid < 8) sh_ctr[tid] = tid == 1 ? QH_SHARED : 0;
   }
   lds_u32 *qg = queues + wave * QCAP;              // 4-pixel groups for the exact pretest
@@ -207,7 +219,7 @@ __device__ __forceinline__ void strip_body(const StripArgs A, const FusedLevel L
   // 64-lane Harris batch per wave, so corners go to ONE queue per workgroup (LDS atomic append)
   // and are scored by all waves together once FAST is finished.  The waves' left-over FAST
   // candidates (< 64 each) are merged the same way.
-  lds_u32 *shq_h = queues + WAVES * QCAP;
+  lds_u32 *shq_h = shq;
   lds_u32 *shq_n = shq_h + QH_SHARED;
   int ng = 0, nf = 0;                               // wave-uniform queue fills
   // NOTE: the lambdas below capture by reference; they must only touch LOCAL copies of kernel
@@ -242,9 +254,11 @@ __device__ __forceinline__ void strip_body(const StripArgs A, const FusedLevel L
     if (valid) {
       const int x = e & 0xffff, r = e >> 16;
       score = (ablate & 32) ? (uint8_t)200 : harris_score_pk(tile + r * tpitch + x - 3, tpitch, hthr);
-      sc[r * pitch + x] = score;
+      if (!ALIAS) sc[r * pitch + x] = score;
     }
-    push_nonzero(score != 0, e);
+    // ALIAS: the score tile does not exist yet (it will overlay the image tile once Harris is done), the
+    // score travels in the top byte of the queue entry
+    push_nonzero(score != 0, ALIAS ? e | ((uint32_t)score << 24) : e);
   };
   auto fast_batch = [&](bool valid, uint32_t e) {
     bool corner = false;
@@ -254,8 +268,8 @@ __device__ __forceinline__ void strip_body(const StripArgs A, const FusedLevel L
     if (valid) corner = fast9(tile + (r + 3) * tpitch + x, tpitch, thr);
     // Fast.h:172: only x < w-B is scored; over-classified columns keep 0xff
     const bool toh = corner && x < Lw - B;
-    if (corner && !toh) sc[r * pitch + x] = 0xff;
-    push_nonzero(corner && !toh, e);
+    if (!ALIAS && corner && !toh) sc[r * pitch + x] = 0xff;
+    push_nonzero(corner && !toh, ALIAS ? e | 0xff000000u : e);
     const uint64_t m = __ballot(toh);
     if (m) {
       const int cnt = __popcll(m);
@@ -269,7 +283,7 @@ __device__ __forceinline__ void strip_body(const StripArgs A, const FusedLevel L
           atomicMin(&sh_ctr[1], (uint32_t)base);
           sh_ctr[3] = 1;                           // their scores are not queued for NMS: scan instead
         }
-        harris_overflow(tile, sc, tpitch, pitch, hthr, toh, e);
+        if (!ALIAS) harris_overflow(tile, sc, tpitch, pitch, hthr, toh, e);   // (ALIAS: the strip is deferred)
       }
     }
   };
@@ -489,6 +503,35 @@ __device__ __forceinline__ void strip_body(const StripArgs A, const FusedLevel L
   }
   if (ablate & 1) return;
   tile = tile0;
+  if ((ablate & 512) && tid == 0) sh_ctr[3] = 1;    // test hook: force the overflow paths
+  if (ablate & 512) lds_barrier();
+  // ALIAS kernels have no dense fallbacks: a strip whose queues overflowed (very dense corners) is put on
+  // the overflow list and redone by k_fused_overflow (non-aliased layout, scan fallbacks) afterwards.
+  auto defer = [&]() {
+    if (tid == 0) {
+      const uint32_t at = atomicAdd(&ovf[0], 1u);
+      ovf[1 + at] = ovf_id;
+      sh_ctr[6] = 1;                                // the next strip of the run must not carry from this one
+    }
+  };
+  if (ALIAS) {
+    if (sh_ctr[3] != 0) {
+      defer();
+      return;
+    }
+    // The image rows 0..R-1 and the per-wave queues are dead now (rows R..R+9 are kept for the next
+    // strip of the run): the score tile is laid over them, zeroed, and the scores are scattered into it
+    // from the queue entries.
+    const int nz = ((L.R + 3) * pitch) >> 4;
+    for (int i = tid; i < nz; i += NT) ((lds_u4 *)sc)[i] = (u32x4)(0u);
+    lds_barrier();
+    const int tn = (int)sh_ctr[2];
+    for (int i = tid; i < tn; i += NT) {
+      const uint32_t e = shq_n[i];
+      sc[(int)((e >> 16) & 0xff) * pitch + (int)(e & 0xffff)] = (uint8_t)(e >> 24);
+    }
+    lds_barrier();
+  }
 
   if (HOOKS && A.dump_score) {   // debug / parity hook: rows this strip owns, [ys, ye)
     uint8_t *dst = score_dump + (size_t)pyr * score_stride + (size_t)L.row0 * A.vstep + L.col0;
@@ -499,8 +542,6 @@ __device__ __forceinline__ void strip_body(const StripArgs A, const FusedLevel L
   }
 
   if (ablate & 8) return;
-  if ((ablate & 512) && tid == 0) sh_ctr[3] = 1;    // test hook: force the scan fallbacks
-  if (ablate & 512) lds_barrier();
   // ---- phase D (queue-driven): 2x2-block NMS only where a non-zero score exists ---------------
   // Each queued pixel evaluates the block it lies in (Fast.h:228-312) and emits it iff it is the
   // block's winner, so several corners in one block yield exactly one keypoint.  Survivors are
@@ -515,7 +556,7 @@ __device__ __forceinline__ void strip_body(const StripArgs A, const FusedLevel L
     for (int c0 = wave * 64; c0 < tn; c0 += WAVES * 64) {
       const bool valid = c0 + lane < tn;
       const uint32_t e = shq_n[min(c0 + lane, tn - 1)];
-      const int x = e & 0xffff, r = e >> 16;
+      const int x = e & 0xffff, r = (e >> 16) & 0xff;
       const int bx = B + ((x - B) & ~1), rb = 1 + ((r - 1) & ~1);   // block origin (column, score row)
       const bool owned = valid && r >= 1 && r <= own_rows && bx < xlimq;
       uint32_t res = 0;
@@ -603,6 +644,10 @@ __device__ __forceinline__ void strip_body(const StripArgs A, const FusedLevel L
       return;
     }
   }
+  if constexpr (ALIAS) {
+    defer();
+    return;
+  } else {
   // Fallback (a queue overflowed: very dense corners): scan the whole score tile.
   if (tid == 0) sh_ctr[6] = 1;                      // the fallbacks scribble over the whole image tile
   if (A.lbs != 0) {
@@ -732,13 +777,41 @@ __device__ __forceinline__ void strip_body(const StripArgs A, const FusedLevel L
     for (int k = 0; k < nbr; k++) tot += rowcnt[k];
     strip_count[(size_t)pyr * A.strips_per_pyr + L.strip0 + s] = tot;
   }
+  }  // !ALIAS
 }
 
-template <bool VEC16, bool HOOKS>
+// LDS layouts of the strip kernels (dynamic shared memory):
+//   plain  : [image tile (R+10) x tpitch][score tile (R+3) x pitch][per-wave queues][shared queues]
+//   ALIAS  : [per-wave queues][apad][image tile (R+10) x tpitch][shared queues]
+//            with the score tile laid over [NMS scratch .. image row R) once Harris is done (see
+//            strip_body): 26 KB instead of 39 KB per workgroup at VGA level 0 -> more resident workgroups.
+struct StripLds {
+  lds_u8 *tile, *sc;
+  lds_u32 *queues, *shq;
+};
+template <bool ALIAS>
+__device__ __forceinline__ StripLds strip_lds(uint8_t *smem, const FusedLevel &L) {
+  StripLds m;
+  if (ALIAS) {
+    m.queues = (lds_u32 *)smem;
+    m.sc = (lds_u8 *)smem + NMS_SCRATCH * 4;
+    m.tile = (lds_u8 *)smem + WAVES * QCAP * 4 + L.apad;
+    m.shq = (lds_u32 *)(m.tile + (L.R + 10) * L.tpitch);
+  } else {
+    m.tile = (lds_u8 *)smem;                        // image tile rows [ys-4, ys+R+6), one x-tile at a time
+    m.sc = m.tile + L.tbytes;                       // score tile rows [ys-1, ys+R+2), full width
+    m.queues = (lds_u32 *)(m.sc + (L.R + 3) * L.pitch);
+    m.shq = m.queues + WAVES * QCAP;
+  }
+  return m;
+}
+
+template <bool VEC16, bool HOOKS, bool ALIAS>
 __global__ __launch_bounds__(NT) void k_fused_strips(
     const FusedParams P, const uint8_t *__restrict__ pyramids, size_t pyr_stride,
     uint32_t *__restrict__ stage_kp, uint32_t *__restrict__ strip_count,
-    uint8_t *__restrict__ score_dump, size_t score_stride, unsigned long long *__restrict__ prof) {
+    uint8_t *__restrict__ score_dump, size_t score_stride, unsigned long long *__restrict__ prof,
+    uint32_t *__restrict__ ovf) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   __shared__ uint32_t sh_ctr[8];
   // XCD-aware mapping: workgroup b runs on XCD b%8; keep all strips of one pyramid on one XCD so
@@ -777,9 +850,7 @@ __global__ __launch_bounds__(NT) void k_fused_strips(
     asm volatile("" : "+s"(li_o));
     asm volatile("" : "+v"(tid_o));
     const FusedLevel L = P.lv[li_o];
-    lds_u8 *tile = (lds_u8 *)smem;                  // image tile rows [ys-4, ys+R+6), one x-tile at a time
-    lds_u8 *sc = tile + (L.R + 10) * L.tpitch;      // score tile rows [ys-1, ys+R+2), full width
-    lds_u32 *queues = (lds_u32 *)(sc + (L.R + 3) * L.pitch);
+    const StripLds m = strip_lds<ALIAS>(smem, L);
     const uint8_t *im = pyramids + (size_t)pyr * pyr_stride + (size_t)L.row0 * P.vstep + L.col0;
     // bytes of this pyramid's buffer that may be read from the level's origin
     const ptrdiff_t lim = (ptrdiff_t)P.rows * P.vstep - ((ptrdiff_t)L.row0 * P.vstep + L.col0);
@@ -789,17 +860,58 @@ __global__ __launch_bounds__(NT) void k_fused_strips(
                  "+s"(A.strips_per_pyr), "+s"(A.hthr));
     const int ys = A.border + s * L.R;              // first block-row y of the strip
     const int ye = min(ys + L.R, L.h - A.border);   // one past the last row owned
-    strip_body<VEC16, HOOKS>(A, L, pyr, s, ys, ye, tile, sc, queues, sh_ctr, im, lim, stage_kp, strip_count,
-                             score_dump, score_stride, carry, tid_o, prof, pf, pf_have, s + 1 < s1, pf_have);
+    strip_body<VEC16, HOOKS, ALIAS>(A, L, pyr, s, ys, ye, m.tile, m.sc, m.queues, m.shq, sh_ctr, im, lim, stage_kp,
+                                    strip_count, score_dump, score_stride, carry, tid_o, prof, pf, pf_have, s + 1 < s1,
+                                    pf_have, ovf, ((uint32_t)pyr << 16) | (uint32_t)(L.strip0 + s));
     if (s + 1 < s1) {
-      lds_barrier();                              // every read of this strip's LDS state is done
-      // (a scan fallback scribbles over the tiles: the next strip then starts afresh)
+      lds_barrier();                                // every read of this strip's LDS state is done
+      // (a scan fallback scribbles over the tiles, a deferred strip leaves no scores: start afresh)
       carry = sh_ctr[6] == 0 && L.R >= 10 && !(HOOKS && (P.ablate & 1024));
       lds_barrier();
       if (HOOKS && prof && threadIdx.x == 0) prof[6] += 1ull;
     }
   }
   if (HOOKS && prof && threadIdx.x == 0) prof[7] += (unsigned long long)(clock64() - t_wg);
+}
+
+// Strips the ALIAS kernel could not finish (a queue overflowed) are redone here, one strip per
+// workgroup iteration, with the plain layout and its scan fallbacks.  Launched after every ALIAS
+// launch with a small fixed grid; normally the list is empty and the workgroups exit at once.
+template <bool VEC16, bool HOOKS>
+__global__ __launch_bounds__(NT) void k_fused_overflow(
+    const FusedParams P, const uint8_t *__restrict__ pyramids, size_t pyr_stride,
+    uint32_t *__restrict__ stage_kp, uint32_t *__restrict__ strip_count,
+    uint8_t *__restrict__ score_dump, size_t score_stride, const uint32_t *__restrict__ ovf) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  __shared__ uint32_t sh_ctr[8];
+  const uint32_t n = ovf[0];
+  u32x4 pf[PF_MAX];
+#pragma unroll
+  for (int k = 0; k < PF_MAX; k++) pf[k] = (u32x4)(0u);
+  for (uint32_t it = blockIdx.x; it < n; it += gridDim.x) {
+    const uint32_t id = ovf[1 + it];
+    int pyr_o = (int)(id >> 16), sg_o = (int)(id & 0xffffu), tid_o = (int)threadIdx.x;
+    asm volatile("" : "+s"(pyr_o), "+s"(sg_o));
+    asm volatile("" : "+v"(tid_o));
+    if (pyr_o >= P.batch || sg_o >= P.strips_per_pyr) continue;   // stale entry of an aborted launch
+    int li = 0;
+    while (li + 1 < P.nlevels && sg_o >= P.lv[li + 1].strip0) li++;
+    const FusedLevel L = P.lv[li];
+    const int s = sg_o - L.strip0;
+    const StripLds m = strip_lds<false>(smem, L);
+    const uint8_t *im = pyramids + (size_t)pyr_o * pyr_stride + (size_t)L.row0 * P.vstep + L.col0;
+    const ptrdiff_t lim = (ptrdiff_t)P.rows * P.vstep - ((ptrdiff_t)L.row0 * P.vstep + L.col0);
+    // (ablate bit 512 forces the ALIAS kernel to defer; here it would force the scan fallbacks too — keep it)
+    const StripArgs A{P.border, P.thr, P.ablate, P.dump_score, P.lbs, P.limit, P.vstep, P.slots_per_pyr,
+                      P.strips_per_pyr, P.hthr};
+    const int ys = A.border + s * L.R;
+    const int ye = min(ys + L.R, L.h - A.border);
+    bool issued = false;
+    strip_body<VEC16, HOOKS, false>(A, L, pyr_o, s, ys, ye, m.tile, m.sc, m.queues, m.shq, sh_ctr, im, lim, stage_kp,
+                                    strip_count, score_dump, score_stride, false, tid_o, nullptr, pf, false, false, issued,
+                                    nullptr, 0u);
+    lds_barrier();
+  }
 }
 
 // One workgroup per pyramid: exclusive scan of the strip counts in strip order (= level order,
@@ -809,10 +921,13 @@ __global__ __launch_bounds__(256) void k_gather(const FusedParams P,
                                                 const uint32_t *__restrict__ stage_kp,
                                                 const uint32_t *__restrict__ strip_count,
                                                 uint32_t *__restrict__ kp, size_t kp_stride,
-                                                uint32_t cap, uint32_t *__restrict__ counts) {
+                                                uint32_t cap, uint32_t *__restrict__ counts,
+                                                uint32_t *__restrict__ ovf_reset) {
   extern __shared__ uint32_t soff[];                // strips_per_pyr + 1
   __shared__ uint32_t wsum[4];
   __shared__ uint32_t carry;
+  // the overflow list of this step has been consumed (stream order): empty it for the next step
+  if (ovf_reset && blockIdx.x == 0 && threadIdx.x == 0) ovf_reset[0] = 0;
   const int pyr = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int S = P.strips_per_pyr;
   const uint32_t *cnt = strip_count + (size_t)pyr * S;
@@ -892,10 +1007,12 @@ __global__ __launch_bounds__(256) void k_gather_orb(
     const FusedParams P, const uint8_t *__restrict__ pyramids, size_t pyr_stride,
     const uint32_t *__restrict__ stage_kp, const uint32_t *__restrict__ strip_count,
     uint32_t *__restrict__ kp, size_t kp_stride, uint32_t cap, uint32_t *__restrict__ counts,
-    uint32_t *__restrict__ desc, size_t desc_stride, int words) {
+    uint32_t *__restrict__ desc, size_t desc_stride, int words, uint32_t *__restrict__ ovf_reset) {
   extern __shared__ __attribute__((aligned(16))) uint8_t osm[];
   __shared__ uint32_t wsum[4];
   __shared__ uint32_t carry;
+  // the overflow list of this step has been consumed (stream order): empty it for the next step
+  if (ovf_reset && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) ovf_reset[0] = 0;
   const int pyr = blockIdx.y, ch = blockIdx.x, nch = gridDim.x;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);

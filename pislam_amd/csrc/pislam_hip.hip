@@ -85,7 +85,7 @@ struct pislam_ctx {
   // compaction scratch (shared by extract and the batch pipeline)
   DevBuf w_cnt, w_off, w_total, w_cellkp;
   // batch pipeline workspace
-  DevBuf w_score, w_stage, w_stripcnt, w_work, w_prof;
+  DevBuf w_score, w_stage, w_stripcnt, w_work, w_prof, w_ovf;
   int num_cus = 0;
   const void *pyr_zeroed = nullptr;   // pyramid buffer whose padding is known to be in its defined state
   size_t pyr_zeroed_sig = 0;
@@ -94,6 +94,7 @@ struct pislam_ctx {
   int opt_strip_rows = 0;    // fused pipeline: strip height override (0 = heuristic)
   int opt_ablate = 0;        // profiling only: skip phases of the fused kernel (results invalid)
   int opt_orb_chunks = 0;    // fused pipeline: workgroups per pyramid in k_gather_orb (0 = heuristic)
+  int opt_alias = 1;         // fused pipeline: score tile laid over the dead image rows (0 = separate tiles)
   int opt_run_len = 0;       // fused pipeline: strips per workgroup run (0 = default, 1 = independent strips)
   int opt_xtile_cols = 0;    // fused pipeline: max classified columns per image x-tile (0 = full width)
   int opt_lds_pad = 0;       // profiling only: extra dynamic LDS bytes per strip workgroup
@@ -370,7 +371,7 @@ PISLAM_EXPORT int pislam_ctx_destroy(pislam_ctx *c) {
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
   for (DevBuf *b : {&c->s_img, &c->s_out, &c->s_pts, &c->s_desc, &c->s_misc, &c->s_rots, &c->s_tmp, &c->w_cnt,
-                    &c->w_off, &c->w_total, &c->w_cellkp, &c->w_score, &c->w_stage, &c->w_stripcnt, &c->w_work, &c->w_prof})
+                    &c->w_off, &c->w_total, &c->w_cellkp, &c->w_score, &c->w_stage, &c->w_stripcnt, &c->w_work, &c->w_prof, &c->w_ovf})
     b->release();
   for (auto &e : c->ev)
     if (e) (void)hipEventDestroy(e);
@@ -394,6 +395,8 @@ PISLAM_EXPORT int pislam_ctx_set_option(pislam_ctx *c, const char *key, int valu
   } else if (!strcmp(key, "xtile_cols")) {
     if (value > 0 && value < 64) return fail(c, PISLAM_ERR_INVALID, "xtile_cols must be 0 (full width), >= 64, or negative (default)");
     c->opt_xtile_cols = value < 0 ? 0 : value;   // (the default is set in one place: here)
+  } else if (!strcmp(key, "alias")) {
+    c->opt_alias = value != 0;
   } else if (!strcmp(key, "run_len")) {
     if (value < 0 || value > 64) return fail(c, PISLAM_ERR_INVALID, "run_len must be 0 (default) .. 64");
     c->opt_run_len = value;
@@ -832,7 +835,7 @@ namespace {
 // Strip plan of the fused pipeline.  Strip height per level: aim at ~8k pixels per workgroup,
 // even, 16..32 rows (override: option "strip_rows").
 bool build_fused_plan(const pislam_ctx *c, const pislam_frontend_params *p, const pislam_level *lv,
-                      int batch, pf::FusedParams *F, size_t *lds_bytes) {
+                      int batch, pf::FusedParams *F, size_t *lds_bytes, size_t *lds_alias_bytes) {
   if (p->nlevels > pf::MAX_LEVELS) return false;
   memset(F, 0, sizeof(*F));
   F->nlevels = p->nlevels;
@@ -849,7 +852,7 @@ bool build_fused_plan(const pislam_ctx *c, const pislam_frontend_params *p, cons
   if (p->log_bucket_size != 0 && (p->log_bucket_size < 2 || p->log_bucket_size > 5)) return false;
   F->ablate = c->opt_ablate;
   int strips = 0, slots = 0, runs = 0;
-  size_t lds = 0;
+  size_t lds = 0, lds_alias = 0;
   for (int l = 0; l < p->nlevels; l++) {
     pf::FusedLevel &L = F->lv[l];
     L.w = lv[l].width;
@@ -903,8 +906,18 @@ bool build_fused_plan(const pislam_ctx *c, const pislam_frontend_params *p, cons
     L.vpr_recip = (uint32_t)(((1ull << 32) + (L.tpitch / 16) - 1) / (L.tpitch / 16));
     strips += L.nstrips;
     slots += L.nstrips * (R / 2) * L.nbx;
-    lds = std::max(lds, (size_t)(R + 10) * L.tpitch + (size_t)(R + 3) * L.pitch +
+    L.tbytes = std::max((R + 10) * L.tpitch, (((R / 2) * L.nbx * 4) + 15) & ~15);
+    lds = std::max(lds, (size_t)L.tbytes + (size_t)(R + 3) * L.pitch +
                             (pf::WAVES * pf::QCAP + pf::SHARED_Q) * sizeof(uint32_t));
+    {
+      // ALIAS layout: the score tile (R+3 rows) is laid over [NMS scratch end, image row R): pad the
+      // per-wave queue area when that span is too short (levels wider than ~680 columns)
+      const long need = (long)pf::NMS_SCRATCH * 4 + (long)(R + 3) * L.pitch;
+      const long have = (long)pf::WAVES * pf::QCAP * 4 + (long)R * L.tpitch;
+      L.apad = need > have ? (int)((need - have + 15) & ~15L) : 0;
+      lds_alias = std::max(lds_alias, (size_t)pf::WAVES * pf::QCAP * 4 + (size_t)L.apad + (size_t)(R + 10) * L.tpitch +
+                                          (size_t)pf::SHARED_Q * 4);
+    }
   }
   // Runs: a workgroup walks run_len consecutive strips of a level (halo carried in LDS).  Longer runs
   // save the duplicated halo work but leave fewer workgroups; keep >= ~3 per resident slot
@@ -920,11 +933,12 @@ bool build_fused_plan(const pislam_ctx *c, const pislam_frontend_params *p, cons
   F->strips_per_pyr = strips;
   F->runs_per_pyr = runs;
   F->slots_per_pyr = slots;
-  *lds_bytes = lds + (size_t)c->opt_lds_pad;     // profiling: opt_lds_pad lowers the residency artificially
+  *lds_bytes = lds;
+  *lds_alias_bytes = lds_alias + (size_t)c->opt_lds_pad;   // profiling: opt_lds_pad lowers the residency artificially
   return strips > 0 && lds <= 150 * 1024;
 }
 
-int run_fused(pislam_ctx *c, const pislam_frontend_params *p, const pf::FusedParams &F, size_t lds,
+int run_fused(pislam_ctx *c, const pislam_frontend_params *p, const pf::FusedParams &F, size_t lds, size_t lds_alias,
               const uint8_t *pyramids, size_t stride, int batch, uint32_t *kp, uint32_t *desc, uint32_t *counts) {
   if (c->w_stage.ensure(sizeof(uint32_t) * (size_t)F.slots_per_pyr * batch) != PISLAM_OK ||
       c->w_stripcnt.ensure(sizeof(uint32_t) * (size_t)F.strips_per_pyr * batch) != PISLAM_OK)
@@ -935,13 +949,33 @@ int run_fused(pislam_ctx *c, const pislam_frontend_params *p, const pf::FusedPar
   const int groups = cdiv(batch, 8);
   uint8_t *dump = F.dump_score ? c->w_score.as<uint8_t>() : nullptr;
   const size_t dump_stride = (size_t)p->rows * p->vstep;
+  // ALIAS layout (score tile laid over the dead image rows, 26 KB instead of 39 KB of LDS per workgroup
+  // at VGA): the default.  Its overflow list (strips with overflowing queues) is drained by
+  // k_fused_overflow right after; the gather kernel empties the list for the next step.
+  const bool alias = c->opt_alias && batch <= 65535 && F.strips_per_pyr <= 65535;
+  uint32_t *ovf = nullptr;
+  if (alias) {
+    bool grew = false;
+    if (c->w_ovf.ensure(sizeof(uint32_t) * ((size_t)F.strips_per_pyr * batch + 1), &grew) != PISLAM_OK)
+      return fail(c, PISLAM_ERR_NOMEM, "hipMalloc(overflow list)");
+    ovf = c->w_ovf.as<uint32_t>();
+    if (grew) HIPCHK(c, hipMemsetAsync(ovf, 0, sizeof(uint32_t), c->stream));
+  }
   {
-    // HOOKS instantiation: score-map dump (debug / parity hook) and the profiling ablations
+    // HOOKS instantiations: score-map dump (debug / parity hook) and the profiling ablations
     const bool hooks = F.dump_score || F.ablate;
-    auto kern = vec ? (hooks ? pf::k_fused_strips<true, true> : pf::k_fused_strips<true, false>)
-                    : (hooks ? pf::k_fused_strips<false, true> : pf::k_fused_strips<false, false>);
-    if (lds > 64 * 1024)
-      HIPCHK(c, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    using KernT = void (*)(const pf::FusedParams, const uint8_t *, size_t, uint32_t *, uint32_t *, uint8_t *, size_t,
+                           unsigned long long *, uint32_t *);
+    static const KernT kerns[8] = {
+        pf::k_fused_strips<false, false, false>, pf::k_fused_strips<false, false, true>,
+        pf::k_fused_strips<false, true, false>,  pf::k_fused_strips<false, true, true>,
+        pf::k_fused_strips<true, false, false>,  pf::k_fused_strips<true, false, true>,
+        pf::k_fused_strips<true, true, false>,   pf::k_fused_strips<true, true, true>};
+    const KernT kern = kerns[(vec ? 4 : 0) | (hooks ? 2 : 0) | (alias ? 1 : 0)];
+    const size_t klds = alias ? lds_alias : lds;
+    if (klds > 150 * 1024) return fail(c, PISLAM_ERR_INVALID, "level too wide for the strip kernel's LDS tiles");
+    if (klds > 64 * 1024)
+      HIPCHK(c, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)klds));
     const dim3 grid((unsigned)(groups * F.runs_per_pyr * 8));
     unsigned long long *prof = nullptr;
     const size_t prof_n = (size_t)grid.x * 8;
@@ -950,8 +984,8 @@ int run_fused(pislam_ctx *c, const pislam_frontend_params *p, const pf::FusedPar
       prof = c->w_prof.as<unsigned long long>();
       HIPCHK(c, hipMemsetAsync(prof, 0, prof_n * sizeof(unsigned long long), c->stream));
     }
-    hipLaunchKernelGGL(kern, grid, dim3(pf::NT), lds, c->stream, F, pyramids, stride, c->w_stage.as<uint32_t>(),
-                       c->w_stripcnt.as<uint32_t>(), dump, dump_stride, prof);
+    hipLaunchKernelGGL(kern, grid, dim3(pf::NT), klds, c->stream, F, pyramids, stride, c->w_stage.as<uint32_t>(),
+                       c->w_stripcnt.as<uint32_t>(), dump, dump_stride, prof, ovf);
     if (prof) {
       std::vector<unsigned long long> hv(prof_n);
       HIPCHK(c, hipMemcpyAsync(hv.data(), prof, prof_n * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
@@ -964,6 +998,19 @@ int run_fused(pislam_ctx *c, const pislam_frontend_params *p, const pf::FusedPar
               h[0] / n, h[1] / n, h[2] / n, h[3] / n, h[4] / n, n, h[6], grid.x, h[7] / n);
     }
     PCHK(launch_ok(c, "k_fused_strips"));
+    if (alias) {
+      using OvfT = void (*)(const pf::FusedParams, const uint8_t *, size_t, uint32_t *, uint32_t *, uint8_t *, size_t,
+                            const uint32_t *);
+      static const OvfT okerns[4] = {pf::k_fused_overflow<false, false>, pf::k_fused_overflow<false, true>,
+                                     pf::k_fused_overflow<true, false>, pf::k_fused_overflow<true, true>};
+      const OvfT okern = okerns[(vec ? 2 : 0) | (hooks ? 1 : 0)];
+      if (lds > 64 * 1024)
+        HIPCHK(c, hipFuncSetAttribute((const void *)okern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL(okern, dim3((unsigned)(2 * std::max(1, c->num_cus))), dim3(pf::NT), lds, c->stream, F, pyramids,
+                         stride, c->w_stage.as<uint32_t>(), c->w_stripcnt.as<uint32_t>(), dump, dump_stride,
+                         (const uint32_t *)ovf);
+      PCHK(launch_ok(c, "k_fused_overflow"));
+    }
   }
   HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
   HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
@@ -972,7 +1019,7 @@ int run_fused(pislam_ctx *c, const pislam_frontend_params *p, const pf::FusedPar
     // other strides take the generic gather + per-keypoint ORB kernels.
     hipLaunchKernelGGL(pf::k_gather, dim3(batch), dim3(256), sizeof(uint32_t) * (F.strips_per_pyr + 1), c->stream,
                        F, c->w_stage.as<uint32_t>(), c->w_stripcnt.as<uint32_t>(), kp, (size_t)p->max_keypoints,
-                       (uint32_t)p->max_keypoints, counts);
+                       (uint32_t)p->max_keypoints, counts, ovf);
     PCHK(launch_ok(c, "k_gather"));
     hipLaunchKernelGGL(pk::k_orb<0>, dim3(cdiv(p->max_keypoints, 4), 1, batch), dim3(256), 0, c->stream,
                        pyramids, p->vstep, stride, kp, (size_t)p->max_keypoints, counts, 0u,
@@ -991,7 +1038,7 @@ int run_fused(pislam_ctx *c, const pislam_frontend_params *p, const pf::FusedPar
     HIPCHK(c, hipFuncSetAttribute((const void *)pf::k_gather_orb, hipFuncAttributeMaxDynamicSharedMemorySize, (int)olds));
   hipLaunchKernelGGL(pf::k_gather_orb, dim3(nch, batch), dim3(256), olds, c->stream, F, pyramids, stride,
                      c->w_stage.as<uint32_t>(), c->w_stripcnt.as<uint32_t>(), kp, (size_t)p->max_keypoints,
-                     (uint32_t)p->max_keypoints, counts, desc, (size_t)p->max_keypoints * p->words, p->words);
+                     (uint32_t)p->max_keypoints, counts, desc, (size_t)p->max_keypoints * p->words, p->words, ovf);
   PCHK(launch_ok(c, "k_gather_orb"));
   return PISLAM_OK;
 }
@@ -1051,13 +1098,14 @@ PISLAM_EXPORT int pislam_orb_frontend_batch(pislam_ctx *c, const pislam_frontend
   c->last_stride = pyr_bytes;
   pf::FusedParams F;
   size_t lds = 0;
-  bool fused = c->opt_pipeline != 1 && build_fused_plan(c, p, lv, batch, &F, &lds);
+  size_t lds_alias = 0;
+  bool fused = c->opt_pipeline != 1 && build_fused_plan(c, p, lv, batch, &F, &lds, &lds_alias);
   if (c->opt_pipeline >= 2 && !fused)
     return fail(c, PISLAM_ERR_INVALID, "fused pipeline unavailable for these parameters (bucket size / LDS size)");
   c->last_pipeline = fused ? 2 : 1;
   HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
   if (fused) {
-    PCHK(run_fused(c, p, F, lds, pyramids, stride, batch, kp, desc, counts));
+    PCHK(run_fused(c, p, F, lds, lds_alias, pyramids, stride, batch, kp, desc, counts));
   } else {
   HIPCHK(c, hipMemsetAsync(counts, 0, sizeof(uint32_t) * batch, c->stream));
   // The score map workspace is laid out with stride pyr_bytes; the image with `stride`.  The stage

@@ -209,24 +209,36 @@ def test_fused_strip_heights(gpu_ctx, orc, strip_rows, xtile_cols, run_len):
     gpu_ctx.set_option("xtile_cols", xtile_cols)
     gpu_ctx.set_option("run_len", run_len)
     try:
-        fe = OrbFrontend(levels, vstep=640, rows=2210, max_keypoints=4096, ctx=gpu_ctx)
-        kp, desc, counts = fe.alloc_outputs(3, dev)
-        fe(torch.from_numpy(pyr).to(dev), kp, desc, counts)
-        torch.cuda.synchronize()
-        c = counts.cpu().numpy().view(np.uint32)
-        k = kp.cpu().numpy().view(np.uint32)
-        d = desc.cpu().numpy().view(np.uint32)
-        for b in range(3):
-            okp, odesc, _, osc = orc.pyramid(pyr[b], levels, return_score=True)
-            assert c[b] == len(okp)
-            assert (k[b, :c[b]] == okp).all() and (d[b, :c[b]] == odesc).all()
-            assert (fe.score_map(b) == osc).all()
+        ref = [orc.pyramid(pyr[b], levels, return_score=True) for b in range(3)]
+        # alias: score tile laid over the dead image rows (default) / separate tiles; dump: HOOKS kernels
+        # (score map compared too) / the product instantiation; ablate 512: every strip is forced onto
+        # the overflow list and redone by k_fused_overflow with the scan fallbacks
+        for alias, dump, ablate in [(1, 1, 0), (1, 0, 0), (0, 1, 0), (0, 0, 0), (1, 1, 512), (0, 1, 512)]:
+            gpu_ctx.set_option("alias", alias)
+            gpu_ctx.set_option("dump_score", dump)
+            gpu_ctx.set_option("ablate", ablate)
+            fe = OrbFrontend(levels, vstep=640, rows=2210, max_keypoints=4096, ctx=gpu_ctx)
+            kp, desc, counts = fe.alloc_outputs(3, dev)
+            for rep in range(2):          # twice: the overflow list must be emptied between steps
+                fe(torch.from_numpy(pyr).to(dev), kp, desc, counts)
+            torch.cuda.synchronize()
+            c = counts.cpu().numpy().view(np.uint32)
+            k = kp.cpu().numpy().view(np.uint32)
+            d = desc.cpu().numpy().view(np.uint32)
+            for b in range(3):
+                okp, odesc, _, osc = ref[b]
+                assert c[b] == len(okp), (alias, dump, ablate)
+                assert (k[b, :c[b]] == okp).all() and (d[b, :c[b]] == odesc).all(), (alias, dump, ablate)
+                if dump:
+                    assert (fe.score_map(b) == osc).all(), (alias, dump, ablate)
     finally:
         gpu_ctx.set_option("pipeline", 0)
         gpu_ctx.set_option("dump_score", 0)
         gpu_ctx.set_option("strip_rows", 0)
         gpu_ctx.set_option("xtile_cols", -1)
         gpu_ctx.set_option("run_len", 0)
+        gpu_ctx.set_option("alias", 1)
+        gpu_ctx.set_option("ablate", 0)
 
 
 def test_fused_odd_shapes_and_unaligned_layouts(gpu_ctx, orc):
