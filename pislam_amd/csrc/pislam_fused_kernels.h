@@ -458,29 +458,43 @@ __device__ __forceinline__ void strip_body(const StripArgs A, const FusedLevel L
     // byte-wise SADs of the group against the rows 3 above/below and the columns 3 left/right must
     // exceed t on both axes (v_sad_u8 sums |a-b| over the 4 bytes, an upper bound of each term).
     const int xs = cxa & ~3;                        // dword-aligned start column of this x-tile
-    for (int r = r_lo + wave; r < r_hi; r += WAVES) {
-      const lds_u8 *trow = tile + (r + 3) * tpitch;
-      for (int cx = xs; cx < cxb; cx += 256) {
-        const int x0 = cx + 4 * lane;
-        // aligned dword reads; lanes past the tile's columns read harmless bytes of the next tile row
-        const uint32_t wc = *(const lds_u32 *)(trow + x0);
-        const uint32_t wl = *(const lds_u32 *)(trow + x0 - 4);
-        const uint32_t wr = *(const lds_u32 *)(trow + x0 + 4);
-        const uint32_t wu = *(const lds_u32 *)(trow + x0 - 3 * tpitch);
-        const uint32_t wd = *(const lds_u32 *)(trow + x0 + 3 * tpitch);
-        const uint32_t sv = max(__builtin_amdgcn_sad_u8(wu, wc, 0u), __builtin_amdgcn_sad_u8(wd, wc, 0u));
-        const uint32_t sh = max(__builtin_amdgcn_sad_u8(__builtin_amdgcn_alignbyte(wc, wl, 1), wc, 0u),
-                                __builtin_amdgcn_sad_u8(__builtin_amdgcn_alignbyte(wr, wc, 3), wc, 0u));
-        const bool g = (min(sv, sh) > (uint32_t)thr) && (x0 < cxb);
-        const uint64_t m = __ballot(g);
-        if (m == 0) continue;
-        if (g) qg[ng + ballot_rank(m)] = pack_xy(x0, r);
-        ng += __popcll(m);
-        if (ng >= 64) {
-          ng -= 64;
-          if (!(ablate & 16)) pretest_batch(true, qg[ng + lane]);
-        }
+    // One lane = one 4-pixel group, 256 columns per wave step: `nfull` steps with all lanes inside the
+    // tile's columns and one tail step with the lanes past cxb masked off, so that the full steps need
+    // no per-lane bounds test (their compare lands directly in VCC = the ballot).
+    const int nfull = (cxb - xs) >> 8, rem = (cxb - xs) & 255;
+    const bool tail_lane = 4 * lane < rem;
+    auto prefilter_step = [&](const lds_u8 *pc, const lds_u8 *pu, const lds_u8 *pd, bool lane_ok, int xrow) {
+      // aligned dword reads; lanes past the tile's columns read harmless bytes of the next tile row
+      const uint32_t wc = *(const lds_u32 *)pc;
+      const uint32_t wl = *(const lds_u32 *)(pc - 4);
+      const uint32_t wr = *(const lds_u32 *)(pc + 4);
+      const uint32_t wu = *(const lds_u32 *)pu;
+      const uint32_t wd = *(const lds_u32 *)pd;
+      const uint32_t sv = max(__builtin_amdgcn_sad_u8(wu, wc, 0u), __builtin_amdgcn_sad_u8(wd, wc, 0u));
+      const uint32_t sh = max(__builtin_amdgcn_sad_u8(__builtin_amdgcn_alignbyte(wc, wl, 1), wc, 0u),
+                              __builtin_amdgcn_sad_u8(__builtin_amdgcn_alignbyte(wr, wc, 3), wc, 0u));
+      const bool g = lane_ok && (min(sv, sh) > (uint32_t)thr);
+      const uint64_t m = __ballot(g);
+      if (m == 0) return;
+      if (g) qg[ng + ballot_rank(m)] = (uint32_t)(xrow + 4 * lane);   // pack_xy(x0, r)
+      ng += __popcll(m);
+      if (ng >= 64) {
+        ng -= 64;
+        if (!(ablate & 16)) pretest_batch(true, qg[ng + lane]);
       }
+    };
+    for (int r = r_lo + wave; r < r_hi; r += WAVES) {
+      const lds_u8 *pc = tile + (r + 3) * tpitch + xs + 4 * lane;
+      const lds_u8 *pu = pc - 3 * tpitch, *pd = pc + 3 * tpitch;
+      int xrow = (int)pack_xy(xs, r);               // wave-uniform: column of lane 0 | row << 16
+      for (int it = 0; it < nfull; it++) {
+        prefilter_step(pc, pu, pd, true, xrow);
+        pc += 256;
+        pu += 256;
+        pd += 256;
+        xrow += 256;
+      }
+      if (rem) prefilter_step(pc, pu, pd, tail_lane, xrow);
     }
     if (ng > 0 && !(ablate & 16)) pretest_batch(lane < ng, lane < ng ? qg[lane] : pack_xy(xs, r_lo));
     ng = 0;
