@@ -224,7 +224,7 @@ def main():
         launch_ms = ev_stage_ms[0] if fused else ev_total_ms
         achieved = b_alg_launch / (launch_ms * 1e-3) / 1e9
         traffic = None                                  # HBM bytes per launch from the committed PMC passes
-        tpath = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
+        tpath = os.path.join(ROOT, "profiles", "r01f_hbm_traffic.json")
         if fused and B == 256 and args.workload == "vga" and not args.log_bucket_size and os.path.exists(tpath):
             try:
                 traffic = json.load(open(tpath))["kernels"]["k_fused_strips"]["hbm_bytes_per_launch"]
