@@ -259,7 +259,8 @@ def main():
                           else "whole staged step (all launches)",
                 "algorithmic_bytes_per_launch": b_alg_launch, "launch_ms": launch_ms,
                 "step_gpu_ms": ev_total_ms,
-                "stage_ms": {"detect+score+nms": ev_stage_ms[0], "gather": ev_stage_ms[1], "orb": ev_stage_ms[2]},
+                "stage_ms": {"detect+score+nms": ev_stage_ms[0], "overflow pass" if fused else "extract": ev_stage_ms[1],
+                             "gather+orb" if fused else "orb": ev_stage_ms[2]},
             },
         }
         if world == 1 and not args.no_cpu_baseline and all(len(t) < 4 or t[3] == 0 for t in levels):

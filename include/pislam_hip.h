@@ -206,7 +206,9 @@ int pislam_frontend_get_score_map(pislam_ctx *ctx, int b, uint8_t *dst);
 
 /* Elapsed milliseconds of the LAST pislam_orb_frontend_batch call on this ctx,
  * measured with hipEvents recorded on the ctx stream around its kernels
- * (total, and per internal stage: 0 detect+score, 1 extract, 2 orb).
+ * (total, and per internal stage — staged pipeline: 0 detect+score, 1 extract,
+ * 2 orb; fused pipeline: 0 strip kernel (detect+score+extract), 1 overflow
+ * pass, 2 gather+orb).
  * Synchronises on the end event. */
 int pislam_frontend_last_timing(pislam_ctx *ctx, float *total_ms, float stage_ms[3]);
 

@@ -1007,6 +1007,7 @@ int run_fused(pislam_ctx *c, const pislam_frontend_params *p, const pf::FusedPar
               h[0] / n, h[1] / n, h[2] / n, h[3] / n, h[4] / n, n, h[6], grid.x, h[7] / n);
     }
     PCHK(launch_ok(c, "k_fused_strips"));
+    HIPCHK(c, hipEventRecord(c->ev[1], c->stream));     // stage 0 = the strip kernel alone
     if (alias) {
       using OvfT = void (*)(const pf::FusedParams, const uint8_t *, size_t, uint32_t *, uint32_t *, uint8_t *, size_t,
                             const uint32_t *);
@@ -1015,14 +1016,13 @@ int run_fused(pislam_ctx *c, const pislam_frontend_params *p, const pf::FusedPar
       const OvfT okern = okerns[(vec ? 2 : 0) | (hooks ? 1 : 0)];
       if (lds > 64 * 1024)
         HIPCHK(c, hipFuncSetAttribute((const void *)okern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      hipLaunchKernelGGL(okern, dim3((unsigned)(2 * std::max(1, c->num_cus))), dim3(pf::NT), lds, c->stream, F, pyramids,
+      hipLaunchKernelGGL(okern, dim3((unsigned)std::max(8, c->num_cus / 2)), dim3(pf::NT), lds, c->stream, F, pyramids,
                          stride, c->w_stage.as<uint32_t>(), c->w_stripcnt.as<uint32_t>(), dump, dump_stride,
                          (const uint32_t *)ovf);
       PCHK(launch_ok(c, "k_fused_overflow"));
     }
   }
-  HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
-  HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
+  HIPCHK(c, hipEventRecord(c->ev[2], c->stream));       // stage 1 = the overflow pass (normally empty)
   if (p->vstep % 16 != 0) {
     // k_gather_orb's 48-byte row windows assume a row-independent byte shift (vstep % 16 == 0);
     // other strides take the generic gather + per-keypoint ORB kernels.
