@@ -208,6 +208,7 @@ def main():
                       "matched_within_64_bits": int(((m_out[1] <= 64) & (torch.arange(args.max_keypoints, device=dev)[None, :]
                                                                           < cq[:, None])).sum().item())}
 
+    deferred, nstrips = fe.last_stats()
     total_kp_step = int(allc.to(torch.int64).sum().item())          # all ranks, one step
     local_kp = int(counts.to(torch.int64).sum().item())
     value = total_kp_step * args.steps / dt
@@ -250,6 +251,7 @@ def main():
                 "pyramids_per_s": B * world * args.steps / dt,
                 "parallelism": f"pyramid-shard x{world}, RCCL all-gather of counts" if world > 1 else "single GPU",
                 "pipeline": "fused" if fused else "staged",
+                "strips_redone_by_overflow_pass": f"{deferred} of {nstrips}",
                 **({"match_inside_step": match_info} if match_info else {}),
             },
             "roofline": {

@@ -212,6 +212,13 @@ int pislam_frontend_get_score_map(pislam_ctx *ctx, int b, uint8_t *dst);
  * Synchronises on the end event. */
 int pislam_frontend_last_timing(pislam_ctx *ctx, float *total_ms, float stage_ms[3]);
 
+/* Diagnostics of the last pislam_orb_frontend_batch call on the fused pipeline:
+ * stats[0] = strips whose on-chip queues overflowed (very dense corners) and
+ * that were redone by the slower overflow pass, stats[1] = strips in the call.
+ * Results are identical either way; a large ratio means the input is denser
+ * than the fast path is sized for.  Synchronises the context stream. */
+int pislam_frontend_last_stats(pislam_ctx *ctx, uint32_t stats[2]);
+
 /* ---- descriptor matching ---------------------------- */
 
 /* The reference ships no matcher (README.md:125-128 only names matching as

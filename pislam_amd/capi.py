@@ -62,6 +62,7 @@ SYMBOLS = {
     "pislam_frontend_get_score_map": (_i, [_vp, _i, _vp]),
     "pislam_frontend_last_timing": (_i, [_vp, ctypes.POINTER(ctypes.c_float),
                                          ctypes.POINTER(ctypes.c_float * 3)]),
+    "pislam_frontend_last_stats": (_i, [_vp, ctypes.POINTER(ctypes.c_uint32 * 2)]),
     "pislam_match_hamming": (_i, [_vp, _i, _vp, _sz, _vp, _sz, _vp, _vp, _vp]),
     "pislam_match_hamming_batch": (_i, [_vp, _i, _vp, _vp, _sz, _vp, _vp, _sz, _i, _vp, _vp, _vp]),
 }

@@ -40,7 +40,8 @@ constexpr int NT = WAVES * 64;         // threads per strip workgroup
 constexpr int QCAP_G = 128;            // 4-pixel groups that passed the SAD prefilter (< 64 before a <= 64 push)
 constexpr int QCAP_F = 192;            // FAST candidates (< 64 before a <= 128 half-push)
 constexpr int QCAP = QCAP_G + QCAP_F;  // dwords of private queue space per wave
-constexpr int QH_SHARED = 512;         // workgroup-shared queue of corners awaiting their Harris score
+constexpr int QH_SHARED = 1024;        // workgroup-shared queue of corners awaiting their Harris score (a 28-row
+                                       // strip of a textured photo holds up to ~900: the reference's demo image)
 constexpr int QN_SHARED = 512;         // workgroup-shared queue of pixels with a non-zero score (NMS candidates)
 constexpr int QS_SHARED = 256;         // survivors of one strip awaiting their rank (lives in the dead image tile)
 constexpr int SHARED_Q = QH_SHARED + QN_SHARED;
@@ -124,12 +125,14 @@ __device__ __forceinline__ void pretest_pk(uint32_t c, uint32_t u, uint32_t d, u
   dark = as_u32(b - lo);
 }
 
-// Rare path (shared corner queue full): score the flagged lanes right away.  Kept out of line so
-// that the hot loops of the kernel do not carry a second inlined copy of the Harris arithmetic.
+// Rare path of the plain layout (shared corner queue full): score the flagged lanes right away.  Kept
+// out of line so that the hot loops of the kernel do not carry a second inlined copy of the Harris
+// arithmetic.  (Returning the score to push it as an NMS candidate instead was measured: the call then
+// keeps 11 more VGPRs live in the caller and costs a resident workgroup.)
 __device__ __attribute__((noinline)) void harris_overflow(lds_u8 *tile, lds_u8 *sc, int tpitch, int pitch, int32_t hthr,
                                                           bool valid, uint32_t e) {
   if (valid) {
-    const int x = e & 0xffff, r = e >> 16;
+    const int x = e & 0xffff, r = (e >> 16) & 0xff;
     sc[r * pitch + x] = harris_score_pk(tile + r * tpitch + x - 3, tpitch, hthr);
   }
 }
@@ -189,17 +192,20 @@ __device__ __forceinline__ void strip_body(const StripArgs A, const FusedLevel L
       for (int i = tid; i < nvs; i += NT) ((lds_u4 *)sc)[i] = ((const lds_u4 *)(sc + R * pitch))[i];
     }
     if (wave == 0) {                                // in-place compaction of the candidate queue (front to back)
-      lds_u32 *qn = shq + QH_SHARED;
-      const int tn = (int)sh_ctr[2];
+      // plain: the queue of non-zero scores; ALIAS: the one queue of corners, whose entries carry their
+      // score in the top byte (0 = scored below the threshold: dropped here)
+      lds_u32 *qn = ALIAS ? shq : shq + QH_SHARED;
+      const int tn = (int)sh_ctr[ALIAS ? 0 : 2];
       int kept = 0;
       for (int c0 = 0; c0 < tn; c0 += 64) {
         const uint32_t e = qn[min(c0 + lane, tn - 1)];
-        const bool k = c0 + lane < tn && (int)((e >> 16) & 0xff) >= R;
+        const bool k = c0 + lane < tn && (int)((e >> 16) & 0xff) >= R && (!ALIAS || (e >> 24) != 0);
         const uint64_t m = __ballot(k);
         if (k) qn[kept + ballot_rank(m)] = e - ((uint32_t)R << 16);
         kept += __popcll(m);
       }
-      if (lane < 8) sh_ctr[lane] = lane == 1 ? QH_SHARED : lane == 2 ? (uint32_t)kept : 0u;
+      if (lane < 8)
+        sh_ctr[lane] = lane == 1 ? QH_SHARED : (lane == 2 || (ALIAS && lane == 0)) ? (uint32_t)kept : 0u;
     }
     lds_barrier();
     if (!ALIAS) {
@@ -246,19 +252,24 @@ __device__ __forceinline__ void strip_body(const StripArgs A, const FusedLevel L
         if (nz) shq_n[base + ballot_rank(m)] = e;
       } else if (lane == 0) {
         sh_ctr[3] = 1;
+        sh_ctr[7] |= 2;                             // (reason, for the profiling line)
       }
     }
   };
-  auto harris_batch = [&](bool valid, uint32_t e) {
+  // plain layout: corners -> shq_h, Harris writes the score tile and queues the non-zero scores in shq_n.
+  // ALIAS layout: ONE queue (shq_h, QH_SHARED entries) whose entries carry their score in the top byte:
+  // FAST appends corners with score 0 and over-classified pixels with 0xff, Harris scores the entries
+  // appended since `h_begin` in place, the strip above leaves its carried entries at the front.
+  auto harris_batch = [&](bool valid, uint32_t e, int at) {
     uint8_t score = 0;
-    if (valid) {
-      const int x = e & 0xffff, r = e >> 16;
+    const bool todo = valid && (!ALIAS || (e >> 24) == 0);
+    if (todo) {
+      const int x = e & 0xffff, r = (e >> 16) & 0xff;
       score = (ablate & 32) ? (uint8_t)200 : harris_score_pk(tile + r * tpitch + x - 3, tpitch, hthr);
-      if (!ALIAS) sc[r * pitch + x] = score;
+      if (ALIAS) shq_h[at] = e | ((uint32_t)score << 24);
+      else sc[r * pitch + x] = score;
     }
-    // ALIAS: the score tile does not exist yet (it will overlay the image tile once Harris is done), the
-    // score travels in the top byte of the queue entry
-    push_nonzero(score != 0, ALIAS ? e | ((uint32_t)score << 24) : e);
+    if (!ALIAS) push_nonzero(score != 0, e);
   };
   auto fast_batch = [&](bool valid, uint32_t e) {
     bool corner = false;
@@ -268,22 +279,26 @@ __device__ __forceinline__ void strip_body(const StripArgs A, const FusedLevel L
     if (valid) corner = fast9(tile + (r + 3) * tpitch + x, tpitch, thr);
     // Fast.h:172: only x < w-B is scored; over-classified columns keep 0xff
     const bool toh = corner && x < Lw - B;
-    if (!ALIAS && corner && !toh) sc[r * pitch + x] = 0xff;
-    push_nonzero(corner && !toh, ALIAS ? e | 0xff000000u : e);
-    const uint64_t m = __ballot(toh);
+    if (!ALIAS) {
+      if (corner && !toh) sc[r * pitch + x] = 0xff;
+      push_nonzero(corner && !toh, e);
+    }
+    const bool q = ALIAS ? corner : toh;
+    const uint64_t m = __ballot(q);
     if (m) {
       const int cnt = __popcll(m);
       int base = 0;
       if (lane == 0) base = (int)atomicAdd(&sh_ctr[0], (uint32_t)cnt);
       base = __builtin_amdgcn_readfirstlane(base);
       if (base + cnt <= QH_SHARED) {
-        if (toh) shq_h[base + ballot_rank(m)] = e;
-      } else {                                     // queue full: score these right away
+        if (q) shq_h[base + ballot_rank(m)] = (ALIAS && !toh) ? e | 0xff000000u : e;
+      } else {                                     // queue full
         if (lane == 0) {
-          atomicMin(&sh_ctr[1], (uint32_t)base);
-          sh_ctr[3] = 1;                           // their scores are not queued for NMS: scan instead
+          atomicMin(&sh_ctr[1], (uint32_t)base);   // entries below `base` stay valid
+          sh_ctr[3] = 1;                           // plain: their scores are not queued for NMS -> scan; ALIAS: defer
+          sh_ctr[7] |= 1;
         }
-        if (!ALIAS) harris_overflow(tile, sc, tpitch, pitch, hthr, toh, e);   // (ALIAS: the strip is deferred)
+        if (!ALIAS) harris_overflow(tile, sc, tpitch, pitch, hthr, toh, e);
       }
     }
   };
@@ -348,6 +363,8 @@ __device__ __forceinline__ void strip_body(const StripArgs A, const FusedLevel L
     }
   };
 
+  // ALIAS: entries [0, h_begin) of the queue are already scored (carried from the strip above)
+  int h_begin = 0;
   for (int xt = 0; xt < L.ntx; xt++) {
     cxa = B + xt * L.tcols;
     cxb = min(cxa + L.tcols, Lxend);
@@ -425,6 +442,7 @@ __device__ __forceinline__ void strip_body(const StripArgs A, const FusedLevel L
     }
     lds_barrier();
     mark(0);
+    if (ALIAS && xt == 0) h_begin = (int)sh_ctr[2]; // carried entries (sh_ctr[0] is already being appended to)
     // Prefetch the next strip's R new image rows (level rows ye+6 ..) into registers now: the loads are
     // in flight during this strip's classification and are only waited for when the next strip stores
     // them (lds_barrier does not wait for global loads).
@@ -506,11 +524,15 @@ __device__ __forceinline__ void strip_body(const StripArgs A, const FusedLevel L
     {
       const int th = (int)min(sh_ctr[0], sh_ctr[1]);
       if (!(ablate & 4))
-        for (int c0 = wave * 64; c0 < th; c0 += WAVES * 64) harris_batch(c0 + lane < th, shq_h[min(c0 + lane, th - 1)]);
+        for (int c0 = h_begin + wave * 64; c0 < th; c0 += WAVES * 64) {
+          const int at = min(c0 + lane, th - 1);
+          harris_batch(c0 + lane < th, shq_h[at], at);
+        }
+      if (ALIAS) h_begin = th;                      // the next x-tile's corners are appended behind these
     }
     lds_barrier();
     mark(2);
-    if (tid == 0) {                                 // fresh corner queue for the next x-tile
+    if (!ALIAS && tid == 0) {                       // fresh corner queue for the next x-tile
       sh_ctr[0] = 0;
       sh_ctr[1] = QH_SHARED;
     }
@@ -524,7 +546,9 @@ __device__ __forceinline__ void strip_body(const StripArgs A, const FusedLevel L
   auto defer = [&]() {
     if (tid == 0) {
       const uint32_t at = atomicAdd(&ovf[0], 1u);
-      ovf[1 + at] = ovf_id;
+      ovf[2 + at] = ovf_id;                         // [0] count, [1] count of the previous step, [2..] entries
+      if (HOOKS && prof) prof[5] += (sh_ctr[7] & 1 ? 1ull : 0ull) + (sh_ctr[7] & 2 ? 1ull << 20 : 0ull) +
+                                    (sh_ctr[7] & 4 ? 1ull << 40 : 0ull);
       sh_ctr[6] = 1;                                // the next strip of the run must not carry from this one
     }
   };
@@ -539,10 +563,10 @@ __device__ __forceinline__ void strip_body(const StripArgs A, const FusedLevel L
     const int nz = ((L.R + 3) * pitch) >> 4;
     for (int i = tid; i < nz; i += NT) ((lds_u4 *)sc)[i] = (u32x4)(0u);
     lds_barrier();
-    const int tn = (int)sh_ctr[2];
+    const int tn = (int)sh_ctr[0];
     for (int i = tid; i < tn; i += NT) {
-      const uint32_t e = shq_n[i];
-      sc[(int)((e >> 16) & 0xff) * pitch + (int)(e & 0xffff)] = (uint8_t)(e >> 24);
+      const uint32_t e = shq_h[i];
+      if (e >> 24) sc[(int)((e >> 16) & 0xff) * pitch + (int)(e & 0xffff)] = (uint8_t)(e >> 24);
     }
     lds_barrier();
   }
@@ -564,12 +588,13 @@ __device__ __forceinline__ void strip_body(const StripArgs A, const FusedLevel L
     lds_u32 *shq_s = queues;                        // survivors (packed keypoints) in the idle per-wave queues
                                                     // (the tiles stay intact for the next strip of the run)
     lds_u32 *shq_k = shq_s + QS_SHARED;            // their block-raster keys
-    const int tn = (int)sh_ctr[2];
+    const int tn = (int)sh_ctr[ALIAS ? 0 : 2];
+    const lds_u32 *nq = ALIAS ? shq_h : shq_n;      // ALIAS: the one queue; entries with score 0 are skipped
     const int own_rows = ye - ys;                   // owned score rows r = 1 .. own_rows
     const int xlimq = Lw - B;
     for (int c0 = wave * 64; c0 < tn; c0 += WAVES * 64) {
-      const bool valid = c0 + lane < tn;
-      const uint32_t e = shq_n[min(c0 + lane, tn - 1)];
+      const uint32_t e = nq[min(c0 + lane, tn - 1)];
+      const bool valid = c0 + lane < tn && (!ALIAS || (e >> 24) != 0);
       const int x = e & 0xffff, r = (e >> 16) & 0xff;
       const int bx = B + ((x - B) & ~1), rb = 1 + ((r - 1) & ~1);   // block origin (column, score row)
       const bool owned = valid && r >= 1 && r <= own_rows && bx < xlimq;
@@ -600,6 +625,7 @@ __device__ __forceinline__ void strip_body(const StripArgs A, const FusedLevel L
             shq_k[slot_i] = ((uint32_t)(decode_y(res) - B) >> 1) << 12 | ((uint32_t)(decode_x(res) - B) >> 1);
           }
         } else if (lane == 0) {
+          sh_ctr[7] |= 4;
           sh_ctr[3] = 2;                            // too many survivors for the ranking buffer
         }
       }
@@ -903,7 +929,7 @@ __global__ __launch_bounds__(NT) void k_fused_overflow(
 #pragma unroll
   for (int k = 0; k < PF_MAX; k++) pf[k] = (u32x4)(0u);
   for (uint32_t it = blockIdx.x; it < n; it += gridDim.x) {
-    const uint32_t id = ovf[1 + it];
+    const uint32_t id = ovf[2 + it];
     int pyr_o = (int)(id >> 16), sg_o = (int)(id & 0xffffu), tid_o = (int)threadIdx.x;
     asm volatile("" : "+s"(pyr_o), "+s"(sg_o));
     asm volatile("" : "+v"(tid_o));
@@ -941,7 +967,10 @@ __global__ __launch_bounds__(256) void k_gather(const FusedParams P,
   __shared__ uint32_t wsum[4];
   __shared__ uint32_t carry;
   // the overflow list of this step has been consumed (stream order): empty it for the next step
-  if (ovf_reset && blockIdx.x == 0 && threadIdx.x == 0) ovf_reset[0] = 0;
+  if (ovf_reset && blockIdx.x == 0 && threadIdx.x == 0) {
+    ovf_reset[1] = ovf_reset[0];                     // kept for pislam_frontend_last_stats
+    ovf_reset[0] = 0;
+  }
   const int pyr = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int S = P.strips_per_pyr;
   const uint32_t *cnt = strip_count + (size_t)pyr * S;
@@ -1026,7 +1055,10 @@ __global__ __launch_bounds__(256) void k_gather_orb(
   __shared__ uint32_t wsum[4];
   __shared__ uint32_t carry;
   // the overflow list of this step has been consumed (stream order): empty it for the next step
-  if (ovf_reset && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) ovf_reset[0] = 0;
+  if (ovf_reset && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+    ovf_reset[1] = ovf_reset[0];                     // kept for pislam_frontend_last_stats
+    ovf_reset[0] = 0;
+  }
   const int pyr = blockIdx.y, ch = blockIdx.x, nch = gridDim.x;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);

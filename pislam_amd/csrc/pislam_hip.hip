@@ -94,6 +94,7 @@ struct pislam_ctx {
   int opt_strip_rows = 0;    // fused pipeline: strip height override (0 = heuristic)
   int opt_ablate = 0;        // profiling only: skip phases of the fused kernel (results invalid)
   int opt_orb_chunks = 0;    // fused pipeline: workgroups per pyramid in k_gather_orb (0 = heuristic)
+  uint32_t last_strips = 0;  // strips of the last fused batch call (pislam_frontend_last_stats)
   int opt_alias = 1;         // fused pipeline: score tile laid over the dead image rows (0 = separate tiles)
   int opt_run_len = 0;       // fused pipeline: strips per workgroup run (0 = default, 1 = independent strips)
   int opt_xtile_cols = 0;    // fused pipeline: max classified columns per image x-tile (0 = full width)
@@ -878,7 +879,7 @@ bool build_fused_plan(const pislam_ctx *c, const pislam_frontend_params *p, cons
       // ALIAS layout (VGA: 24 rows at level 0, 28 below; measured 0.293 ms vs 0.311 ms with 16-row strips)
       R = std::min(28, std::max(16, (16384 / L.w) & ~1));
       const int tpitch_l = (xend_l - p->border + ((p->border - 4) & 15) + 4 + 8 + 15) & ~15;
-      const long budget = 160 * 1024 / 5 - (long)(pf::WAVES * pf::QCAP + pf::SHARED_Q) * 4;
+      const long budget = 160 * 1024 / 5 - (long)(pf::WAVES * pf::QCAP + pf::QH_SHARED) * 4;
       const int rcap = (int)(budget / tpitch_l - 10) & ~1;
       R = std::max(16, std::min(R, rcap));
     }
@@ -925,7 +926,7 @@ bool build_fused_plan(const pislam_ctx *c, const pislam_frontend_params *p, cons
       const long have = (long)pf::WAVES * pf::QCAP * 4 + (long)R * L.tpitch;
       L.apad = need > have ? (int)((need - have + 15) & ~15L) : 0;
       lds_alias = std::max(lds_alias, (size_t)pf::WAVES * pf::QCAP * 4 + (size_t)L.apad + (size_t)(R + 10) * L.tpitch +
-                                          (size_t)pf::SHARED_Q * 4);
+                                          (size_t)pf::QH_SHARED * 4);   // (one shared queue in this layout)
     }
   }
   // Runs: a workgroup walks run_len consecutive strips of a level (halo carried in LDS).  Longer runs
@@ -965,10 +966,11 @@ int run_fused(pislam_ctx *c, const pislam_frontend_params *p, const pf::FusedPar
   uint32_t *ovf = nullptr;
   if (alias) {
     bool grew = false;
-    if (c->w_ovf.ensure(sizeof(uint32_t) * ((size_t)F.strips_per_pyr * batch + 1), &grew) != PISLAM_OK)
+    if (c->w_ovf.ensure(sizeof(uint32_t) * ((size_t)F.strips_per_pyr * batch + 2), &grew) != PISLAM_OK)
       return fail(c, PISLAM_ERR_NOMEM, "hipMalloc(overflow list)");
     ovf = c->w_ovf.as<uint32_t>();
-    if (grew) HIPCHK(c, hipMemsetAsync(ovf, 0, sizeof(uint32_t), c->stream));
+    if (grew) HIPCHK(c, hipMemsetAsync(ovf, 0, 2 * sizeof(uint32_t), c->stream));
+    c->last_strips = (uint32_t)F.strips_per_pyr * (uint32_t)batch;
   }
   {
     // HOOKS instantiations: score-map dump (debug / parity hook) and the profiling ablations
@@ -1000,7 +1002,18 @@ int run_fused(pislam_ctx *c, const pislam_frontend_params *p, const pf::FusedPar
       HIPCHK(c, hipMemcpyAsync(hv.data(), prof, prof_n * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
       HIPCHK(c, hipStreamSynchronize(c->stream));
       double h[8] = {0};
-      for (size_t i = 0; i < prof_n; i++) h[i & 7] += (double)hv[i];
+      unsigned long long why[3] = {0, 0, 0};
+      for (size_t i = 0; i < prof_n; i++) {
+        if ((i & 7) == 5) {
+          why[0] += hv[i] & 0xfffff;
+          why[1] += (hv[i] >> 20) & 0xfffff;
+          why[2] += hv[i] >> 40;
+        } else {
+          h[i & 7] += (double)hv[i];
+        }
+      }
+      fprintf(stderr, "[pislam prof] deferred strips by reason: corner queue %llu, score queue %llu, survivor buffer %llu\n",
+              why[0], why[1], why[2]);
       const double n = (double)F.strips_per_pyr * batch;
       fprintf(stderr, "[pislam prof] cycles/strip: stage %.0f classify %.0f harris %.0f nms %.0f emit %.0f "
                       "(strips %.0f, carried %.0f, workgroups %u, lifetime %.0f/strip)\n",
@@ -1169,6 +1182,17 @@ PISLAM_EXPORT int pislam_frontend_get_score_map(pislam_ctx *c, int b, uint8_t *d
   HIPCHK(c, hipMemcpyAsync(dst, c->w_score.as<uint8_t>() + (size_t)b * bytes, bytes, hipMemcpyDefault,
                            c->stream));
   return sync(c);
+}
+
+PISLAM_EXPORT int pislam_frontend_last_stats(pislam_ctx *c, uint32_t stats[2]) {
+  if (!c || !stats) return PISLAM_ERR_INVALID;
+  stats[0] = stats[1] = 0;
+  if (!c->w_ovf.p || !c->last_strips) return PISLAM_OK;      // staged pipeline / separate-tile layout: nothing deferred
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipMemcpyAsync(&stats[0], c->w_ovf.as<uint32_t>() + 1, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+  PCHK(sync(c));
+  stats[1] = c->last_strips;
+  return PISLAM_OK;
 }
 
 PISLAM_EXPORT int pislam_frontend_last_timing(pislam_ctx *c, float *total_ms, float stage_ms[3]) {

@@ -307,3 +307,10 @@ class OrbFrontend:
         c.check(c.lib.pislam_frontend_last_timing(c.h, ctypes.byref(tot), ctypes.byref(st)),
                 "pislam_frontend_last_timing")
         return float(tot.value), [float(v) for v in st]
+
+    def last_stats(self):
+        """(strips redone by the overflow pass, strips) of the last call — see pislam_frontend_last_stats."""
+        c = self.ctx
+        st = (ctypes.c_uint32 * 2)()
+        c.check(c.lib.pislam_frontend_last_stats(c.h, ctypes.byref(st)), "pislam_frontend_last_stats")
+        return int(st[0]), int(st[1])
