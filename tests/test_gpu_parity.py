@@ -74,6 +74,10 @@ def test_batch_path_on_reference_demo_pyramid(gpu_ctx, demo, pipeline):
     assert c[0] == 1754 == c[2]
     assert sha16(k[0, :1754]) == SURVEY_PINS["kp"] and sha16(d[0, :1754]) == SURVEY_PINS["desc"]
     assert (k[2] == k[0]).all() and (d[2] == d[0]).all()           # independent of batch position
+    if pipeline == 2:
+        # the reference's own demo photo must stay on the fast path: no strip redone by the overflow pass
+        redone, strips = fe.last_stats()
+        assert strips > 0 and redone == 0, (redone, strips)
     try:
         sm = fe.score_map(0)
     except Exception:
@@ -527,3 +531,39 @@ def test_batch_call_is_hipgraph_capturable(gpu_ctx, orc):
     c = counts.cpu().numpy().view(np.uint32)
     okp, odesc, _ = orc.pyramid(synth.make_pyramid(61), levels)
     assert c[1] == len(okp) and (kp.cpu().numpy().view(np.uint32)[1, :len(okp)] == okp).all()
+
+
+def test_dense_input_takes_the_overflow_pass_and_stays_exact(gpu_ctx, orc):
+    """Uniform noise: nearly every pixel is a corner, the on-chip queues of the fast path overflow, the
+    strips are redone by the overflow pass (plain layout, scan fallbacks).  Results must not change and
+    pislam_frontend_last_stats must report it; a second call must start from an empty overflow list."""
+    import torch
+    from pislam_amd import synth
+    from pislam_amd.frontend import OrbFrontend
+    levels = [(160, 120, 0), (133, 100, 120), (111, 83, 220)]
+    rows = 303
+    rng = np.random.default_rng(7)
+    pyr = np.zeros((2, rows, 160), np.uint8)
+    for (w, h, r0) in levels:
+        pyr[0, r0:r0 + h, :w] = rng.integers(0, 256, (h, w), dtype=np.uint8)
+    pyr[1] = synth.make_batch(5, 1, w0=160, h0=120, vstep=160, levels=levels)[0]   # a sparse one in the same batch
+    dev = torch.device("cuda:0")
+    gpu_ctx.set_option("pipeline", 2)
+    try:
+        fe = OrbFrontend(levels, vstep=160, rows=rows, max_keypoints=8192, ctx=gpu_ctx)
+        kp, desc, counts = fe.alloc_outputs(2, dev)
+        for rep in range(2):
+            fe(torch.from_numpy(pyr).to(dev), kp, desc, counts)
+            torch.cuda.synchronize()
+            redone, strips = fe.last_stats()
+            assert strips > 0 and 0 < redone < strips, (redone, strips)
+            c = counts.cpu().numpy().view(np.uint32)
+            k = kp.cpu().numpy().view(np.uint32)
+            d = desc.cpu().numpy().view(np.uint32)
+            for b in range(2):
+                okp, odesc, _ = orc.pyramid(pyr[b], levels)
+                n = min(int(c[b]), 8192)
+                assert c[b] == len(okp)
+                assert (k[b, :n] == okp[:n]).all() and (d[b, :n] == odesc[:n]).all()
+    finally:
+        gpu_ctx.set_option("pipeline", 0)
