@@ -1178,17 +1178,20 @@ __global__ __launch_bounds__(256) void k_gather_orb(
     p0 = (it < npairs) ? kpl_l[i0 - lo] : 0u;
     p1 = (it < npairs && i0 + 1 < hi) ? kpl_l[i0 + 1 - lo] : 0u;
   };
+  // (32-bit byte offsets inside the pyramid: a pyramid is far below 2 GiB; a negative offset wraps to a
+  //  huge unsigned value and fails the single bounds test)
+  const uint32_t img_bytes32 = (uint32_t)img_bytes;
   auto fetch = [&](uint32_t p0, uint32_t p1) {
     Win f;
     // byte offset of the patch origin (row y-15, column x-15) of either keypoint
-    const ptrdiff_t org0 = (ptrdiff_t)(decode_y(p0) - 15) * vstep + (decode_x(p0) - 15);
-    const ptrdiff_t org1 = (ptrdiff_t)(decode_y(p1) - 15) * vstep + (decode_x(p1) - 15);
+    const int org0 = (decode_y(p0) - 15) * vstep + (decode_x(p0) - 15);
+    const int org1 = (decode_y(p1) - 15) * vstep + (decode_x(p1) - 15);
 #pragma unroll
     for (int j = 0; j < 3; j++) {
-      const ptrdiff_t org = sl_h[j] ? org1 : org0;
+      const int org = sl_h[j] ? org1 : org0;
       const bool v = sl_on[j] && (sl_h[j] ? p1 : p0) != 0;
-      const ptrdiff_t a = ((org + sl_rel[j]) & ~(ptrdiff_t)15) + 0;   // vstep % 16 == 0: row offsets keep the alignment
-      f.w[j] = (v && a >= 0 && a + 16 <= img_bytes) ? *(const uint4 *)(im + a) : make_uint4(0, 0, 0, 0);
+      const uint32_t a = (uint32_t)(org + (int)sl_rel[j]) & ~15u;   // vstep % 16 == 0: row offsets keep the alignment
+      f.w[j] = (v && a <= img_bytes32 - 16u) ? *(const uint4 *)(im + a) : make_uint4(0, 0, 0, 0);
     }
     return f;
   };
@@ -1253,8 +1256,9 @@ __global__ __launch_bounds__(256) void k_gather_orb(
       const uint32_t e = ent[round];
       const uint32_t a = bp[e & 0xffffu], b = bp[e >> 16];
       const uint64_t m = __ballot(a < b);                           // Brief.h:52
+      // lane `round` of either half keeps that half's word (v_writelane: rounds >= words are never stored)
       const uint32_t w = half ? (uint32_t)(m >> 32) : (uint32_t)m;
-      if (r == round) myword = w;                                   // rounds >= words are never stored
+      if (r == round) myword = w;
     }
     if (valid && r < words) dsc[(size_t)idx * words + r] = myword;
   }

@@ -1036,9 +1036,9 @@ int run_fused(pislam_ctx *c, const pislam_frontend_params *p, const pf::FusedPar
     }
   }
   HIPCHK(c, hipEventRecord(c->ev[2], c->stream));       // stage 1 = the overflow pass (normally empty)
-  if (p->vstep % 16 != 0) {
-    // k_gather_orb's 48-byte row windows assume a row-independent byte shift (vstep % 16 == 0);
-    // other strides take the generic gather + per-keypoint ORB kernels.
+  if (p->vstep % 16 != 0 || (size_t)p->rows * p->vstep > 0x7fffffffu) {
+    // k_gather_orb's 48-byte row windows assume a row-independent byte shift (vstep % 16 == 0) and
+    // 32-bit byte offsets inside a pyramid; other layouts take the generic gather + per-keypoint ORB kernels.
     hipLaunchKernelGGL(pf::k_gather, dim3(batch), dim3(256), sizeof(uint32_t) * (F.strips_per_pyr + 1), c->stream,
                        F, c->w_stage.as<uint32_t>(), c->w_stripcnt.as<uint32_t>(), kp, (size_t)p->max_keypoints,
                        (uint32_t)p->max_keypoints, counts, ovf);
