@@ -170,25 +170,34 @@ def main():
         t_desc, t_counts = torch.roll(desc, 1, 0).contiguous(), torch.roll(counts, 1, 0).contiguous()
         m_out = [torch.empty((B, args.max_keypoints), dtype=torch.int32, device=dev) for _ in range(3)]
 
+    # Two output sets, alternating per step: the consumer of step i's outputs — here the all-gather of its
+    # counts (pislam_amd.dist.CountExchange, on RCCL's own stream) — overlaps step i+1's kernels.
+    outs = [(kp, desc, counts)] + ([fe.alloc_outputs(B, dev)] if world > 1 else [])
+    xchg = pdist.CountExchange(world)
+    nstep = [0]
+
     def step():
+        k_, d_, c_ = outs[nstep[0] % len(outs)]
+        nstep[0] += 1
         if builder is not None:
             builder(d_frames, d_pyr)
-        fe(d_pyr, kp, desc, counts)
+        fe(d_pyr, k_, d_, c_)
         if m_out is not None:
-            matchHammingBatch(desc, counts, t_desc, t_counts, *m_out, ctx=ctx)
-        return pdist.gather_counts(counts, world)
+            matchHammingBatch(d_, c_, t_desc, t_counts, *m_out, ctx=ctx)
+        xchg.start(c_)
 
     for _ in range(args.warmup):
-        allc = step()
+        step()
+    xchg.finish()
     torch.cuda.synchronize()
     if world > 1:
         torch.distributed.barrier()
     torch.cuda.synchronize()
-    gpu_ms = []
+    nstep[0] = 0
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        allc = step()
-        gpu_ms.append(None)
+        step()
+    allc = xchg.finish()                                # every step's all-gather has completed
     torch.cuda.synchronize()
     if world > 1:
         torch.distributed.barrier()

@@ -567,3 +567,30 @@ def test_dense_input_takes_the_overflow_pass_and_stays_exact(gpu_ctx, orc):
                 assert (k[b, :n] == okp[:n]).all() and (d[b, :n] == odesc[:n]).all()
     finally:
         gpu_ctx.set_option("pipeline", 0)
+
+
+def test_count_exchange_on_rccl_single_rank_group():
+    """pislam_amd.dist.CountExchange on the real RCCL backend (a 1-rank group is all a 1-GPU box offers):
+    asynchronous all-gathers on RCCL's stream, two alternating buffers, waits ordered for buffer reuse."""
+    import os
+    import torch
+    import torch.distributed as dist
+    from pislam_amd import dist as pdist
+    if dist.is_initialized():
+        pytest.skip("a process group already exists in this process")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29533", rank=0, world_size=1, device_id=dev)
+    try:
+        x = pdist.CountExchange(1, always_collective=True)
+        bufs = [torch.zeros(256, dtype=torch.int32, device=dev) for _ in range(2)]
+        for i in range(7):
+            b = bufs[i & 1]
+            b.fill_(i + 1)                    # "step i" writes its counts ...
+            x.start(b)                        # ... and hands them to the exchange
+        out = x.finish()
+        torch.cuda.synchronize()
+        assert out.shape == (256,) and (out.cpu().numpy() == 7).all()
+    finally:
+        dist.destroy_process_group()
