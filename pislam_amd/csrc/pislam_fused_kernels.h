@@ -1,24 +1,27 @@
-// pislam_fused_kernels.h — the measured path: fused detect + score + NMS per strip.
+// pislam_fused_kernels.h — the measured path: fused detect + score + NMS per strip, then gather + ORB.
 //
-// One workgroup owns one horizontal strip (R rows x the full level width) of one
-// level of one pyramid.  The image strip (+halo) is staged into LDS with 16-byte
-// coalesced loads; everything up to the keypoint list happens out of LDS, so the
-// image is read from HBM once and the reference's score map (`out`, Fast.h:54 /
-// Fast.h:166) is never materialised in HBM:
+// A strip = R rows x the full width of one level of one pyramid; a 256-thread workgroup walks a run of
+// consecutive strips of one level (k_fused_strips).  The image strip (+halo) is staged into LDS with
+// 16-byte coalesced loads; everything up to the keypoint list happens out of LDS, so the image is read
+// from HBM once and the reference's score map (`out`, Fast.h:54 / Fast.h:166) is never materialised
+// in HBM:
 //
-//   phase A  cheap necessary test on every pixel (two adjacent compass points of
-//            the Bresenham ring both darker / both brighter); survivors are
-//            compacted per wave (ballot + mbcnt) into a wave-private LDS queue
-//   phase B  whenever a queue holds >= 64 entries the wave pops 64 and runs the
-//            full FAST-9 arc test on densely packed lanes (result-identical to
-//            Fast.h:63-147); corners go to a second queue
-//   phase C  same scheme for the 6x6 Harris score (Harris.h:80-248) -> LDS score tile
-//   phase D  2x2-block NMS (Fast.h:228-312) on the LDS score tile; survivors are
-//            written in block-raster order to the strip's slot of a staging buffer
+//   phase A0 SAD prefilter on every 4-pixel group (necessary condition of the compass test)
+//   phase A1 exact "two adjacent compass points" test on the surviving groups, 4 pixels per lane on
+//            packed u16; survivors are compacted per wave (ballot + mbcnt) into a wave-private LDS queue
+//   phase B  whenever a queue holds >= 64 entries the wave pops 64 and runs the full FAST-9 arc test
+//            on densely packed lanes (result-identical to Fast.h:63-147); corners go to ONE queue per
+//            workgroup
+//   phase C  all waves score that queue: 6x6 Harris (Harris.h:80-248)
+//   phase D  2x2-block NMS (Fast.h:228-312), driven by the queue of non-zero scores; survivors are
+//            ranked into block-raster order and written to the strip's slots of a staging buffer
 //
-// A second kernel (k_gather) turns per-strip counts into offsets (exclusive scan in
-// strip order = reference order) and copies the staged keypoints to their final
-// positions; k_orb then describes them.  Deterministic: no atomics-order dependence.
+// Two LDS layouts (strip_lds): ALIAS (product: the score tile is laid over the dead image rows after
+// phase C, scores travel in the queue entries; strips whose queues overflow go to an overflow list) and
+// plain (separate score tile, scan fallbacks: k_fused_overflow and the option alias=0).
+// k_gather_orb turns per-strip counts into offsets (exclusive scan in strip order = reference order),
+// copies the staged keypoints to their final positions and describes them (orbCompute, Orb.h:396).
+// Deterministic: no result depends on the order of atomics.
 #pragma once
 #include "pislam_dev.h"
 
@@ -42,8 +45,8 @@ constexpr int QCAP_F = 192;            // FAST candidates (< 64 before a <= 128 
 constexpr int QCAP = QCAP_G + QCAP_F;  // dwords of private queue space per wave
 constexpr int QH_SHARED = 1024;        // workgroup-shared queue of corners awaiting their Harris score (a 28-row
                                        // strip of a textured photo holds up to ~900: the reference's demo image)
-constexpr int QN_SHARED = 512;         // workgroup-shared queue of pixels with a non-zero score (NMS candidates)
-constexpr int QS_SHARED = 256;         // survivors of one strip awaiting their rank (lives in the dead image tile)
+constexpr int QN_SHARED = 512;         // plain layout only: queue of pixels with a non-zero score (NMS candidates)
+constexpr int QS_SHARED = 256;         // survivors of one strip awaiting their rank
 constexpr int SHARED_Q = QH_SHARED + QN_SHARED;
 constexpr int NMS_SCRATCH = 3 * QS_SHARED;   // dwords: survivors, their keys, bucket keep flags (in the idle per-wave queues)
 static_assert(NMS_SCRATCH <= WAVES * QCAP, "NMS scratch must fit the per-wave queue area");
