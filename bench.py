@@ -87,6 +87,8 @@ def main():
     ap.add_argument("--xtile-cols", type=int, default=-1)
     ap.add_argument("--run-len", type=int, default=0)
     ap.add_argument("--alias", type=int, default=-1)
+    ap.add_argument("--graph", type=int, default=0,
+                    help="1: capture the step's launches into a hipGraph (torch.cuda.CUDAGraph) per output set and replay it")
     ap.add_argument("--match", action="store_true",
                     help="also match every pyramid's descriptors against its neighbour's inside the step (SURVEY 8f-4)")
     ap.add_argument("--lds-pad", type=int, default=0, help="profiling only: extra LDS per strip workgroup")
@@ -122,6 +124,8 @@ def main():
     B = args.batch
     distinct = args.distinct or (B if args.workload == "vga" else min(B, 16))
     first = rank * B
+    if args.graph:                                     # graph capture needs a non-default stream
+        torch.cuda.set_stream(torch.cuda.Stream(dev))
     stream = torch.cuda.current_stream(dev)
     ctx = Context(device=local_rank, stream=stream.cuda_stream)
     ctx.set_option("pipeline", args.pipeline)
@@ -176,15 +180,33 @@ def main():
     xchg = pdist.CountExchange(world)
     nstep = [0]
 
-    def step():
-        k_, d_, c_ = outs[nstep[0] % len(outs)]
-        nstep[0] += 1
+    def launches(k_, d_, c_):
         if builder is not None:
             builder(d_frames, d_pyr)
         fe(d_pyr, k_, d_, c_)
         if m_out is not None:
             matchHammingBatch(d_, c_, t_desc, t_counts, *m_out, ctx=ctx)
-        xchg.start(c_)
+
+    graphs = None
+    if args.graph:
+        for o in outs:
+            launches(*o)                                # warm-up outside the capture (allocations, module load)
+        torch.cuda.synchronize()
+        graphs = []
+        for o in outs:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=stream):
+                launches(*o)
+            graphs.append(g)
+
+    def step():
+        i = nstep[0] % len(outs)
+        nstep[0] += 1
+        if graphs is not None:
+            graphs[i].replay()
+        else:
+            launches(*outs[i])
+        xchg.start(outs[i][2])
 
     for _ in range(args.warmup):
         step()
@@ -277,6 +299,7 @@ def main():
                 "pyramids_per_s": B * world * args.steps / dt,
                 "parallelism": f"pyramid-shard x{world}, RCCL all-gather of counts" if world > 1 else "single GPU",
                 "pipeline": "fused" if fused else "staged",
+                "launch": "hipGraph replay" if graphs is not None else "eager",
                 "strips_redone_by_overflow_pass": f"{deferred} of {nstrips}",
                 **({"match_inside_step": match_info} if match_info else {}),
             },
