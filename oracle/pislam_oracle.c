@@ -17,6 +17,10 @@
  *   - BRIEF sampler (Brief.h): PINNED against the real reference — Brief.h
  *     contains no NEON and is compiled unmodified into oracle/_ref/ by
  *     oracle/Makefile; tests compare this file's table and descriptors with it.
+ *   - fill_spiral (test/TestUtil.cpp, the fixture of GaussianTest / BilinearTest): PINNED
+ *     against the real reference — plain C++, compiled where it lies into oracle/_ref/.
+ *   - gaussian5x5 / bilinear (scalar reference() of GaussianTest.cpp / BilinearTest.cpp): restated
+ *     from files that include the NEON headers and gtest — not buildable here, unpinned.
  *   - FAST / Harris / NMS / centroid / atan2 (Fast.h, Harris.h, Orb.h):
  *     the reference needs <arm_neon.h> and ARM inline asm, which an x86 image
  *     cannot build without stand-in headers, so there is no oracle/_ref build

@@ -171,6 +171,26 @@ def test_brief_descriptor_equals_real_reference_when_built(orc, demo):
         assert (orc.brief_describe(img, x, y, rot) == exp).all()
 
 
+def test_fill_spiral_equals_real_reference_when_built(orc):
+    """Direct execution of the reference's own test fixture generator test/TestUtil.cpp:27
+    (oracle/_ref/libtestutil_ref.so, built in the dev container) over the sizes GaussianTest / BilinearTest use."""
+    so = os.path.join(os.path.dirname(GOLDEN), "..", "oracle", "_ref", "libtestutil_ref.so")
+    if not os.path.exists(so):
+        pytest.skip("oracle/_ref not built here")
+    ref = ctypes.CDLL(so)
+    ref.ref_fill_spiral.argtypes = [ctypes.c_int] * 5 + [ctypes.c_void_p]
+    cases = [(640, w, h, 640 // 3, 640 // 3) for w in (16, 31, 63) for h in (16, 40, 63)]      # GaussianTest.cpp
+    cases += [(64, w, h, 21, 21) for w in (1, 7, 16, 33, 47) for h in (1, 8, 30, 47)]          # BilinearTest.cpp
+    cases += [(640, 640, 480, 320, 240), (1280, 1280, 720, 600, 300)]
+    for vstep, w, h, cx, cy in cases:
+        # the reference marks every spiral point with row < vstep (its tests use vstep x vstep buffers);
+        # the oracle only keeps the rows < height, which is all the parity tests read
+        exp = np.full((max(vstep, h), vstep), 0xAA, np.uint8)
+        ref.ref_fill_spiral(vstep, w, h, cx, cy, exp.ctypes.data)
+        got = orc.fill_spiral(vstep, w, h, cx, cy, rows=h)
+        assert (got == exp[:h]).all(), (vstep, w, h, cx, cy)
+
+
 def test_extract_edge_cases(orc):
     rng = np.random.default_rng(4)
     # empty map, tiny level, ties, capacity clipping
