@@ -17,6 +17,7 @@
  *   - BRIEF sampler (Brief.h): PINNED against the real reference — Brief.h
  *     contains no NEON and is compiled unmodified into oracle/_ref/ by
  *     oracle/Makefile; tests compare this file's table and descriptors with it.
+ *   - keypoint codec (Util.h): PINNED against the real header (oracle/_ref/libutil_ref.so).
  *   - fill_spiral (test/TestUtil.cpp, the fixture of GaussianTest / BilinearTest): PINNED
  *     against the real reference — plain C++, compiled where it lies into oracle/_ref/.
  *   - gaussian5x5 / bilinear (scalar reference() of GaussianTest.cpp / BilinearTest.cpp): restated

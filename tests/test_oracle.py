@@ -171,6 +171,29 @@ def test_brief_descriptor_equals_real_reference_when_built(orc, demo):
         assert (orc.brief_describe(img, x, y, rot) == exp).all()
 
 
+def test_keypoint_codec_equals_real_reference_when_built():
+    """Direct execution of the reference's include/Util.h (oracle/_ref/libutil_ref.so): the Python mirror of
+    the codec and the decode helpers agree with it on edge and random values."""
+    so = os.path.join(os.path.dirname(GOLDEN), "..", "oracle", "_ref", "libutil_ref.so")
+    if not os.path.exists(so):
+        pytest.skip("oracle/_ref not built here")
+    from pislam_amd import frontend as fr
+    ref = ctypes.CDLL(so)
+    for f in ("ref_encodeFast", "ref_rencodeFastScore", "ref_decodeFastX", "ref_decodeFastY", "ref_decodeFastScore"):
+        getattr(ref, f).restype = ctypes.c_uint32
+        getattr(ref, f).argtypes = [ctypes.c_uint32] * (3 if f == "ref_encodeFast" else 2 if f == "ref_rencodeFastScore" else 1)
+    rng = np.random.default_rng(11)
+    vals = [(0, 0, 0), (255, 4095, 4095), (137, 493, 16), (1, 16, 2209)] + \
+           [tuple(int(v) for v in rng.integers(0, [256, 4096, 4096])) for _ in range(200)]
+    for sc, x, y in vals:
+        e = ref.ref_encodeFast(sc, x, y)
+        assert fr.encodeFast(sc, x, y) == e
+        assert (fr.decodeFastX(e), fr.decodeFastY(e), fr.decodeFastScore(e)) == \
+               (ref.ref_decodeFastX(e), ref.ref_decodeFastY(e), ref.ref_decodeFastScore(e)) == (x, y, sc)
+        assert fr.rencodeFastScore((sc * 7) & 255, e) == ref.ref_rencodeFastScore((sc * 7) & 255, e)
+    assert ref.ref_encodeFast(137, 493, 16) == 0x891ED010          # SURVEY §8c: first keypoint of the demo image
+
+
 def test_fill_spiral_equals_real_reference_when_built(orc):
     """Direct execution of the reference's own test fixture generator test/TestUtil.cpp:27
     (oracle/_ref/libtestutil_ref.so, built in the dev container) over the sizes GaussianTest / BilinearTest use."""
