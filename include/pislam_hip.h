@@ -48,9 +48,13 @@ int pislam_ctx_create(int device, pislam_ctx **ctx);
 int pislam_ctx_destroy(pislam_ctx *ctx);
 /* hip_stream is a hipStream_t passed as void*; NULL = null stream. */
 int pislam_ctx_set_stream(pislam_ctx *ctx, void *hip_stream);
-/* Tuning / test hooks.  Keys: "pipeline" (0 auto, 1 staged = one launch group per level with an
- * HBM score map, 2 fused strips), "dump_score" (fused pipeline also materialises the score map so
- * that pislam_frontend_get_score_map works), "strip_rows" (fused strip height, 0 = heuristic). */
+/* Tuning / test hooks; results never depend on them.  Keys:
+ *   "pipeline"   0 auto, 1 staged (one launch group per reference call, HBM score map), 2 fused strips
+ *   "dump_score" fused pipeline also materialises the score map (pislam_frontend_get_score_map)
+ *   "strip_rows" fused strip height (0 = heuristic);  "run_len" strips per workgroup run (0 = by batch)
+ *   "alias"      1 (default) score tile laid over the dead image rows + overflow pass, 0 separate tiles
+ *   "xtile_cols" image x-tiles inside a strip (0 = full width);  "orb_chunks" gather+ORB workgroups per pyramid
+ *   "wgs_per_cu", "lds_pad", "ablate"  profiling only (ablate != 0 gives INVALID results by design) */
 int pislam_ctx_set_option(pislam_ctx *ctx, const char *key, int value);
 int pislam_ctx_synchronize(pislam_ctx *ctx);
 const char *pislam_last_error(const pislam_ctx *ctx);
