@@ -1192,9 +1192,11 @@ __global__ __launch_bounds__(256) void k_gather_orb(
 #pragma unroll
     for (int j = 0; j < 3; j++) {
       const int org = sl_h[j] ? org1 : org0;
-      const bool v = sl_on[j] && (sl_h[j] ? p1 : p0) != 0;
-      const uint32_t a = (uint32_t)(org + (int)sl_rel[j]) & ~15u;   // vstep % 16 == 0: row offsets keep the alignment
-      f.w[j] = (v && a <= img_bytes32 - 16u) ? *(const uint4 *)(im + a) : make_uint4(0, 0, 0, 0);
+      // vstep % 16 == 0: row offsets keep the alignment.  A chunk that starts outside the pyramid (absent
+      // keypoint, idle slot, window slack past the last row) holds no byte any patch uses — the buffer
+      // size is a multiple of 16 — so it is simply clamped into the buffer instead of being zero-filled.
+      const uint32_t a = min((uint32_t)(org + (int)sl_rel[j]) & ~15u, img_bytes32 - 16u);
+      f.w[j] = *(const uint4 *)(im + a);
     }
     return f;
   };
@@ -1245,7 +1247,11 @@ __global__ __launch_bounds__(256) void k_gather_orb(
     right = __builtin_amdgcn_udot4(row[7] & cmask[7], 0x000f0e0du, right, false);  // dx  13..15 (16 masked)
     const int m10 = half_sum((int)right - (int)left, half);
     const int m01 = half_sum(dy * (int)sv, half);
-    const uint32_t rot = angle_bin(m10, m01);
+    const uint32_t rot = (P.ablate & 16384) ? 0u : angle_bin(m10, m01);   // (profiling only)
+    if (P.ablate & 32768) {                          // profiling only: no BRIEF
+      if (valid && r < words) dsc[(size_t)idx * words + r] = rot + sv;
+      continue;
+    }
     // BRIEF: pair k = 32*round + r of this half's keypoint -> bit r of word `round`
     const uint32_t *tab = ::g_brief_ofs.v + rot * 256 + r;   // defined by the including TU
     // the patch's byte (dy,dx) sits at (dy+15)*48 + sh + dx+15; sh is the same for every row
