@@ -1201,15 +1201,9 @@ __global__ __launch_bounds__(256) void k_gather_orb(
     return f;
   };
   if (P.ablate & 64) return;                        // profiling only: prologue cost
-  uint32_t np0, np1;
-  pair_of(wv, np0, np1);
-  Win nxt = fetch(np0, np1);
   lds_u8 *patch_l = wave_patches + half * ORB_PATCH_BYTES;
-  for (uint32_t it = wv; it < npairs; it += OWAVES) {
-    const Win cur = nxt;
-    const uint32_t p0 = np0, p1 = np1;
-    pair_of(it + OWAVES, np0, np1);
-    nxt = fetch(np0, np1);
+  // one pair: park the fetched windows, moments, angle, BRIEF, store
+  auto describe = [&](const Win &cur, const uint32_t p0, const uint32_t p1, const uint32_t it) {
     const uint32_t idx = lo + 2 * it + half;
     const uint32_t pme = half ? p1 : p0;
     const bool valid = pme != 0;
@@ -1250,7 +1244,7 @@ __global__ __launch_bounds__(256) void k_gather_orb(
     const uint32_t rot = (P.ablate & 16384) ? 0u : angle_bin(m10, m01);   // (profiling only)
     if (P.ablate & 32768) {                          // profiling only: no BRIEF
       if (valid && r < words) dsc[(size_t)idx * words + r] = rot + sv;
-      continue;
+      return;
     }
     // BRIEF: pair k = 32*round + r of this half's keypoint -> bit r of word `round`
     const uint32_t *tab = ::g_brief_ofs.v + rot * 256 + r;   // defined by the including TU
@@ -1270,6 +1264,20 @@ __global__ __launch_bounds__(256) void k_gather_orb(
       if (r == round) myword = w;
     }
     if (valid && r < words) dsc[(size_t)idx * words + r] = myword;
+  };
+  // Two register sets (A, B) in ping-pong: the loads of the next pair are in flight while the current one
+  // is described, without copying 12 registers per iteration.
+  uint32_t a0, a1, b0, b1;
+  pair_of(wv, a0, a1);
+  Win wa = fetch(a0, a1), wb;
+  for (uint32_t it = wv; it < npairs; it += 2 * OWAVES) {
+    pair_of(it + OWAVES, b0, b1);
+    wb = fetch(b0, b1);
+    describe(wa, a0, a1, it);
+    if (it + OWAVES >= npairs) break;
+    pair_of(it + 2 * OWAVES, a0, a1);
+    wa = fetch(a0, a1);
+    describe(wb, b0, b1, it + OWAVES);
   }
 }
 
