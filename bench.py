@@ -87,8 +87,9 @@ def main():
     ap.add_argument("--xtile-cols", type=int, default=-1)
     ap.add_argument("--run-len", type=int, default=0)
     ap.add_argument("--alias", type=int, default=-1)
-    ap.add_argument("--graph", type=int, default=0,
-                    help="1: capture the step's launches into a hipGraph (torch.cuda.CUDAGraph) per output set and replay it")
+    ap.add_argument("--graph", type=int, default=1,
+                    help="1 (default): capture the step's launches into a hipGraph (torch.cuda.CUDAGraph) per output set "
+                         "and replay it — falls back to eager launches if the capture or its check fails; 0: eager")
     ap.add_argument("--match", action="store_true",
                     help="also match every pyramid's descriptors against its neighbour's inside the step (SURVEY 8f-4)")
     ap.add_argument("--lds-pad", type=int, default=0, help="profiling only: extra LDS per strip workgroup")
@@ -189,15 +190,30 @@ def main():
 
     graphs = None
     if args.graph:
-        for o in outs:
-            launches(*o)                                # warm-up outside the capture (allocations, module load)
-        torch.cuda.synchronize()
-        graphs = []
-        for o in outs:
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, stream=stream):
-                launches(*o)
-            graphs.append(g)
+        # The batch call allocates nothing and never synchronises once the workspace is reserved, so a step's
+        # launches can be replayed from a hipGraph.  Any failure (capture error, replay not reproducing the
+        # eager counts) falls back to eager launches: the measurement must never depend on this.
+        try:
+            for o in outs:
+                launches(*o)                            # warm-up outside the capture (allocations, module load)
+            torch.cuda.synchronize()
+            want = [o[2].clone() for o in outs]
+            graphs = []
+            for o in outs:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=stream):
+                    launches(*o)
+                graphs.append(g)
+            for o, g, w in zip(outs, graphs, want):
+                o[2].zero_()
+                g.replay()
+                torch.cuda.synchronize()
+                if not torch.equal(o[2], w):
+                    raise RuntimeError("graph replay does not reproduce the eager result")
+        except Exception as e:                          # noqa: BLE001
+            print(f"[bench] hipGraph path disabled: {e!r}", file=sys.stderr)
+            graphs = None
+            torch.cuda.synchronize()
 
     def step():
         i = nstep[0] % len(outs)
