@@ -66,8 +66,10 @@ def cpu_baseline(pyr_host, levels, budget_s=10.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--spin-s", type=float, default=0.5,
+                    help="seconds of untimed load before the warm-up steps (GPU clock ramp)")
     ap.add_argument("--batch", type=int, default=256, help="pyramids per GPU")
     ap.add_argument("--distinct", type=int, default=0,
                     help="distinct synthetic pyramids generated per GPU (0 = all of the batch)")
@@ -224,6 +226,15 @@ def main():
             launches(*outs[i])
         xchg.start(outs[i][2])
 
+    # Clock ramp: the GPU idles at a few hundred MHz and needs a fraction of a second of load to reach its
+    # sustained clocks — far longer than a handful of 0.4 ms steps.  Spin the same step, untimed, before the W
+    # warm-up steps so that W and K measure the steady state whatever their values.
+    t_spin = time.perf_counter()
+    while time.perf_counter() - t_spin < args.spin_s:
+        for _ in range(8):
+            step()
+        xchg.finish()
+        torch.cuda.synchronize()
     for _ in range(args.warmup):
         step()
     xchg.finish()
