@@ -27,7 +27,7 @@ __device__ __forceinline__ int reflect101(int i, int n) {
 // horizontal pass produces 4 pixels per lane and stores them as one dword.
 // src and dst must not alias (the ABI stages in-place calls through a temporary).
 // ---------------------------------------------------------------------------
-constexpr int G_TW = 128, G_TH = 16;
+constexpr int G_TW = 128, G_TH = 32;
 constexpr int G_PW = G_TW + 8;                       // LDS row: 4 halo bytes (2 used) on either side, dword aligned
 
 // byte-wise rounding halving add of 4 packed pixels: ceil((a+b)/2) = (a|b) - (((a^b) & 0xfe..) >> 1)
@@ -36,7 +36,7 @@ __device__ __forceinline__ uint32_t tap5x4(uint32_t a, uint32_t b, uint32_t c, u
   return rhadd4(rhadd4(rhadd4(rhadd4(a, e), c), c), rhadd4(b, d));
 }
 
-// One workgroup = one 128 x 16 output tile.  Rows are staged as dwords (interior tiles: aligned
+// One workgroup = one 128 x 32 output tile (36 staged rows: 12 % halo).  Rows are staged as dwords (interior tiles: aligned
 // 4-byte loads; tiles touching the left/right image border or an unaligned source: per-byte with
 // the reflect-101 rule), both passes work on 4 packed pixels per lane (SWAR RHADD), the horizontal
 // taps come from v_alignbyte on aligned LDS dwords, and each lane stores one dword.
