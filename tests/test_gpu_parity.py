@@ -594,3 +594,35 @@ def test_count_exchange_on_rccl_single_rank_group():
         assert out.shape == (256,) and (out.cpu().numpy() == 7).all()
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("border", [16, 17, 19, 20, 32])
+def test_fused_borders(gpu_ctx, orc, border):
+    """Any border >= 16 (odd ones too: block origins and x-tile edges then fall off dword boundaries), with
+    and without buckets, on both LDS layouts."""
+    import torch
+    from pislam_amd import synth
+    from pislam_amd.frontend import OrbFrontend
+    levels = [(320, 240, 0), (267, 200, 240), (222, 167, 440), (185, 139, 607)]
+    rows = 746
+    pyr = synth.make_batch(11, 2, w0=320, h0=240, vstep=320, levels=levels)
+    dev = torch.device("cuda:0")
+    try:
+        for lbs, lim in ((0, 5), (3, 2)):
+            ref = [orc.pyramid(pyr[b], levels, border=border, log_bucket=lbs, bucket_limit=lim) for b in range(2)]
+            for alias in (1, 0):
+                gpu_ctx.set_option("alias", alias)
+                fe = OrbFrontend(levels, vstep=320, rows=rows, max_keypoints=4096, border=border, log_bucket_size=lbs,
+                                 bucket_limit=lim, ctx=gpu_ctx)
+                kp, desc, counts = fe.alloc_outputs(2, dev)
+                fe(torch.from_numpy(pyr).to(dev), kp, desc, counts)
+                torch.cuda.synchronize()
+                c = counts.cpu().numpy().view(np.uint32)
+                k = kp.cpu().numpy().view(np.uint32)
+                d = desc.cpu().numpy().view(np.uint32)
+                for b in range(2):
+                    okp, odesc, _ = ref[b]
+                    assert c[b] == len(okp), (border, lbs, alias)
+                    assert (k[b, :c[b]] == okp).all() and (d[b, :c[b]] == odesc).all(), (border, lbs, alias)
+    finally:
+        gpu_ctx.set_option("alias", 1)
