@@ -67,7 +67,7 @@ struct FusedLevel {
   int nruns, run0;   // runs (= workgroups) of this level: run_len consecutive strips each
   int apad;          // ALIAS layout: bytes between the per-wave queues and the image tile (multiple of 16)
   int tbytes;        // plain layout: bytes reserved for the image tile = max((R+10)*tpitch, the scan
-                     // fallbacks' survivor buffers R/2 * nbx dwords — larger only with narrow x-tiles)
+                     // fallbacks' survivor / per-cell buffers — larger only with narrow x-tiles)
   uint32_t vpr_recip; // ceil(2^32 / (tpitch/16)): row = umulhi(i, vpr_recip) for i < 2^16
 };
 

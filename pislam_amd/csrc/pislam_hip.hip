@@ -916,7 +916,9 @@ bool build_fused_plan(const pislam_ctx *c, const pislam_frontend_params *p, cons
     L.vpr_recip = (uint32_t)(((1ull << 32) + (L.tpitch / 16) - 1) / (L.tpitch / 16));
     strips += L.nstrips;
     slots += L.nstrips * (R / 2) * L.nbx;
-    L.tbytes = std::max((R + 10) * L.tpitch, (((R / 2) * L.nbx * 4) + 15) & ~15);
+    // scan fallbacks reuse the image tile: row buffers of R/2 x nbx dwords, or per-cell results (<= one
+    // dword per block) + per-cell counts (<= a quarter of that: a cell holds >= 2x2 blocks)
+    L.tbytes = std::max((R + 10) * L.tpitch, (((R / 2) * L.nbx * 5 + 64) + 15) & ~15);
     lds = std::max(lds, (size_t)L.tbytes + (size_t)(R + 3) * L.pitch +
                             (pf::WAVES * pf::QCAP + pf::SHARED_Q) * sizeof(uint32_t));
     {
