@@ -947,7 +947,7 @@ bool build_fused_plan(const pislam_ctx *c, const pislam_frontend_params *p, cons
   F->slots_per_pyr = slots;
   *lds_bytes = lds;
   *lds_alias_bytes = lds_alias + (size_t)c->opt_lds_pad;   // profiling: opt_lds_pad lowers the residency artificially
-  return strips > 0 && lds <= 150 * 1024;
+  return lds <= 150 * 1024;       // (strips == 0: no level holds a classifiable pixel — the caller writes zero counts)
 }
 
 int run_fused(pislam_ctx *c, const pislam_frontend_params *p, const pf::FusedParams &F, size_t lds, size_t lds_alias,
@@ -1128,6 +1128,13 @@ PISLAM_EXPORT int pislam_orb_frontend_batch(pislam_ctx *c, const pislam_frontend
     return fail(c, PISLAM_ERR_INVALID, "fused pipeline unavailable for these parameters (bucket size / LDS size)");
   c->last_pipeline = fused ? 2 : 1;
   HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
+  if (fused && F.strips_per_pyr == 0) {            // every level is smaller than 2 x border: nothing to extract
+    HIPCHK(c, hipMemsetAsync(counts, 0, sizeof(uint32_t) * batch, c->stream));
+    for (int i = 1; i < 4; i++) HIPCHK(c, hipEventRecord(c->ev[i], c->stream));
+    c->timing_valid = true;
+    c->last_strips = 0;
+    return PISLAM_OK;
+  }
   if (fused) {
     PCHK(run_fused(c, p, F, lds, lds_alias, pyramids, stride, batch, kp, desc, counts));
   } else {
