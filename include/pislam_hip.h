@@ -65,7 +65,12 @@ const char *pislam_last_error(const pislam_ctx *ctx);
  * — reference include/Fast.h:54-158.  FAST-9 segment test; writes 0xff/0x00
  * to out rows [border,height-border), columns [border, border+16*ceil((width-
  * 2*border)/16)), plus out[y][width]=out[y][width+1]=0 when width%16 != 0.
- * Nothing else in `out` is touched.  Requires border >= 3. */
+ * Nothing else in `out` is touched.  Requires border >= 3.  Like the
+ * reference's 16-byte vectors, the over-classified columns are addressed
+ * flat: when border + 16*ceil((width-2*border)/16) + 3 > vstep they continue
+ * in the next row, and `img` must be readable up to byte
+ * (height-border+2)*vstep + that column (a few bytes past height*vstep only
+ * for border < 6 on a level as wide as vstep). */
 int pislam_fast_detect(pislam_ctx *ctx, int vstep, int border, int width, int height,
                        const uint8_t *img, uint8_t *out, int threshold);
 

@@ -449,8 +449,16 @@ PISLAM_EXPORT int pislam_fast_detect(pislam_ctx *c, int vstep, int border, int w
   if (!img || !out) return fail(c, PISLAM_ERR_INVALID, "null image");
   HIPCHK(c, hipSetDevice(c->device));
   const size_t bytes = (size_t)height * vstep;
+  // The over-classified columns [width-border, xend) may run past vstep, i.e. into the next row (flat
+  // addressing, as the reference's 16-byte vectors do): with a small border the ring of the last
+  // classified row then reaches a few bytes beyond height*vstep — bytes the reference reads too.
+  size_t img_bytes = bytes;
+  if (height > 2 * border && width > 2 * border) {
+    const size_t xend = (size_t)border + 16 * (size_t)cdiv(width - 2 * border, 16);
+    img_bytes = std::max(bytes, (size_t)(height - border + 2) * vstep + xend + 3);
+  }
   Staged si, so;
-  PCHK(stage_in(c, c->s_img, img, bytes, &si));
+  PCHK(stage_in(c, c->s_img, img, img_bytes, &si));
   PCHK(stage_in(c, c->s_out, out, bytes, &so));
   PCHK(launch_detect(c, (const uint8_t *)si.dev, (uint8_t *)so.dev, vstep, 0, 1, border, width, height,
                      threshold));

@@ -61,7 +61,15 @@ def _vstep(a) -> int:
 def fastDetect(width, height, img, out, threshold, *, border=16, ctx: Context | None = None):
     """pislam::fastDetect<vstep,border>(width, height, img, out, threshold)."""
     ctx = ctx or default_context()
-    ctx.check(ctx.lib.pislam_fast_detect(ctx.h, _vstep(img), border, width, height, ptr(img), ptr(out),
+    vstep = _vstep(img)
+    if isinstance(img, np.ndarray) and width > 2 * border and height > 2 * border:
+        # flat addressing of the over-classified columns (see pislam_hip.h): never read past the array
+        need = (height - border + 2) * vstep + border + 16 * (-(-(width - 2 * border) // 16)) + 3
+        if need > img.size:
+            pad = np.zeros(need, np.uint8)
+            pad[:img.size] = img.reshape(-1)
+            img = pad
+    ctx.check(ctx.lib.pislam_fast_detect(ctx.h, vstep, border, width, height, ptr(img), ptr(out),
                                          threshold), "pislam_fast_detect")
 
 

@@ -66,3 +66,59 @@ def test_random_configurations_match_the_oracle(gpu_ctx, orc, chunk):
     finally:
         for k, v in dict(pipeline=0, alias=1, run_len=0, strip_rows=0, xtile_cols=-1).items():
             gpu_ctx.set_option(k, v)
+
+
+def test_random_single_level_calls_match_the_oracle(gpu_ctx, orc):
+    """The four reference entry points on host arrays (any border >= 3 / 4 / 16, widths up to vstep —
+    including the flat-addressing wrap of the over-classified columns —, stale `out` contents, bucket sizes
+    1..64), the matcher and gaussian5x5 on random sizes."""
+    from pislam_amd import frontend as pl
+    for t in range(160):
+        rng = np.random.default_rng(31000 + t)
+        vstep = int(rng.choice([64, 96, 160, 208, 320, 640]))
+        w, h = int(rng.integers(8, vstep + 1)), int(rng.integers(8, 200))
+        rows = h + int(rng.integers(1, 4))
+        kind = int(rng.integers(0, 3))
+        if kind == 0:
+            img = rng.integers(0, 256, (rows, vstep), dtype=np.uint8)
+        else:
+            base = rng.integers(0, 256, (rows // 4 + 2, vstep // 4 + 2), dtype=np.uint8)
+            img = np.kron(base, np.ones((4, 4), np.uint8))[:rows, :vstep].copy()
+            if kind == 2:
+                img = (img.astype(np.int32) + rng.integers(-6, 7, img.shape)).clip(0, 255).astype(np.uint8)
+        border, thr = int(rng.integers(3, 24)), int(rng.choice([0, 5, 20, 60, 255]))
+        tag = (t, w, h, vstep, border, thr)
+        stale = rng.integers(0, 256, (rows, vstep), dtype=np.uint8)      # `out` may only change where the reference writes
+        o_g, o_o = stale.copy(), stale.copy()
+        pl.fastDetect(w, h, img, o_g, thr, border=border, ctx=gpu_ctx)
+        orc.fast_detect(img, o_o, w, h, thr, border=border)
+        assert (o_g == o_o).all(), tag
+        if border >= 4:
+            hthr = int(rng.choice([-(1 << 31), 0, 1 << 15, 1 << 24]))
+            z_g = np.zeros((rows, vstep), np.uint8)
+            z_o = z_g.copy()
+            pl.fastDetect(w, h, img, z_g, thr, border=border, ctx=gpu_ctx)
+            orc.fast_detect(img, z_o, w, h, thr, border=border)
+            pl.fastScoreHarris(w, h, img, hthr, z_g, border=border, ctx=gpu_ctx)
+            orc.fast_score_harris(img, z_o, w, h, hthr, border=border)
+            assert (z_g == z_o).all(), tag
+            lbs, lim = int(rng.choice([0, 0, 1, 2, 3, 4, 5, 6])), int(rng.integers(1, 8))
+            kg = pl.fastExtract(w, h, z_g, border=border, logBucketSize=lbs, bucketLimit=lim, ctx=gpu_ctx)
+            ko = orc.fast_extract(z_o, w, h, border=border, log_bucket=lbs, bucket_limit=lim)
+            assert len(kg) == len(ko) and (kg == ko).all(), tag + (lbs, lim)
+            if border >= 16 and len(ko):
+                words = int(rng.choice([1, 2, 4, 8]))
+                assert (pl.orbCompute(img, ko, words=words, ctx=gpu_ctx) == orc.orb_compute(img, ko, words=words)).all(), tag
+        words, nq, nt = int(rng.choice([1, 2, 4, 8])), int(rng.integers(0, 700)), int(rng.integers(0, 900))
+        q = rng.integers(0, 2**32, (nq, words), dtype=np.uint64).astype(np.uint32)
+        tr = rng.integers(0, 2**32, (nt, words), dtype=np.uint64).astype(np.uint32)
+        if nq and nt and rng.integers(0, 2):
+            q[: min(nq, nt) // 2] = tr[: min(nq, nt) // 2]           # exact matches and ties
+        for a, b in zip(pl.matchHamming(q, tr, ctx=gpu_ctx), orc.match_hamming(q.reshape(nq, words), tr.reshape(nt, words))):
+            assert (a == b).all(), (t, nq, nt, words)
+        if rows >= 17:
+            gw, gh = int(rng.integers(16, vstep + 1)), int(rng.integers(16, rows + 1))
+            a, b = img.copy(), img.copy()
+            pl.gaussian5x5(gw, gh, a, a, ctx=gpu_ctx)
+            orc.gaussian5x5(b, gw, gh)
+            assert (a[:gh, :gw] == b[:gh, :gw]).all(), (t, gw, gh, vstep)
