@@ -122,3 +122,98 @@ def test_random_single_level_calls_match_the_oracle(gpu_ctx, orc):
             pl.gaussian5x5(gw, gh, a, a, ctx=gpu_ctx)
             orc.gaussian5x5(b, gw, gh)
             assert (a[:gh, :gw] == b[:gh, :gw]).all(), (t, gw, gh, vstep)
+
+
+def test_random_packed_layouts_match_the_oracle(gpu_ctx, orc):
+    """Levels packed side by side on shelves (arbitrary col0, unaligned -> scalar staging path), both
+    pipelines; expectation = the oracle run level by level on a flat view shifted to the level's origin."""
+    import torch
+    from pislam_amd.frontend import OrbFrontend
+    dev = torch.device("cuda:0")
+    try:
+        for t in range(100):
+            rng = np.random.default_rng(47000 + t)
+            vstep = int(rng.choice([256, 320, 400, 512, 640]))
+            levels, x, y, shelf_h = [], int(rng.integers(0, 20)), 0, 0
+            for _ in range(int(rng.integers(2, 7))):
+                w, h = int(rng.integers(40, 260)), int(rng.integers(40, 140))
+                if x + w > vstep:
+                    y += shelf_h + int(rng.integers(0, 5))
+                    x, shelf_h = int(rng.integers(0, 20)), 0
+                w = min(w, vstep - x)
+                levels.append((w, h, y, x))
+                shelf_h = max(shelf_h, h)
+                x += w + int(rng.integers(16, 40))
+            rows = y + shelf_h + int(rng.integers(1, 4))
+            batch = int(rng.integers(1, 5))
+            base = rng.integers(0, 256, (batch, rows // 4 + 2, vstep // 4 + 2), dtype=np.uint8)
+            pyr = np.kron(base, np.ones((4, 4), np.uint8))[:, :rows, :vstep].copy()
+            if rng.integers(0, 2):
+                pyr = (pyr.astype(np.int32) + rng.integers(-6, 7, pyr.shape)).clip(0, 255).astype(np.uint8)
+            lbs, lim, border = int(rng.choice([0, 0, 3, 4])), int(rng.integers(1, 6)), int(rng.integers(16, 20))
+            opts = dict(pipeline=int(rng.choice([1, 2, 2])), alias=int(rng.integers(0, 2)), run_len=int(rng.choice([0, 1, 5])),
+                        strip_rows=int(rng.choice([0, 16, 22])), xtile_cols=int(rng.choice([0, 0, 64])))
+            for k, v in opts.items():
+                gpu_ctx.set_option(k, v)
+            fe = OrbFrontend(levels, vstep=vstep, rows=rows, max_keypoints=8192, border=border, log_bucket_size=lbs,
+                             bucket_limit=lim, ctx=gpu_ctx)
+            kp, desc, counts = fe.alloc_outputs(batch, dev)
+            fe(torch.from_numpy(pyr).to(dev), kp, desc, counts)
+            torch.cuda.synchronize()
+            c = counts.cpu().numpy().view(np.uint32)
+            k_ = kp.cpu().numpy().view(np.uint32)
+            d_ = desc.cpu().numpy().view(np.uint32)
+            for b in range(batch):
+                exp = []
+                for (w, h, r0, c0) in levels:
+                    view = np.ascontiguousarray(pyr[b, r0:].reshape(-1)[c0:])
+                    view = np.concatenate([view, np.zeros((-len(view)) % vstep + vstep, np.uint8)]).reshape(-1, vstep)
+                    lkp, _, _ = orc.pyramid(view, [(w, h, 0)], border=border, log_bucket=lbs, bucket_limit=lim)
+                    exp.append(lkp + np.uint32((c0 << 12) | r0))
+                exp = np.concatenate(exp)
+                assert c[b] == len(exp) and (k_[b, :len(exp)] == exp).all(), (t, b, levels, opts)
+                assert (d_[b, :len(exp)] == orc.orb_compute(pyr[b], exp)).all(), (t, b, levels, opts)
+    finally:
+        for k, v in dict(pipeline=0, alias=1, run_len=0, strip_rows=0, xtile_cols=-1).items():
+            gpu_ctx.set_option(k, v)
+
+
+def test_random_pyramid_builds_match_the_oracle(gpu_ctx, orc):
+    """pislam_pyramid_build_batch on random frame sizes and 7/8, 13/16 chains (with and without the blur) ==
+    the oracle running the reference tests' scalar functions in the same order on a zeroed stacked buffer."""
+    import torch
+    from pislam_amd.capi import PislamError
+    from pislam_amd.frontend import PyramidBuilder
+    ran = 0
+    for t in range(80):
+        rng = np.random.default_rng(59000 + t)
+        w0, h0 = int(rng.integers(16, 700)), int(rng.integers(16, 400))
+        steps = tuple(int(v) for v in rng.integers(1, 3, int(rng.integers(1, 8))))
+        blur = bool(rng.integers(0, 2))
+        try:
+            pb = PyramidBuilder(w0, h0, steps, blur=blur, ctx=gpu_ctx)
+        except PislamError:
+            continue                                  # a level shrinks to nothing: rejected by the layout
+        ran += 1
+        batch = int(rng.integers(1, 4))
+        frames = rng.integers(0, 256, (batch, h0, w0), dtype=np.uint8)
+        d_pyr = torch.empty((batch, pb.rows, pb.vstep), dtype=torch.uint8, device="cuda")
+        pb(torch.from_numpy(frames).cuda(), d_pyr)
+        torch.cuda.synchronize()
+        got = d_pyr.cpu().numpy()
+        for b in range(batch):
+            exp = np.zeros((pb.rows, pb.vstep), np.uint8)
+            w, h, r0, _ = pb.levels[0]
+            exp[r0:r0 + h, :w] = frames[b]
+            if blur:
+                orc.gaussian5x5(exp[r0:], w, h)
+            for k, st in enumerate(steps):
+                w, h, r0, _ = pb.levels[k]
+                tmp = exp[r0:].copy()                 # out of place: level k -> level k+1 slot
+                (orc.bilinear7_8 if st == 1 else orc.bilinear13_16)(tmp, w, h)
+                r1 = pb.levels[k + 1][2]
+                N, M = (8, 7) if st == 1 else (16, 13)
+                oh, ow = -(-h // N) * M, -(-w // N) * M
+                exp[r1:r1 + oh, :ow] = tmp[:oh, :ow]
+            assert (got[b] == exp).all(), (t, w0, h0, steps, blur)
+    assert ran > 60
