@@ -203,7 +203,9 @@ def main():
             graphs = []
             for o in outs:
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, stream=stream):
+                # thread_local: API calls of other threads (the RCCL watchdog of a multi-rank run) must not
+                # invalidate the capture
+                with torch.cuda.graph(g, stream=stream, capture_error_mode="thread_local"):
                     launches(*o)
                 graphs.append(g)
             for o, g, w in zip(outs, graphs, want):
@@ -229,11 +231,14 @@ def main():
     # Clock ramp: the GPU idles at a few hundred MHz and needs a fraction of a second of load to reach its
     # sustained clocks — far longer than a handful of 0.4 ms steps.  Spin the same step, untimed, before the W
     # warm-up steps so that W and K measure the steady state whatever their values.
+    # (No collective in here: the loop is time-based, so ranks run different iteration counts.)
     t_spin = time.perf_counter()
     while time.perf_counter() - t_spin < args.spin_s:
         for _ in range(8):
-            step()
-        xchg.finish()
+            if graphs is not None:
+                graphs[0].replay()
+            else:
+                launches(*outs[0])
         torch.cuda.synchronize()
     for _ in range(args.warmup):
         step()

@@ -626,3 +626,22 @@ def test_fused_borders(gpu_ctx, orc, border):
                     assert (k[b, :c[b]] == okp).all() and (d[b, :c[b]] == odesc).all(), (border, lbs, alias)
     finally:
         gpu_ctx.set_option("alias", 1)
+
+
+def test_bench_two_ranks_on_one_gpu_does_not_deadlock():
+    """bench.py under torchrun with 2 ranks (gloo test mode: both ranks share this box's one GPU): every
+    collective must be reached by both ranks the same number of times — time-based loops may hold none —
+    and rank 0 prints the one JSON line."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", "29541", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "6",
+           "--warmup", "2", "--batch", "16", "--dist-backend", "gloo", "--no-cpu-baseline", "--spin-s", "0.2"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=240, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["steps"] == 6 and d["value"] > 0 and d["config"]["global_batch"] == 32
