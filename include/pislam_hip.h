@@ -54,7 +54,7 @@ int pislam_ctx_set_stream(pislam_ctx *ctx, void *hip_stream);
  *   "strip_rows" fused strip height (0 = heuristic);  "run_len" strips per workgroup run (0 = by batch)
  *   "alias"      1 (default) score tile laid over the dead image rows + overflow pass, 0 separate tiles
  *   "xtile_cols" image x-tiles inside a strip (0 = full width);  "orb_chunks" gather+ORB workgroups per pyramid
- *   "wgs_per_cu", "lds_pad", "ablate"  profiling only (ablate != 0 gives INVALID results by design) */
+ *   "wgs_per_cu", "lds_pad", "repeat_strips", "ablate"  profiling only (ablate != 0 gives INVALID results by design) */
 int pislam_ctx_set_option(pislam_ctx *ctx, const char *key, int value);
 int pislam_ctx_synchronize(pislam_ctx *ctx);
 const char *pislam_last_error(const pislam_ctx *ctx);

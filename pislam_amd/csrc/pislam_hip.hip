@@ -95,6 +95,7 @@ struct pislam_ctx {
   int opt_ablate = 0;        // profiling only: skip phases of the fused kernel (results invalid)
   int opt_orb_chunks = 0;    // fused pipeline: workgroups per pyramid in k_gather_orb (0 = heuristic)
   uint32_t last_strips = 0;  // strips of the last fused batch call (pislam_frontend_last_stats)
+  int opt_repeat_strips = 1; // profiling: launch the strip kernel n times inside the stage-0 event bracket
   int opt_alias = 1;         // fused pipeline: score tile laid over the dead image rows (0 = separate tiles)
   int opt_run_len = 0;       // fused pipeline: strips per workgroup run (0 = default, 1 = independent strips)
   int opt_xtile_cols = 0;    // fused pipeline: max classified columns per image x-tile (0 = full width)
@@ -396,6 +397,9 @@ PISLAM_EXPORT int pislam_ctx_set_option(pislam_ctx *c, const char *key, int valu
   } else if (!strcmp(key, "xtile_cols")) {
     if (value > 0 && value < 64) return fail(c, PISLAM_ERR_INVALID, "xtile_cols must be 0 (full width), >= 64, or negative (default)");
     c->opt_xtile_cols = value < 0 ? 0 : value;   // (the default is set in one place: here)
+  } else if (!strcmp(key, "repeat_strips")) {
+    if (value < 1 || value > 64) return fail(c, PISLAM_ERR_INVALID, "repeat_strips must be 1..64");
+    c->opt_repeat_strips = value;
   } else if (!strcmp(key, "alias")) {
     c->opt_alias = value != 0;
   } else if (!strcmp(key, "run_len")) {
@@ -1005,8 +1009,14 @@ int run_fused(pislam_ctx *c, const pislam_frontend_params *p, const pf::FusedPar
       prof = c->w_prof.as<unsigned long long>();
       HIPCHK(c, hipMemsetAsync(prof, 0, prof_n * sizeof(unsigned long long), c->stream));
     }
-    hipLaunchKernelGGL(kern, grid, dim3(pf::NT), klds, c->stream, F, pyramids, stride, c->w_stage.as<uint32_t>(),
-                       c->w_stripcnt.as<uint32_t>(), dump, dump_stride, prof, ovf);
+    // (profiling option "repeat_strips": the strip kernel launched n times back to back inside the stage-0
+    //  event bracket, so that the per-launch duration is not inflated by the command-processor latency
+    //  around a single eager launch; every launch rewrites the same outputs)
+    for (int rep = 0; rep < std::max(1, c->opt_repeat_strips); rep++) {
+      if (rep && ovf) HIPCHK(c, hipMemsetAsync(ovf, 0, sizeof(uint32_t), c->stream));   // the last launch's list counts
+      hipLaunchKernelGGL(kern, grid, dim3(pf::NT), klds, c->stream, F, pyramids, stride, c->w_stage.as<uint32_t>(),
+                         c->w_stripcnt.as<uint32_t>(), dump, dump_stride, prof, ovf);
+    }
     if (prof) {
       std::vector<unsigned long long> hv(prof_n);
       HIPCHK(c, hipMemcpyAsync(hv.data(), prof, prof_n * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
