@@ -36,6 +36,15 @@ WORKER = textwrap.dedent('''
         assert torch.equal(allc, exp), (allc, exp)
         off = pdist.global_offsets(allc)
         assert off[0] == 0 and off[-1] == int(exp[:-1].sum())
+    elif mode == "exchange":
+        # bench.py's per-step exchange: two alternating count buffers, the last step's gather is returned
+        x = pdist.CountExchange(world)
+        bufs = [torch.zeros(4, dtype=torch.int32) for _ in range(2)]
+        for i in range(5):
+            bufs[i & 1].fill_(10 * i + rank)
+            x.start(bufs[i & 1])
+        allc = x.finish()
+        assert allc.tolist() == [40] * 4 + [41] * 4, allc
     else:
         # strong scaling / ragged: 7 pyramids over 2 ranks -> 4 + 3, results independent of the sharding
         G = 7
@@ -52,7 +61,7 @@ WORKER = textwrap.dedent('''
 ''') % ROOT
 
 
-@pytest.mark.parametrize("mode", ["equal", "ragged"])
+@pytest.mark.parametrize("mode", ["equal", "ragged", "exchange"])
 def test_two_rank_gloo_count_allgather(tmp_path, mode):
     script = tmp_path / "worker.py"
     script.write_text(WORKER)
