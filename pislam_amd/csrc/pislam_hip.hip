@@ -1122,6 +1122,20 @@ PISLAM_EXPORT int pislam_frontend_reserve(pislam_ctx *c, const pislam_frontend_p
       (p->log_bucket_size &&
        c->w_cellkp.ensure(sizeof(uint32_t) * maxn * batch * p->bucket_limit) != PISLAM_OK))
     return fail(c, PISLAM_ERR_NOMEM, "hipMalloc(extract scratch)");
+  // fused pipeline: strip staging, strip counts, overflow list (so that the batch call itself allocates
+  // nothing — it can then be captured into a hipGraph)
+  if (c->opt_pipeline != 1) {
+    pf::FusedParams F;
+    size_t lds = 0, lds_alias = 0;
+    if (build_fused_plan(c, p, lv, batch, &F, &lds, &lds_alias) && F.strips_per_pyr > 0) {
+      bool grew_ovf = false;
+      if (c->w_stage.ensure(sizeof(uint32_t) * (size_t)F.slots_per_pyr * batch) != PISLAM_OK ||
+          c->w_stripcnt.ensure(sizeof(uint32_t) * (size_t)F.strips_per_pyr * batch) != PISLAM_OK ||
+          c->w_ovf.ensure(sizeof(uint32_t) * ((size_t)F.strips_per_pyr * batch + 2), &grew_ovf) != PISLAM_OK)
+        return fail(c, PISLAM_ERR_NOMEM, "hipMalloc(fused staging)");
+      if (grew_ovf) HIPCHK(c, hipMemsetAsync(c->w_ovf.p, 0, 2 * sizeof(uint32_t), c->stream));
+    }
+  }
   return PISLAM_OK;
 }
 
