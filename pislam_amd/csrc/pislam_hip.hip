@@ -908,7 +908,12 @@ bool build_fused_plan(const pislam_ctx *c, const pislam_frontend_params *p, cons
     }
     if (p->log_bucket_size) {            // strips hold whole bucket rows
       const int bs = 1 << p->log_bucket_size;
-      R = std::max(bs, (R / bs) * bs);
+      if (c->opt_strip_rows == 0 && c->opt_alias)
+        // heuristic height: round UP to whole bucket rows (16-px buckets: 32-row strips — measured 0.315 ms
+        // vs 0.371 ms with 16-row strips, although level 0 then keeps only 4 workgroups per CU)
+        R = std::min(std::max(bs, 32), ((R + bs - 1) / bs) * bs);
+      else
+        R = std::max(bs, (R / bs) * bs);
     }
     L.R = R;
     L.nstrips = cdiv(ny, R);
