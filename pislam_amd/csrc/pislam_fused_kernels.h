@@ -66,6 +66,8 @@ struct FusedLevel {
   int tpitch;        // LDS IMAGE tile pitch in bytes (multiple of 16) = tcols + halo
   int nruns, run0;   // runs (= workgroups) of this level: run_len consecutive strips each
   int apad;          // ALIAS layout: bytes between the per-wave queues and the image tile (multiple of 16)
+  int qh;            // ALIAS layout: entries of the shared corner queue (>= QH_SHARED: the plan hands the LDS
+                     // a level's narrower tiles leave under the residency budget to its queue)
   int tbytes;        // plain layout: bytes reserved for the image tile = max((R+10)*tpitch, the scan
                      // fallbacks' survivor / per-cell buffers — larger only with narrow x-tiles)
   uint32_t vpr_recip; // ceil(2^32 / (tpitch/16)): row = umulhi(i, vpr_recip) for i < 2^16
@@ -208,7 +210,7 @@ __device__ __forceinline__ void strip_body(const StripArgs A, const FusedLevel L
         kept += __popcll(m);
       }
       if (lane < 8)
-        sh_ctr[lane] = lane == 1 ? QH_SHARED : (lane == 2 || (ALIAS && lane == 0)) ? (uint32_t)kept : 0u;
+        sh_ctr[lane] = lane == 1 ? (uint32_t)(ALIAS ? L.qh : QH_SHARED) : (lane == 2 || (ALIAS && lane == 0)) ? (uint32_t)kept : 0u;
     }
     lds_barrier();
     if (!ALIAS) {
@@ -220,7 +222,7 @@ __device__ __forceinline__ void strip_body(const StripArgs A, const FusedLevel L
       const int nz = ((L.R + 3) * pitch) >> 4;
       for (int i = tid; i < nz; i += NT) ((lds_u4 *)sc)[i] = (u32x4)(0u);
     }
-    if (tid < 8) sh_ctr[tid] = tid == 1 ? QH_SHARED : 0;
+    if (tid < 8) sh_ctr[tid] = tid == 1 ? (uint32_t)(ALIAS ? L.qh : QH_SHARED) : 0u;
   }
   lds_u32 *qg = queues + wave * QCAP;              // 4-pixel groups for the exact pretest
   lds_u32 *qf = qg + QCAP_G;                       // FAST candidates
@@ -229,7 +231,8 @@ __device__ __forceinline__ void strip_body(const StripArgs A, const FusedLevel L
   // and are scored by all waves together once FAST is finished.  The waves' left-over FAST
   // candidates (< 64 each) are merged the same way.
   lds_u32 *shq_h = shq;
-  lds_u32 *shq_n = shq_h + QH_SHARED;
+  lds_u32 *shq_n = shq_h + QH_SHARED;               // (plain layout only)
+  const int qcap = ALIAS ? L.qh : QH_SHARED;         // capacity of the shared corner queue
   int ng = 0, nf = 0;                               // wave-uniform queue fills
   // NOTE: the lambdas below capture by reference; they must only touch LOCAL copies of kernel
   // arguments — capturing `P` itself makes the compiler spill the whole 800-byte struct to scratch.
@@ -293,7 +296,7 @@ __device__ __forceinline__ void strip_body(const StripArgs A, const FusedLevel L
       int base = 0;
       if (lane == 0) base = (int)atomicAdd(&sh_ctr[0], (uint32_t)cnt);
       base = __builtin_amdgcn_readfirstlane(base);
-      if (base + cnt <= QH_SHARED) {
+      if (base + cnt <= qcap) {
         if (q) shq_h[base + ballot_rank(m)] = (ALIAS && !toh) ? e | 0xff000000u : e;
       } else {                                     // queue full
         if (lane == 0) {
@@ -537,7 +540,7 @@ __device__ __forceinline__ void strip_body(const StripArgs A, const FusedLevel L
     mark(2);
     if (!ALIAS && tid == 0) {                       // fresh corner queue for the next x-tile
       sh_ctr[0] = 0;
-      sh_ctr[1] = QH_SHARED;
+      sh_ctr[1] = QH_SHARED;                        // (plain layout: qcap == QH_SHARED)
     }
   }
   if (ablate & 1) return;

@@ -944,8 +944,13 @@ bool build_fused_plan(const pislam_ctx *c, const pislam_frontend_params *p, cons
       const long need = (long)pf::NMS_SCRATCH * 4 + (long)(R + 3) * L.pitch;
       const long have = (long)pf::WAVES * pf::QCAP * 4 + (long)R * L.tpitch;
       L.apad = need > have ? (int)((need - have + 15) & ~15L) : 0;
-      lds_alias = std::max(lds_alias, (size_t)pf::WAVES * pf::QCAP * 4 + (size_t)L.apad + (size_t)(R + 10) * L.tpitch +
-                                          (size_t)pf::QH_SHARED * 4);   // (one shared queue in this layout)
+      // one shared queue in this layout: at least QH_SHARED entries, and whatever LDS the level's tile
+      // leaves under the 5-workgroups-per-CU budget (narrow levels of a textured photo are the dense ones)
+      const long fixed = (long)pf::WAVES * pf::QCAP * 4 + L.apad + (long)(R + 10) * L.tpitch;
+      // (margin of 1280 B: static LDS + allocation granule — with 512 B the kernel measurably lost its 5th workgroup)
+      const long spare = (160 * 1024 / 5 - 1280 - fixed) / 4;
+      L.qh = (int)std::min<long>(4096, std::max<long>(pf::QH_SHARED, spare & ~3L));
+      lds_alias = std::max(lds_alias, (size_t)fixed + (size_t)L.qh * 4);
     }
   }
   // Runs: a workgroup walks run_len consecutive strips of a level (halo carried in LDS).  Longer runs
