@@ -49,14 +49,15 @@ __global__ __launch_bounds__(256) void k_gaussian5x5(const uint8_t *__restrict__
   uint8_t *d = dst + (size_t)blockIdx.z * stride_dst;
   const int x0 = blockIdx.x * G_TW, y0 = blockIdx.y * G_TH;
   constexpr int DW = G_PW / 4;                       // 34 dwords per staged row: columns x0-4 .. x0+131
-  const bool interior = x0 >= 4 && x0 + G_TW + 4 <= width && (((uintptr_t)s) & 3) == 0 && (vstep_src & 3) == 0;
+  const bool aligned = (((uintptr_t)s) & 3) == 0 && (vstep_src & 3) == 0;
   for (int i = threadIdx.x; i < (G_TH + 4) * DW; i += 256) {
     const int r = i / DW, q = i - r * DW;
     const int gy = min(max(reflect101(y0 - 2 + r, height), 0), height - 1);
     const uint8_t *row = s + (ptrdiff_t)gy * vstep_src;
+    const int gx0 = x0 - 4 + 4 * q;
     uint32_t w;
-    if (interior) {
-      w = *(const uint32_t *)(row + x0 - 4 + 4 * q);
+    if (aligned && gx0 >= 0 && gx0 + 4 <= width) {   // dword inside the image: one aligned load (also in border tiles)
+      w = *(const uint32_t *)(row + gx0);
     } else {
       w = 0;
 #pragma unroll
