@@ -28,7 +28,9 @@ __device__ __forceinline__ int reflect101(int i, int n) {
 // src and dst must not alias (the ABI stages in-place calls through a temporary).
 // ---------------------------------------------------------------------------
 constexpr int G_TW = 128, G_TH = 32;
-constexpr int G_PW = G_TW + 8;                       // LDS row: 4 halo bytes (2 used) on either side, dword aligned
+constexpr int G_DW = 40;                             // LDS row pitch in dwords: [3] = left halo dword (x0-4..x0-1),
+                                                     // [4..35] = the tile's 128 columns (16-byte aligned), [36] = right halo
+constexpr int G_NC = G_TW / 4 + 2;                   // 34 dword columns take part in the vertical pass
 
 // byte-wise rounding halving add of 4 packed pixels in ONE instruction: v_lerp_u8 computes
 // (a + b + (c & 1)) >> 1 per byte, i.e. NEON's vrhadd.u8 with c = 0x01010101
@@ -39,52 +41,71 @@ __device__ __forceinline__ uint32_t tap5x4(uint32_t a, uint32_t b, uint32_t c, u
   return rhadd4(rhadd4(rhadd4(rhadd4(a, e), c), c), rhadd4(b, d));
 }
 
-// One workgroup = one 128 x 32 output tile (36 staged rows: 12 % halo).  Rows are staged as dwords (interior tiles: aligned
-// 4-byte loads; tiles touching the left/right image border or an unaligned source: per-byte with
-// the reflect-101 rule), both passes work on 4 packed pixels per lane (SWAR RHADD), the horizontal
-// taps come from v_alignbyte on aligned LDS dwords, and each lane stores one dword.
+typedef uint32_t g_u32x4 __attribute__((ext_vector_type(4)));
+
+// One workgroup = one 128 x 32 output tile (36 staged rows: 12 % halo).  Full, 16-byte aligned tiles stage
+// their 128 columns with 16-byte loads (8 per row) plus one halo dword on either side; partial or
+// unaligned tiles stage dword by dword (aligned loads inside the image, per-byte with the reflect-101
+// rule across its border).  Both passes work on 4 packed pixels per lane, the vertical one with a fixed
+// dword column per lane (no index arithmetic in its loop), the horizontal taps come from v_alignbyte on
+// aligned LDS dwords, and each lane stores one dword.
 __global__ __launch_bounds__(256) void k_gaussian5x5(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst,
                                                      int vstep_src, int vstep_dst, size_t stride_src,
                                                      size_t stride_dst, int width, int height) {
-  __shared__ __attribute__((aligned(16))) uint32_t in[(G_TH + 4) * (G_PW / 4)];
-  __shared__ __attribute__((aligned(16))) uint32_t mid[G_TH * (G_PW / 4)];
+  __shared__ __attribute__((aligned(16))) uint32_t in[(G_TH + 4) * G_DW];
+  __shared__ __attribute__((aligned(16))) uint32_t mid[G_TH * G_DW];
   const uint8_t *s = src + (size_t)blockIdx.z * stride_src;
   uint8_t *d = dst + (size_t)blockIdx.z * stride_dst;
   const int x0 = blockIdx.x * G_TW, y0 = blockIdx.y * G_TH;
-  constexpr int DW = G_PW / 4;                       // 34 dwords per staged row: columns x0-4 .. x0+131
-  const bool aligned = (((uintptr_t)s) & 3) == 0 && (vstep_src & 3) == 0;
-  for (int i = threadIdx.x; i < (G_TH + 4) * DW; i += 256) {
-    const int r = i / DW, q = i - r * DW;
-    const int gy = min(max(reflect101(y0 - 2 + r, height), 0), height - 1);
-    const uint8_t *row = s + (ptrdiff_t)gy * vstep_src;
-    const int gx0 = x0 - 4 + 4 * q;
-    uint32_t w;
-    if (aligned && gx0 >= 0 && gx0 + 4 <= width) {   // dword inside the image: one aligned load (also in border tiles)
-      w = *(const uint32_t *)(row + gx0);
-    } else {
-      w = 0;
+  const int tid = threadIdx.x;
+  const bool aligned4 = (((uintptr_t)s) & 3) == 0 && (vstep_src & 3) == 0;
+  const bool vec_ok = (((uintptr_t)s) & 15) == 0 && (vstep_src & 15) == 0 && x0 + G_TW <= width;
+  // one dword of the staged tile: aligned load inside the image, per-byte reflect-101 across its border
+  auto stage_dword = [&](const uint8_t *row, int gx0) -> uint32_t {
+    if (aligned4 && gx0 >= 0 && gx0 + 4 <= width) return *(const uint32_t *)(row + gx0);
+    uint32_t w = 0;
 #pragma unroll
-      for (int k = 0; k < 4; k++) {
-        const int gx = min(max(reflect101(x0 - 4 + 4 * q + k, width), 0), width - 1);
-        w |= (uint32_t)row[gx] << (8 * k);
-      }
+    for (int k = 0; k < 4; k++) {
+      const int gx = min(max(reflect101(gx0 + k, width), 0), width - 1);
+      w |= (uint32_t)row[gx] << (8 * k);
     }
-    in[i] = w;
+    return w;
+  };
+  if (vec_ok) {
+    for (int i = tid; i < (G_TH + 4) * 8; i += 256) {          // 8 x 16 bytes per row
+      const int r = i >> 3, v = i & 7;
+      const int gy = min(max(reflect101(y0 - 2 + r, height), 0), height - 1);
+      *(g_u32x4 *)&in[r * G_DW + 4 + 4 * v] = *(const g_u32x4 *)(s + (ptrdiff_t)gy * vstep_src + x0 + 16 * v);
+    }
+    if (tid < (G_TH + 4) * 2) {                                // the two halo dwords of every row
+      const int r = tid >> 1, side = tid & 1;
+      const int gy = min(max(reflect101(y0 - 2 + r, height), 0), height - 1);
+      in[r * G_DW + (side ? 36 : 3)] = stage_dword(s + (ptrdiff_t)gy * vstep_src, side ? x0 + G_TW : x0 - 4);
+    }
+  } else {
+    for (int i = tid; i < (G_TH + 4) * G_NC; i += 256) {
+      const int r = i / G_NC, q = i - r * G_NC;
+      const int gy = min(max(reflect101(y0 - 2 + r, height), 0), height - 1);
+      in[r * G_DW + 3 + q] = stage_dword(s + (ptrdiff_t)gy * vstep_src, x0 - 4 + 4 * q);
+    }
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < G_TH * DW; i += 256) {
-    const int r = i / DW, q = i - r * DW;
-    const uint32_t *p = in + r * DW + q;
-    mid[i] = tap5x4(p[0], p[DW], p[2 * DW], p[3 * DW], p[4 * DW]);
+  // vertical pass: lane = (row group, dword column), 7 row groups x 34 columns = 238 lanes
+  if (tid < 7 * G_NC) {
+    const int rg = tid / G_NC, q = tid - rg * G_NC;
+    for (int r = rg; r < G_TH; r += 7) {
+      const uint32_t *p = in + r * G_DW + 3 + q;
+      mid[r * G_DW + 3 + q] = tap5x4(p[0], p[G_DW], p[2 * G_DW], p[3 * G_DW], p[4 * G_DW]);
+    }
   }
   __syncthreads();
   // horizontal pass on the vertical result; the staged halo columns already hold the reflected
   // columns (reflection commutes with the column-wise vertical pass), GaussianTest.cpp:189-213
-  for (int i = threadIdx.x; i < G_TH * (G_TW / 4); i += 256) {
-    const int r = i / (G_TW / 4), q = i - r * (G_TW / 4);
+  for (int i = tid; i < G_TH * (G_TW / 4); i += 256) {
+    const int r = i >> 5, q = i & 31;
     const int gy = y0 + r, gx = x0 + 4 * q;
     if (gy >= height || gx >= width) continue;
-    const uint32_t *p = mid + r * DW + q + 1;          // dword holding columns gx .. gx+3
+    const uint32_t *p = mid + r * G_DW + 4 + q;        // dword holding columns gx .. gx+3
     const uint32_t wl = p[-1], wc = p[0], wr = p[1];
     const uint32_t o = tap5x4(__builtin_amdgcn_alignbyte(wc, wl, 2), __builtin_amdgcn_alignbyte(wc, wl, 3), wc,
                               __builtin_amdgcn_alignbyte(wr, wc, 1), __builtin_amdgcn_alignbyte(wr, wc, 2));
