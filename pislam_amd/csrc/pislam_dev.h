@@ -61,6 +61,43 @@ __device__ __forceinline__ bool fast9(const P *c, int pitch, int thr) {
   return has_arc9(dm) || has_arc9(bm);
 }
 
+// The same decision with the multimedia byte instructions: the 16 ring pixels are packed 4 per dword
+// and compared 4 at a time with v_lerp_u8 — lerp(a, ~b, 1) = (a + 255 - b + 1) >> 1 per byte, whose
+// bit 7 is [a >= b].  With hi = min(c + t, 255) and lo = max(c - t, 0) (the reference's saturating
+// forms, Fast.h:63-64):  NOT bright = [hi >= p],  NOT dark = [p >= lo].  The four flag bits of a dword
+// are gathered with v_dot4_u32_u8 (weights = bit positions, flags are 0x80 -> the sum is 128 x the
+// bits).  ~40 VALU for the two 16-bit masks instead of 64 (one subtract + one v_alignbit per pixel and
+// side in fast9); identical result.
+template <class P>
+__device__ __forceinline__ bool fast9_mm(const P *c, int pitch, int thr) {
+  const int v = c[0];
+  // bright: p > c+t  <=>  p >= hi1 with hi1 = c+t+1 (impossible when hi1 > 255);  dark: p < lo  <=>  NOT p >= lo
+  const int hi1 = v + thr + 1;
+  const uint32_t nhi4 = ~((uint32_t)min(hi1, 255) * 0x01010101u);
+  const uint32_t nlo4 = ~((uint32_t)max(v - thr, 0) * 0x01010101u);
+  uint32_t px[16];
+#define PISLAM_F(k, dy, dx) px[k] = c[(dy) * pitch + (dx)];
+  PISLAM_RING16(PISLAM_F)
+#undef PISLAM_F
+  uint32_t tb[2] = {0u, 0u}, td[2] = {0u, 0u};         // 128 x the low / high 8 mask bits
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    // 4 zero-extended bytes -> one dword with three v_perm_b32
+    const uint32_t t01 = __builtin_amdgcn_perm(px[4 * j + 1], px[4 * j], 0x0c0c0400u);
+    const uint32_t t23 = __builtin_amdgcn_perm(px[4 * j + 3], px[4 * j + 2], 0x0c0c0400u);
+    const uint32_t w = __builtin_amdgcn_perm(t23, t01, 0x05040100u);
+    const uint32_t gb = __builtin_amdgcn_lerp(w, nhi4, 0x01010101u);      // bit 7 of a byte: p >= hi1 (bright)
+    const uint32_t nd = __builtin_amdgcn_lerp(w, nlo4, 0x01010101u);      // bit 7 of a byte: p >= lo (not dark)
+    const uint32_t wt = (j & 1) ? 0x80402010u : 0x08040201u;
+    tb[j >> 1] = __builtin_amdgcn_udot4(gb & 0x80808080u, wt, tb[j >> 1], false);
+    td[j >> 1] = __builtin_amdgcn_udot4(~nd & 0x80808080u, wt, td[j >> 1], false);
+  }
+  uint32_t bm = (tb[0] >> 7) | (tb[1] << 1);
+  const uint32_t dm = (td[0] >> 7) | (td[1] << 1);
+  if (hi1 > 255) bm = 0;
+  return has_arc9(dm) || has_arc9(bm);
+}
+
 // The same test when it is known per lane which side can hold an arc.  A dark arc and a bright arc
 // cannot coexist (9 + 9 > 16), and "p < lo" <=> "~p > ~lo", so one compare per ring pixel suffices:
 // side = 0 tests p > hi, side = -1 tests ~p > ~lo.  Lanes whose compass test fired on BOTH sides

@@ -282,7 +282,7 @@ __device__ __forceinline__ void strip_body(const StripArgs A, const FusedLevel L
     const int x = e & 0xffff, r = e >> 16;
     // (a one-sided test keyed on which compass side fired was measured: 16 % of the candidates fire on
     //  both sides, so nearly every 64-lane batch needed the second pass and it was slower)
-    if (valid) corner = fast9(tile + (r + 3) * tpitch + x, tpitch, thr);
+    if (valid) corner = fast9_mm(tile + (r + 3) * tpitch + x, tpitch, thr);
     // Fast.h:172: only x < w-B is scored; over-classified columns keep 0xff
     const bool toh = corner && x < Lw - B;
     if (!ALIAS) {
