@@ -234,6 +234,71 @@ __device__ __forceinline__ uint8_t harris_score_pk(const lds_byte *row0, int pit
   return harris_eval(sxx >> 4, syy >> 4, sxy >> 4, threshold);
 }
 
+// The same score with the gradients computed in the BYTE domain, as the reference's NEON code does
+// (vhsub.u8 / vhadd.s8 on 8-bit lanes, Harris.h:123-162), 4 pixels per instruction:
+//   floor((a - b) / 2) + 128 = v_lerp_u8(a, ~b, 1)      (a - b + 256) >> 1 — never leaves a byte)
+//   floor((e + f) / 2) + 128 = v_lerp_u8(E, F, 0)       for E = e + 128, F = f + 128
+// so a difference and both halving adds of the Sobel chains are single instructions on offset-binary
+// bytes.  Only the products need 16 bits (vmull.s8 / vmlal.s8 wrap there, Harris.h:164-200): the
+// gradients are widened to packed i16 pairs (v_perm_b32, minus the bias) and multiplied exactly as in
+// harris_score_pk.  ~320 VALU instead of ~430 per 64 corners; identical result.
+__device__ __forceinline__ uint8_t harris_score_mm(const lds_byte *row0, int pitch_bytes, int32_t threshold) {
+  const uint32_t sh = (uint32_t)(uintptr_t)row0 & 3u;     // tile base and pitch are 16-byte aligned
+  const lds_byte *base = row0 - sh;
+  constexpr uint32_t ONE4 = 0x01010101u;
+  uint32_t w0[8], w1[8], n0[8], n1[8], E0[8], E1[8];
+#pragma unroll
+  for (int r = 0; r < 8; r++) {
+    const lds_word *rp = (const lds_word *)(base + r * pitch_bytes);
+    const uint32_t i0 = rp[0], i1 = rp[1], i2 = rp[2];
+    w0[r] = __builtin_amdgcn_alignbyte(i1, i0, sh);        // window columns 0..3 of row r
+    w1[r] = __builtin_amdgcn_alignbyte(i2, i1, sh);        // columns 4..7
+    n0[r] = ~w0[r];
+    n1[r] = ~w1[r];
+    // horizontal differences (P[c+2] - P[c]) >> 1 of columns c = 0..3 and 4..5 (bytes 2,3 of E1 unused)
+    E0[r] = __builtin_amdgcn_lerp(__builtin_amdgcn_alignbyte(w1[r], w0[r], 2), n0[r], ONE4);
+    E1[r] = __builtin_amdgcn_lerp(w1[r] >> 16, n1[r], ONE4);
+  }
+  const pk_s2 bias = {128, 128};
+  pk_s2 dx[6][3], dy[6][3];
+#pragma unroll
+  for (int m = 0; m < 6; m++) {
+    // dx: (((e_m + e_m+2) >> 1) + e_m+1) >> 1, Harris.h:139-162
+    const uint32_t DX0 = __builtin_amdgcn_lerp(__builtin_amdgcn_lerp(E0[m], E0[m + 2], 0u), E0[m + 1], 0u);
+    const uint32_t DX1 = __builtin_amdgcn_lerp(__builtin_amdgcn_lerp(E1[m], E1[m + 2], 0u), E1[m + 1], 0u);
+    // vertical differences (P[m+2] - P[m]) >> 1 of columns 0..3 and 4..7, then
+    // dy: (d_c+1 + ((d_c + d_c+2) >> 1)) >> 1, Harris.h:123-135
+    const uint32_t V0 = __builtin_amdgcn_lerp(w0[m + 2], n0[m], ONE4);
+    const uint32_t V1 = __builtin_amdgcn_lerp(w1[m + 2], n1[m], ONE4);
+    const uint32_t DY0 = __builtin_amdgcn_lerp(__builtin_amdgcn_lerp(V0, __builtin_amdgcn_alignbyte(V1, V0, 2), 0u),
+                                               __builtin_amdgcn_alignbyte(V1, V0, 1), 0u);
+    const uint32_t DY1 = __builtin_amdgcn_lerp(__builtin_amdgcn_lerp(V1, V1 >> 16, 0u), V1 >> 8, 0u);
+    // offset-binary bytes -> packed i16 pairs of columns (0,1) (2,3) (4,5)
+    dx[m][0] = __builtin_bit_cast(pk_s2, __builtin_amdgcn_perm(0, DX0, 0x0c010c00u)) - bias;
+    dx[m][1] = __builtin_bit_cast(pk_s2, __builtin_amdgcn_perm(0, DX0, 0x0c030c02u)) - bias;
+    dx[m][2] = __builtin_bit_cast(pk_s2, __builtin_amdgcn_perm(0, DX1, 0x0c010c00u)) - bias;
+    dy[m][0] = __builtin_bit_cast(pk_s2, __builtin_amdgcn_perm(0, DY0, 0x0c010c00u)) - bias;
+    dy[m][1] = __builtin_bit_cast(pk_s2, __builtin_amdgcn_perm(0, DY0, 0x0c030c02u)) - bias;
+    dy[m][2] = __builtin_bit_cast(pk_s2, __builtin_amdgcn_perm(0, DY1, 0x0c010c00u)) - bias;
+  }
+  uint32_t sxx = 0, syy = 0;
+  int32_t sxy = 0;
+  const pk_s2 one = {1, 1};
+#pragma unroll
+  for (int n = 0; n < 6; n += 2) {
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      const pk_s2 xx = dx[n][k] * dx[n][k] + dx[n + 1][k] * dx[n + 1][k];     // 16-bit wrap per column
+      const pk_s2 yy = dy[n][k] * dy[n][k] + dy[n + 1][k] * dy[n + 1][k];
+      const pk_s2 xy = dx[n][k] * dy[n][k] + dx[n + 1][k] * dy[n + 1][k];
+      sxx = __builtin_amdgcn_udot2(__builtin_bit_cast(pk_u2, xx), __builtin_bit_cast(pk_u2, one), sxx, false);
+      syy = __builtin_amdgcn_udot2(__builtin_bit_cast(pk_u2, yy), __builtin_bit_cast(pk_u2, one), syy, false);
+      sxy = __builtin_amdgcn_sdot2(xy, one, sxy, false);
+    }
+  }
+  return harris_eval(sxx >> 4, syy >> 4, sxy >> 4, threshold);
+}
+
 // ---------------------------------------------------------------------------
 // 2x2-block non-max suppression — reference Fast.h:228-312.
 // s points at S[y][x] (block origin).  Returns the packed keypoint

@@ -271,7 +271,7 @@ __device__ __forceinline__ void strip_body(const StripArgs A, const FusedLevel L
     const bool todo = valid && (!ALIAS || (e >> 24) == 0);
     if (todo) {
       const int x = e & 0xffff, r = (e >> 16) & 0xff;
-      score = (ablate & 32) ? (uint8_t)200 : harris_score_pk(tile + r * tpitch + x - 3, tpitch, hthr);
+      score = (ablate & 32) ? (uint8_t)200 : harris_score_mm(tile + r * tpitch + x - 3, tpitch, hthr);
       if (ALIAS) shq_h[at] = e | ((uint32_t)score << 24);
       else sc[r * pitch + x] = score;
     }
