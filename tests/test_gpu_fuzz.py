@@ -217,3 +217,55 @@ def test_random_pyramid_builds_match_the_oracle(gpu_ctx, orc):
                 exp[r1:r1 + oh, :ow] = tmp[:oh, :ow]
             assert (got[b] == exp).all(), (t, w0, h0, steps, blur)
     assert ran > 60
+
+
+def test_binary_patterns_score_maps_match_the_oracle(gpu_ctx, orc):
+    """Saturated inputs (0/255 checkerboards, stripes, dots, random bits, a few flipped pixels): the extreme
+    gradients (-128, the 16-bit wrap of the row-pair products, Harris.h:164-200) and the densest corner
+    sets.  Score map (dump hook) and keypoints must equal the oracle on both LDS layouts."""
+    import torch
+    from pislam_amd.frontend import OrbFrontend
+    dev = torch.device("cuda:0")
+    try:
+        for t in range(200):
+            rng = np.random.default_rng(83000 + t)
+            w, h = int(rng.integers(60, 200)), int(rng.integers(60, 160))
+            vstep, rows = (w + 15) & ~15, h + 2
+            kind = int(rng.integers(0, 5))
+            yy, xx = np.mgrid[0:rows, 0:vstep]
+            lo_v, hi_v = (0, 255) if rng.integers(0, 2) else (int(rng.integers(0, 3)), int(rng.integers(253, 256)))
+            if kind == 0:
+                m = rng.integers(0, 2, (rows, vstep))
+            elif kind == 1:
+                p = int(rng.integers(1, 6))
+                m = (yy // p + xx // p) & 1
+            elif kind == 2:
+                p = int(rng.integers(1, 5))
+                m = ((xx // p) & 1) if rng.integers(0, 2) else ((yy // p) & 1)
+            elif kind == 3:
+                p, q = int(rng.integers(1, 5)), int(rng.integers(1, 5))
+                m = ((yy // p) & 1) & ((xx // q) & 1)
+            else:
+                m = np.kron(rng.integers(0, 2, (rows // 3 + 2, vstep // 3 + 2)), np.ones((3, 3), np.int64))[:rows, :vstep]
+            img = np.where(m > 0, hi_v, lo_v).astype(np.uint8)
+            if rng.integers(0, 3) == 0:
+                flip = rng.integers(0, 20, img.shape) == 0
+                img = np.where(flip, rng.integers(0, 256, img.shape), img).astype(np.uint8)
+            thr = int(rng.choice([0, 1, 20, 100, 254]))
+            hthr = int(rng.choice([-(1 << 31), -(1 << 20), 0, 1 << 15, 1 << 26]))
+            gpu_ctx.set_option("pipeline", 2)
+            gpu_ctx.set_option("dump_score", 1)
+            gpu_ctx.set_option("alias", int(rng.integers(0, 2)))
+            fe = OrbFrontend([(w, h, 0)], vstep=vstep, rows=rows, max_keypoints=8192, fast_threshold=thr,
+                             harris_threshold=hthr, ctx=gpu_ctx)
+            kp, desc, counts = fe.alloc_outputs(1, dev)
+            fe(torch.from_numpy(img[None].copy()).to(dev), kp, desc, counts)
+            torch.cuda.synchronize()
+            okp, _, _, osc = orc.pyramid(img, [(w, h, 0)], fast_threshold=thr, harris_threshold=hthr, return_score=True)
+            c = int(counts.cpu().numpy().view(np.uint32)[0])
+            m_ = min(len(okp), 8192)
+            assert (fe.score_map(0) == osc).all(), (t, w, h, kind, thr, hthr)
+            assert c == len(okp) and (kp.cpu().numpy().view(np.uint32)[0, :m_] == okp[:m_]).all(), (t, w, h, kind, thr, hthr)
+    finally:
+        for k, v in dict(pipeline=0, alias=1, dump_score=0).items():
+            gpu_ctx.set_option(k, v)
