@@ -239,9 +239,8 @@ __device__ __forceinline__ uint8_t harris_score_pk(const lds_byte *row0, int pit
 //   floor((a - b) / 2) + 128 = v_lerp_u8(a, ~b, 1)      (a - b + 256) >> 1 — never leaves a byte)
 //   floor((e + f) / 2) + 128 = v_lerp_u8(E, F, 0)       for E = e + 128, F = f + 128
 // so a difference and both halving adds of the Sobel chains are single instructions on offset-binary
-// bytes.  Only the products need 16 bits (vmull.s8 / vmlal.s8 wrap there, Harris.h:164-200): the
-// gradients are widened to packed i16 pairs (v_perm_b32, minus the bias) and multiplied exactly as in
-// harris_score_pk.  ~320 VALU instead of ~430 per 64 corners; identical result.
+// bytes, and the products are v_dot4_i32_i8 (see below why the reference's 16-bit product lanes never
+// wrap).  ~260 VALU instead of ~430 per 64 corners; identical result.
 __device__ __forceinline__ uint8_t harris_score_mm(const lds_byte *row0, int pitch_bytes, int32_t threshold) {
   const uint32_t sh = (uint32_t)(uintptr_t)row0 & 3u;     // tile base and pitch are 16-byte aligned
   const lds_byte *base = row0 - sh;
@@ -259,8 +258,13 @@ __device__ __forceinline__ uint8_t harris_score_mm(const lds_byte *row0, int pit
     E0[r] = __builtin_amdgcn_lerp(__builtin_amdgcn_alignbyte(w1[r], w0[r], 2), n0[r], ONE4);
     E1[r] = __builtin_amdgcn_lerp(w1[r] >> 16, n1[r], ONE4);
   }
-  const pk_s2 bias = {128, 128};
-  pk_s2 dx[6][3], dy[6][3];
+  // Products.  The reference multiplies on 16-bit lanes (vmull.s8 / vmlal.s8 per row pair, then widening
+  // adds, Harris.h:164-200), but those lanes can never wrap: a gradient is in [-128, 127], so a row pair
+  // of squares is <= 2 * 16384 (fits u16), and dx = dy = -128 at one position is impossible — dx = -128
+  // needs P[m..m+2][c] = 255, P[..][c+2] = 0 while dy = -128 needs P[m+2][c..c+2] = 0 — so a row pair of
+  // dx * dy stays within [-32512, 32512].  The three sums are therefore plain sums of byte products:
+  // v_dot4_i32_i8 on the two's-complement bytes (offset-binary ^ 0x80), 4 positions per instruction.
+  int32_t sxx = 0, syy = 0, sxy = 0;
 #pragma unroll
   for (int m = 0; m < 6; m++) {
     // dx: (((e_m + e_m+2) >> 1) + e_m+1) >> 1, Harris.h:139-162
@@ -273,30 +277,14 @@ __device__ __forceinline__ uint8_t harris_score_mm(const lds_byte *row0, int pit
     const uint32_t DY0 = __builtin_amdgcn_lerp(__builtin_amdgcn_lerp(V0, __builtin_amdgcn_alignbyte(V1, V0, 2), 0u),
                                                __builtin_amdgcn_alignbyte(V1, V0, 1), 0u);
     const uint32_t DY1 = __builtin_amdgcn_lerp(__builtin_amdgcn_lerp(V1, V1 >> 16, 0u), V1 >> 8, 0u);
-    // offset-binary bytes -> packed i16 pairs of columns (0,1) (2,3) (4,5)
-    dx[m][0] = __builtin_bit_cast(pk_s2, __builtin_amdgcn_perm(0, DX0, 0x0c010c00u)) - bias;
-    dx[m][1] = __builtin_bit_cast(pk_s2, __builtin_amdgcn_perm(0, DX0, 0x0c030c02u)) - bias;
-    dx[m][2] = __builtin_bit_cast(pk_s2, __builtin_amdgcn_perm(0, DX1, 0x0c010c00u)) - bias;
-    dy[m][0] = __builtin_bit_cast(pk_s2, __builtin_amdgcn_perm(0, DY0, 0x0c010c00u)) - bias;
-    dy[m][1] = __builtin_bit_cast(pk_s2, __builtin_amdgcn_perm(0, DY0, 0x0c030c02u)) - bias;
-    dy[m][2] = __builtin_bit_cast(pk_s2, __builtin_amdgcn_perm(0, DY1, 0x0c010c00u)) - bias;
+    // signed bytes of columns 0..3 and of columns 4,5 (the unused upper bytes zeroed)
+    const int x0 = (int)(DX0 ^ 0x80808080u), x1 = (int)((DX1 ^ 0x80808080u) & 0x0000ffffu);
+    const int y0 = (int)(DY0 ^ 0x80808080u), y1 = (int)((DY1 ^ 0x80808080u) & 0x0000ffffu);
+    sxx = __builtin_amdgcn_sdot4(x1, x1, __builtin_amdgcn_sdot4(x0, x0, sxx, false), false);
+    syy = __builtin_amdgcn_sdot4(y1, y1, __builtin_amdgcn_sdot4(y0, y0, syy, false), false);
+    sxy = __builtin_amdgcn_sdot4(x1, y1, __builtin_amdgcn_sdot4(x0, y0, sxy, false), false);
   }
-  uint32_t sxx = 0, syy = 0;
-  int32_t sxy = 0;
-  const pk_s2 one = {1, 1};
-#pragma unroll
-  for (int n = 0; n < 6; n += 2) {
-#pragma unroll
-    for (int k = 0; k < 3; k++) {
-      const pk_s2 xx = dx[n][k] * dx[n][k] + dx[n + 1][k] * dx[n + 1][k];     // 16-bit wrap per column
-      const pk_s2 yy = dy[n][k] * dy[n][k] + dy[n + 1][k] * dy[n + 1][k];
-      const pk_s2 xy = dx[n][k] * dy[n][k] + dx[n + 1][k] * dy[n + 1][k];
-      sxx = __builtin_amdgcn_udot2(__builtin_bit_cast(pk_u2, xx), __builtin_bit_cast(pk_u2, one), sxx, false);
-      syy = __builtin_amdgcn_udot2(__builtin_bit_cast(pk_u2, yy), __builtin_bit_cast(pk_u2, one), syy, false);
-      sxy = __builtin_amdgcn_sdot2(xy, one, sxy, false);
-    }
-  }
-  return harris_eval(sxx >> 4, syy >> 4, sxy >> 4, threshold);
+  return harris_eval((uint32_t)sxx >> 4, (uint32_t)syy >> 4, sxy >> 4, threshold);
 }
 
 // ---------------------------------------------------------------------------
