@@ -98,25 +98,6 @@ __device__ __forceinline__ bool fast9_mm(const P *c, int pitch, int thr) {
   return has_arc9(dm) || has_arc9(bm);
 }
 
-// The same test when it is known per lane which side can hold an arc.  A dark arc and a bright arc
-// cannot coexist (9 + 9 > 16), and "p < lo" <=> "~p > ~lo", so one compare per ring pixel suffices:
-// side = 0 tests p > hi, side = -1 tests ~p > ~lo.  Lanes whose compass test fired on BOTH sides
-// (rare) must be run through fast9 instead.
-template <class P>
-__device__ __forceinline__ bool fast9_sided(const P *c, int pitch, int thr, int side /* 0 or -1 */) {
-  const int v = c[0];
-  const int bound = side ? ~(v - thr) : (v + thr);
-  uint32_t m = 0;
-#define PISLAM_F(k, dy, dx)                                       \
-  {                                                               \
-    const int p = c[(dy) * pitch + (dx)];                         \
-    m |= (uint32_t)((p ^ side) > bound) << (k);                   \
-  }
-  PISLAM_RING16(PISLAM_F)
-#undef PISLAM_F
-  return has_arc9(m);
-}
-
 // ---------------------------------------------------------------------------
 // Harris 6x6 Sobel score byte — reference Harris.h:80-248 + harrisEval
 // Harris.h:37-69.  c points at img[y][x].
@@ -183,64 +164,15 @@ typedef __attribute__((address_space(3))) uint32_t lds_word;
 // row0 = &tile[y-3][x-3] in LDS, any byte alignment.  gfx950 serves byte-unaligned ds_read_b32 but
 // stalls ~47 cycles on each (SQ_LDS_UNALIGNED_STALL), so every row is fetched as three aligned
 // dwords and funnel-shifted with v_alignbyte.
-__device__ __forceinline__ uint8_t harris_score_pk(const lds_byte *row0, int pitch_bytes, int32_t threshold) {
-  pk_s2 P[8][4];
-  const uint32_t sh = (uint32_t)(uintptr_t)row0 & 3u;     // tile base and pitch are 16-byte aligned
-  const lds_byte *base = row0 - sh;
-#pragma unroll
-  for (int r = 0; r < 8; r++) {
-    const lds_word *rp = (const lds_word *)(base + r * pitch_bytes);
-    const uint32_t i0 = rp[0], i1 = rp[1], i2 = rp[2];
-    const uint32_t w0 = __builtin_amdgcn_alignbyte(i1, i0, sh), w1 = __builtin_amdgcn_alignbyte(i2, i1, sh);
-    P[r][0] = __builtin_bit_cast(pk_s2, __builtin_amdgcn_perm(0, w0, 0x0c010c00u));
-    P[r][1] = __builtin_bit_cast(pk_s2, __builtin_amdgcn_perm(0, w0, 0x0c030c02u));
-    P[r][2] = __builtin_bit_cast(pk_s2, __builtin_amdgcn_perm(0, w1, 0x0c010c00u));
-    P[r][3] = __builtin_bit_cast(pk_s2, __builtin_amdgcn_perm(0, w1, 0x0c030c02u));
-  }
-  uint32_t sxx = 0, syy = 0;
-  int32_t sxy = 0;
-  const pk_s2 one = {1, 1};
-#pragma unroll
-  for (int n = 0; n < 6; n += 2) {
-    pk_s2 dx[2][3], dy[2][3];
-#pragma unroll
-    for (int h = 0; h < 2; h++) {
-      const int m = n + h;
-#pragma unroll
-      for (int k = 0; k < 3; k++) {
-        // dx: Harris.h:139-162
-        const pk_s2 e0 = (P[m][k + 1] - P[m][k]) >> 1;
-        const pk_s2 e1 = (P[m + 1][k + 1] - P[m + 1][k]) >> 1;
-        const pk_s2 e2 = (P[m + 2][k + 1] - P[m + 2][k]) >> 1;
-        dx[h][k] = (((e0 + e2) >> 1) + e1) >> 1;
-        // dy: Harris.h:123-135
-        const pk_s2 d0 = (P[m + 2][k] - P[m][k]) >> 1;          // columns 2k, 2k+1
-        const pk_s2 d2 = (P[m + 2][k + 1] - P[m][k + 1]) >> 1;  // columns 2k+2, 2k+3
-        const pk_s2 d1 = __builtin_bit_cast(pk_s2, __builtin_amdgcn_alignbit(__builtin_bit_cast(uint32_t, d2),
-                                                                            __builtin_bit_cast(uint32_t, d0), 16));
-        dy[h][k] = (d1 + ((d0 + d2) >> 1)) >> 1;
-      }
-    }
-#pragma unroll
-    for (int k = 0; k < 3; k++) {
-      const pk_s2 xx = dx[0][k] * dx[0][k] + dx[1][k] * dx[1][k];     // 16-bit wrap per column
-      const pk_s2 yy = dy[0][k] * dy[0][k] + dy[1][k] * dy[1][k];
-      const pk_s2 xy = dx[0][k] * dy[0][k] + dx[1][k] * dy[1][k];
-      sxx = __builtin_amdgcn_udot2(__builtin_bit_cast(pk_u2, xx), __builtin_bit_cast(pk_u2, one), sxx, false);
-      syy = __builtin_amdgcn_udot2(__builtin_bit_cast(pk_u2, yy), __builtin_bit_cast(pk_u2, one), syy, false);
-      sxy = __builtin_amdgcn_sdot2(xy, one, sxy, false);
-    }
-  }
-  return harris_eval(sxx >> 4, syy >> 4, sxy >> 4, threshold);
-}
-
-// The same score with the gradients computed in the BYTE domain, as the reference's NEON code does
+//
+// Harris 6x6 for one corner with the gradients computed in the BYTE domain, as the reference's NEON code does
 // (vhsub.u8 / vhadd.s8 on 8-bit lanes, Harris.h:123-162), 4 pixels per instruction:
 //   floor((a - b) / 2) + 128 = v_lerp_u8(a, ~b, 1)      (a - b + 256) >> 1 — never leaves a byte)
 //   floor((e + f) / 2) + 128 = v_lerp_u8(E, F, 0)       for E = e + 128, F = f + 128
 // so a difference and both halving adds of the Sobel chains are single instructions on offset-binary
 // bytes, and the products are v_dot4_i32_i8 (see below why the reference's 16-bit product lanes never
-// wrap).  ~260 VALU instead of ~430 per 64 corners; identical result.
+// wrap).  ~250 VALU per 64 corners (a packed-i16 formulation of the same arithmetic took ~430);
+// result-identical to the scalar harris_score above.
 __device__ __forceinline__ uint8_t harris_score_mm(const lds_byte *row0, int pitch_bytes, int32_t threshold) {
   const uint32_t sh = (uint32_t)(uintptr_t)row0 & 3u;     // tile base and pitch are 16-byte aligned
   const lds_byte *base = row0 - sh;

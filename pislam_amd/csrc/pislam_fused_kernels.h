@@ -101,18 +101,10 @@ constexpr int PF_MAX = 3;              // 16-byte vectors a thread can hold for 
 __device__ __forceinline__ uint32_t pack_xy(int x, int r) { return (uint32_t)x | ((uint32_t)r << 16); }
 
 // Necessary condition for a 9-arc: an arc of 9 ring positions contains two ADJACENT compass
-// points (ring indices 1,5,9,13), so both must be dark (or both bright).
+// points (ring indices 1,5,9,13), so both must be dark (or both bright):
 //   exists adjacent pair both > hi  <=>  min(max(p1,p9), max(p5,p13)) > hi
 //   exists adjacent pair both < lo  <=>  max(min(p1,p9), min(p5,p13)) < lo
-__device__ __forceinline__ bool fast_pretest(const uint8_t *c, int pitch, int thr) {
-  const int v = c[0];
-  const int p1 = c[-3 * pitch], p9 = c[3 * pitch], p5 = c[3], p13 = c[-3];
-  const int mx = min(max(p1, p9), max(p5, p13));
-  const int mn = max(min(p1, p9), min(p5, p13));
-  return (mx > v + thr) | (mn < v - thr);
-}
-
-// The same test for 4 horizontally adjacent pixels held in one dword, evaluated on packed
+// The test for 4 horizontally adjacent pixels held in one dword, evaluated on packed
 // unsigned 16-bit pairs (v_pk_min/max/add/sub_u16): `ce/co` are the even/odd centre pixels
 // zero-extended to 16 bit, etc.  Returns a word whose bit 15 / bit 31 is set when the pixel in
 // the low / high half passes.
@@ -138,7 +130,7 @@ __device__ __attribute__((noinline)) void harris_overflow(lds_u8 *tile, lds_u8 *
                                                           bool valid, uint32_t e) {
   if (valid) {
     const int x = e & 0xffff, r = (e >> 16) & 0xff;
-    sc[r * pitch + x] = harris_score_pk(tile + r * tpitch + x - 3, tpitch, hthr);
+    sc[r * pitch + x] = harris_score_mm(tile + r * tpitch + x - 3, tpitch, hthr);
   }
 }
 
