@@ -71,6 +71,7 @@ struct FusedLevel {
   int tbytes;        // plain layout: bytes reserved for the image tile = max((R+10)*tpitch, the scan
                      // fallbacks' survivor / per-cell buffers — larger only with narrow x-tiles)
   uint32_t vpr_recip; // ceil(2^32 / (tpitch/16)): row = umulhi(i, vpr_recip) for i < 2^16
+  int st_dr, st_dv;  // staging step of a thread: NT / (tpitch/16) rows and NT % (tpitch/16) vectors
 };
 
 struct FusedParams {
@@ -378,7 +379,7 @@ __device__ __forceinline__ void strip_body(const StripArgs A, const FusedLevel L
         const int vpr = tpitch >> 4;
         int r = (int)__umulhi((uint32_t)tid, L.vpr_recip), v = tid - r * vpr;
         r += 10;
-        const int dr = NT / vpr, dv = NT - dr * vpr;
+        const int dr = L.st_dr, dv = L.st_dv;          // NT / vpr and NT % vpr, from the plan (no division here)
 #pragma unroll
         for (int k = 0; k < PF_MAX; k++) {
           if (r < nrows) *(lds_u4 *)(tile0 + r * tpitch + 16 * v) = pf[k];
@@ -395,12 +396,12 @@ __device__ __forceinline__ void strip_body(const StripArgs A, const FusedLevel L
         // division, and the end-of-buffer clipping is only compiled into the (wave-uniform) tail case
         int r = (int)__umulhi((uint32_t)tid, L.vpr_recip), v = tid - r * vpr;
         r += r_st0;
-        const int dr = NT / vpr, dv = NT - dr * vpr;
+        const int dr = L.st_dr, dv = L.st_dv;          // NT / vpr and NT % vpr, from the plan (no division here)
         const uint8_t *src0 = im + (ptrdiff_t)y_lo * A.vstep + xbase;
         const bool tail = (ptrdiff_t)(y_lo + nrows - 1) * A.vstep + xbase + tpitch > lim;
         if (!tail) {
           for (; r < nrows; r += dr) {
-            *(lds_u4 *)(tile0 + r * tpitch + 16 * v) = *(const u32x4 *)(src0 + (ptrdiff_t)r * A.vstep + 16 * v);
+            *(lds_u4 *)(tile0 + r * tpitch + 16 * v) = *(const u32x4 *)(src0 + (uint32_t)(r * A.vstep + 16 * v));   // (a pyramid is < 2 GiB)
             v += dv;
             if (v >= vpr) {
               v -= vpr;
@@ -453,10 +454,10 @@ __device__ __forceinline__ void strip_body(const StripArgs A, const FusedLevel L
         const uint8_t *src_n = im + (ptrdiff_t)ylo_n * A.vstep + xbase;
         int r = (int)__umulhi((uint32_t)tid, L.vpr_recip), v = tid - r * vpr;
         r += 10;
-        const int dr = NT / vpr, dv = NT - dr * vpr;
+        const int dr = L.st_dr, dv = L.st_dv;          // NT / vpr and NT % vpr, from the plan (no division here)
 #pragma unroll
         for (int k = 0; k < PF_MAX; k++) {
-          if (r < nrows_n) pf[k] = *(const u32x4 *)(src_n + (ptrdiff_t)r * A.vstep + 16 * v);
+          if (r < nrows_n) pf[k] = *(const u32x4 *)(src_n + (uint32_t)(r * A.vstep + 16 * v));
           v += dv;
           if (v >= vpr) {
             v -= vpr;

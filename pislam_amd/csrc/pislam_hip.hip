@@ -931,6 +931,8 @@ bool build_fused_plan(const pislam_ctx *c, const pislam_frontend_params *p, cons
       L.tpitch = (L.tcols + worst_lead + 8 + 15) & ~15;
     }
     L.vpr_recip = (uint32_t)(((1ull << 32) + (L.tpitch / 16) - 1) / (L.tpitch / 16));
+    L.st_dr = pf::NT / (L.tpitch / 16);
+    L.st_dv = pf::NT % (L.tpitch / 16);
     strips += L.nstrips;
     slots += L.nstrips * (R / 2) * L.nbx;
     // scan fallbacks reuse the image tile: row buffers of R/2 x nbx dwords, or per-cell results (<= one
@@ -969,6 +971,7 @@ bool build_fused_plan(const pislam_ctx *c, const pislam_frontend_params *p, cons
   F->slots_per_pyr = slots;
   *lds_bytes = lds;
   *lds_alias_bytes = lds_alias + (size_t)c->opt_lds_pad;   // profiling: opt_lds_pad lowers the residency artificially
+  if ((size_t)p->rows * p->vstep > 0x7fffffffu) return false;   // 32-bit byte offsets inside a pyramid
   return lds <= 150 * 1024;       // (strips == 0: no level holds a classifiable pixel — the caller writes zero counts)
 }
 
