@@ -299,12 +299,37 @@ __device__ __forceinline__ float vrecpe_f32(float f) {
   return __uint_as_float(sign | ((253 - e) << 23) | ((s - 256) << 15));
 }
 
+// The 8-bit estimate of FPRecipEstimate as a table: entry i (the top 8 mantissa bits) holds s - 256 with
+// s = (2^19 + q) / (2 q), q = 2 (256 + i) + 1  — the integer division of vrecpe_f32, done at compile time.
+struct VrecpeTab {
+  uint8_t v[256];
+};
+static constexpr VrecpeTab make_vrecpe_tab() {
+  VrecpeTab t{};
+  for (int i = 0; i < 256; i++) {
+    const uint32_t q2 = 2u * (256u + (uint32_t)i) + 1u;
+    t.v[i] = (uint8_t)((((1u << 19) + q2) / (2u * q2)) - 256u);
+  }
+  return t;
+}
+// vrecpe_f32 with the table in LDS and the special cases as selects (no division, no branches)
+template <class TAB>
+__device__ __forceinline__ float vrecpe_f32_tab(float f, const TAB *tab) {
+  const uint32_t u = __float_as_uint(f), sign = u & 0x80000000u, e = (u >> 23) & 0xff, m = u & 0x7fffffu;
+  uint32_t r = sign | ((253u - e) << 23) | ((uint32_t)tab[m >> 15] << 15);
+  r = e >= 253 ? sign : r;
+  r = e == 0 ? (sign | 0x7f800000u) : r;
+  r = e == 0xff ? (m ? 0x7fc00000u : sign) : r;
+  return __uint_as_float(r);
+}
+
 // (m10, m01) -> angle bin 0..29.  Float ops are individually rounded (the
 // library is built with -ffp-contract=off; ARMv7 NEON has no fused MAC here).
-__device__ __forceinline__ uint32_t angle_bin(int32_t x, int32_t y) {
+template <class RECIP>
+__device__ __forceinline__ uint32_t angle_bin_with(int32_t x, int32_t y, RECIP recip) {
   const float xf = fabsf((float)x), yf = fabsf((float)y);      // Orb.h:318-322
   const float zmax = fmaxf(xf, yf), zmin = fminf(xf, yf);      // Orb.h:324-325
-  const float z = __fmul_rn(zmin, vrecpe_f32(zmax));           // Orb.h:327-329
+  const float z = __fmul_rn(zmin, recip(zmax));                // Orb.h:327-329
   const float c0 = (float)(256 * 14.999998);                   // Orb.h:336
   const float c1 = (float)(256 * 4.723436);                    // Orb.h:343
   const float c2 = (float)(256 * 1.266240);                    // Orb.h:344
@@ -329,6 +354,9 @@ __device__ __forceinline__ uint32_t angle_bin(int32_t x, int32_t y) {
   angle >>= 10;                                                // Orb.h:376
   if (!(0 <= angle && angle < 30)) angle = 0;                  // Orb.h:377-380
   return (uint32_t)angle;
+}
+__device__ __forceinline__ uint32_t angle_bin(int32_t x, int32_t y) {
+  return angle_bin_with(x, y, [](float f) { return vrecpe_f32(f); });
 }
 
 // ---------------------------------------------------------------------------

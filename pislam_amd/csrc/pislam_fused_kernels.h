@@ -1053,6 +1053,9 @@ __global__ __launch_bounds__(256) void k_gather_orb(
   extern __shared__ __attribute__((aligned(16))) uint8_t osm[];
   __shared__ uint32_t wsum[4];
   __shared__ uint32_t carry;
+  __shared__ uint8_t sh_rtab[256];                  // vrecpe estimate table (256 threads: one entry each)
+  sh_rtab[threadIdx.x] = ::g_vrecpe_tab.v[threadIdx.x];
+  const lds_u8 *rtab = (const lds_u8 *)sh_rtab;
   // the overflow list of this step has been consumed (stream order): empty it for the next step
   if (ovf_reset && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
     ovf_reset[1] = ovf_reset[0];                     // kept for pislam_frontend_last_stats
@@ -1237,7 +1240,8 @@ __global__ __launch_bounds__(256) void k_gather_orb(
     right = __builtin_amdgcn_udot4(row[7] & cmask[7], 0x000f0e0du, right, false);  // dx  13..15 (16 masked)
     const int m10 = half_sum((int)right - (int)left, half);
     const int m01 = half_sum(dy * (int)sv, half);
-    const uint32_t rot = (P.ablate & 16384) ? 0u : angle_bin(m10, m01);   // (profiling only)
+    const uint32_t rot = (P.ablate & 16384) ? 0u                          // (profiling only)
+                                             : angle_bin_with(m10, m01, [&](float f) { return vrecpe_f32_tab(f, rtab); });
     if (P.ablate & 32768) {                          // profiling only: no BRIEF
       if (valid && r < words) dsc[(size_t)idx * words + r] = rot + sv;
       return;

@@ -37,6 +37,8 @@ static constexpr BriefOfsTab make_brief_ofs() {
 }
 __device__ const BriefOfsTab g_brief_ofs = make_brief_ofs();
 
+#include "pislam_dev.h"
+__device__ const pdev::VrecpeTab g_vrecpe_tab = pdev::make_vrecpe_tab();   // used by pf::k_gather_orb
 #include "pislam_stage_kernels.h"
 #include "pislam_fused_kernels.h"
 #include "pislam_prep_kernels.h"
