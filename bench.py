@@ -26,17 +26,18 @@ import torch
 HBM_PEAK_GBPS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
-def cpu_baseline(pyr_host, levels, budget_s=10.0):
+def cpu_baseline(pyr_host, levels, budget_s=10.0, mt_s=3.0):
     """The oracle (bit-exact plain-C restatement of the reference path, oracle/pislam_oracle.c) timed
     on ONE host thread — the reference itself is single-threaded — on a bounded sample of the same
-    workload."""
+    workload; then the same port on EVERY visible host thread (pthreads inside liborc, one pyramid per
+    thread at a time, timed in C) for >= mt_s seconds.  levels: (w, h, row0[, col0])."""
     from oracle import orc
     orc.lib()
     CPU_CAP = 16384                                       # output capacity per pyramid (keeps allocation out of the timing)
-    orc.pyramid(pyr_host[0], levels, cap=CPU_CAP)         # warm caches / lazy table
+    orc.pyramid4(pyr_host[0], levels, cap=CPU_CAP)        # warm caches / lazy table
     n_kp, n_pyr, t0 = 0, 0, time.perf_counter()
     for b in range(64 * len(pyr_host)):                   # ~budget_s of work: the batch, repeated if need be
-        kp, _, _ = orc.pyramid(pyr_host[b % len(pyr_host)], levels, cap=CPU_CAP)
+        kp, _, _ = orc.pyramid4(pyr_host[b % len(pyr_host)], levels, cap=CPU_CAP)
         n_kp += len(kp)
         n_pyr += 1
         if time.perf_counter() - t0 > budget_s:
@@ -45,19 +46,12 @@ def cpu_baseline(pyr_host, levels, budget_s=10.0):
     out = {"value": n_kp / dt, "unit": "kp+desc/s", "cores": 1, "kind": "port",
            "sample": f"{n_pyr} pyramids of the batch ({n_kp} keypoints) in {dt:.2f} s, 1 thread, "
                      f"oracle/pislam_oracle.c -O3 on {os.cpu_count()} visible host cores"}
-    # the same port on every host thread, one pyramid per thread (ctypes releases the
-    # GIL); reported beside the single-thread figure, which stays `value` (the reference is single-threaded)
+    # reported beside the single-thread figure, which stays `value`
     try:
-        from concurrent.futures import ThreadPoolExecutor
-        nthr = max(1, min(os.cpu_count() or 1, 64))
-        reps = max(1, int(nthr * 4 / max(1, len(pyr_host))) + 1)
-        work = [pyr_host[i % len(pyr_host)] for i in range(len(pyr_host) * reps)]
-        t1 = time.perf_counter()
-        with ThreadPoolExecutor(nthr) as ex:
-            tot = sum(ex.map(lambda im: len(orc.pyramid(im, levels, cap=CPU_CAP)[0]), work))
-        dt2 = time.perf_counter() - t1
+        nthr = max(1, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
+        tot, done, dt2 = orc.pyramid_mt(np.ascontiguousarray(pyr_host), levels, nthr, mt_s, cap=CPU_CAP)
         out["all_threads"] = {"value": tot / dt2, "cores": nthr,
-                              "sample": f"{len(work)} pyramids ({tot} keypoints) in {dt2:.2f} s"}
+                              "sample": f"{done} pyramids ({tot} keypoints) in {dt2:.2f} s, {nthr} pthreads (orc_pyramid_mt)"}
     except Exception as e:                                   # never let the extra leg break the bench line
         out["all_threads"] = {"error": repr(e)}
     return out
@@ -73,7 +67,12 @@ def main():
     ap.add_argument("--batch", type=int, default=256, help="pyramids per GPU")
     ap.add_argument("--distinct", type=int, default=0,
                     help="distinct synthetic pyramids generated per GPU (0 = all of the batch)")
-    ap.add_argument("--max-keypoints", type=int, default=4096)
+    ap.add_argument("--max-keypoints", type=int, default=0,
+                    help="keypoint / descriptor capacity per pyramid (0 = 4096 for vga, 8192 for the larger workloads)")
+    ap.add_argument("--selftest-spawn", action="store_true",
+                    help="testing only: exercise launch + rendezvous + count exchange with fake counts on the CPU "
+                         "(no GPU work, value is null)")
+    ap.add_argument("--cpu-seconds", type=float, default=10.0, help="budget of the 1-thread cpu_baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dist-backend", default=None,
                     help="override the torch.distributed backend (default nccl = RCCL); 'gloo' lets the N>1 code "
@@ -99,16 +98,51 @@ def main():
     ap.add_argument("--bucket-limit", type=int, default=5, help="fastExtract bucketLimit (README uses 3)")
     ap.add_argument("--ablate", type=int, default=0, help="profiling only (results invalid): fused-kernel phase mask")
     args = ap.parse_args()
+    if not args.max_keypoints:
+        args.max_keypoints = 4096 if args.workload == "vga" else 8192
 
-    from pislam_amd import dist as pdist, synth
+    from pislam_amd import dist as pdist
+
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # Plain `python bench.py --gpus N`: start the N ranks ourselves (one process per GPU under
+        # torch.distributed.run on 127.0.0.1); rank 0 prints the JSON line.
+        shared_ok = args.dist_backend == "gloo" or args.selftest_spawn     # test modes: ranks may share a GPU / need none
+        if not shared_ok and torch.cuda.device_count() < args.gpus:
+            raise SystemExit(f"bench.py --gpus {args.gpus}: only {torch.cuda.device_count()} GPU(s) visible "
+                             "(one process per GPU; there is no CPU fallback)")
+        raise SystemExit(pdist.self_launch([os.path.abspath(__file__)] + sys.argv[1:], args.gpus))
+
+    rank, local_rank, world = pdist.init(backend="gloo" if args.selftest_spawn else args.dist_backend)
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus} "
+                         "(or run `python bench.py --gpus N` without a torchrun environment)")
+    if args.selftest_spawn:
+        # launch / rendezvous / exchange plumbing only (CPU, gloo): every rank contributes fake counts
+        B = 4
+        fake = torch.arange(B, dtype=torch.int32) + 100 * rank
+        xchg = pdist.CountExchange(world)
+        xchg.before_step()
+        xchg.start(fake)
+        allc = xchg.finish()
+        ok = allc.tolist() == [100 * r + i for r in range(world) for i in range(B)]
+        if world > 1:
+            torch.distributed.barrier()
+        if rank == 0:
+            print(json.dumps({"metric": "ORB keypoints+descriptors/sec, 640x480 8-level pyramid", "value": None,
+                              "unit": "kp+desc/s", "n_gpus": world, "selftest": "spawn", "exchange_ok": ok,
+                              "count_allgather": xchg.path}))
+        if world > 1:
+            torch.distributed.destroy_process_group()
+        return
+
+    from pislam_amd import synth
     from pislam_amd.frontend import OrbFrontend
     from pislam_amd.capi import Context
 
-    rank, local_rank, world = pdist.init(backend=args.dist_backend)
     if args.dist_backend == "gloo":
         local_rank = local_rank % max(1, torch.cuda.device_count())   # ranks may share a GPU in this test mode
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU fallback)"
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
@@ -180,7 +214,18 @@ def main():
     # Two output sets, alternating per step: the consumer of step i's outputs — here the all-gather of its
     # counts (pislam_amd.dist.CountExchange, on RCCL's own stream) — overlaps step i+1's kernels.
     outs = [(kp, desc, counts)] + ([fe.alloc_outputs(B, dev)] if world > 1 else [])
-    xchg = pdist.CountExchange(world)
+    # The count all-gather goes through the C ABI (pislam_dist_*: RCCL communicator from a unique id,
+    # ncclAllGather on the context's collective stream).  Ranks sharing one GPU (gloo test mode) cannot form
+    # an RCCL communicator; if the C-ABI path fails on any rank, all ranks fall back to torch.distributed's
+    # all-gather and the JSON line says so.
+    rccl_err = None
+    if world > 1 and args.dist_backend == "gloo":
+        rccl_err = "test mode: ranks share a GPU"
+    elif world > 1:
+        rccl_err = pdist.init_rccl(ctx, rank, world, dev)
+        if rccl_err and rank == 0:
+            print(f"[bench] C-ABI RCCL path unavailable, using torch.distributed: {rccl_err}", file=sys.stderr)
+    xchg = pdist.CountExchange(world, ctx=ctx if (world > 1 and rccl_err is None) else None)
     nstep = [0]
 
     def launches(k_, d_, c_):
@@ -222,6 +267,7 @@ def main():
     def step():
         i = nstep[0] % len(outs)
         nstep[0] += 1
+        xchg.before_step()                              # the launch stream waits for the all-gather of step i-2
         if graphs is not None:
             graphs[i].replay()
         else:
@@ -258,7 +304,7 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=dev if torch.distributed.get_backend() == "nccl" else None)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
 
@@ -303,8 +349,11 @@ def main():
                                                                           < cq[:, None])).sum().item())}
 
     deferred, nstrips = fe.last_stats()
-    total_kp_step = int(allc.to(torch.int64).sum().item())          # all ranks, one step
-    local_kp = int(counts.to(torch.int64).sum().item())
+    # counts are the reference's un-clamped totals; keypoints beyond the capacity are neither stored nor
+    # described, so only min(count, max_keypoints) per pyramid is credited
+    capped = int((allc.to(torch.int64) > args.max_keypoints).sum().item())
+    total_kp_step = int(torch.clamp(allc.to(torch.int64), max=args.max_keypoints).sum().item())   # all ranks, one step
+    local_kp = int(torch.clamp(counts.to(torch.int64), max=args.max_keypoints).sum().item())
     value = total_kp_step * args.steps / dt
 
     if rank == 0:
@@ -318,13 +367,27 @@ def main():
         # pipeline there is no single dominant launch, so the whole step is priced instead
         launch_ms = (strip_ms if strip_ms else ev_stage_ms[0]) if fused else ev_total_ms
         achieved = b_alg_launch / (launch_ms * 1e-3) / 1e9
-        traffic = None                                  # HBM bytes per launch from the committed PMC passes
-        tpath = os.path.join(ROOT, "profiles", "r01f_hbm_traffic.json")
+        # HBM bytes per launch come from separate rocprofv3 --pmc passes (tools/pmc_hbm.sh), which cannot run
+        # inside this process: the number is read from the committed profile and reported ONLY when that
+        # profile was taken on exactly these kernel sources and this workload; `traffic_source` says where it
+        # is from (or why it is null).
+        from pislam_amd import build as pbuild
+        traffic, traffic_step, traffic_source = None, None, None
+        tpath = os.path.join(ROOT, "profiles", "r02_hbm_traffic.json")
         if fused and B == 256 and args.workload == "vga" and not args.log_bucket_size and os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath))["kernels"]["k_fused_strips"]["hbm_bytes_per_launch"]
-            except Exception:
-                traffic = None
+                tj = json.load(open(tpath))
+                if tj.get("source_hash") == pbuild.source_hash():
+                    traffic = tj["kernels"]["k_fused_strips"]["hbm_bytes_per_launch"]
+                    traffic_step = sum(k["hbm_bytes_per_launch"] for k in tj["kernels"].values() if "hbm_bytes_per_launch" in k)
+                    traffic_source = f"profiles/r02_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes on kernel sources {tj['source_hash']}; not measured in this run)"
+                else:
+                    traffic_source = (f"null: profiles/r02_hbm_traffic.json was measured on kernel sources {tj.get('source_hash')}, "
+                                      f"this run uses {pbuild.source_hash()}")
+            except Exception as e:                          # noqa: BLE001
+                traffic_source = f"null: {e!r}"
+        else:
+            traffic_source = "null: no PMC profile for this workload / configuration"
         out = {
             "metric": "ORB keypoints+descriptors/sec, 640x480 8-level pyramid",
             "value": value, "unit": "kp+desc/s", "n_gpus": world, "steps": args.steps,
@@ -347,11 +410,14 @@ def main():
                 "pipeline": "fused" if fused else "staged",
                 "launch": "hipGraph replay" if graphs is not None else "eager",
                 "strips_redone_by_overflow_pass": f"{deferred} of {nstrips}",
+                "max_keypoints": args.max_keypoints, "pyramids_over_capacity": capped,
+                "count_allgather": xchg.path,
                 **({"match_inside_step": match_info} if match_info else {}),
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_source,
+                "traffic_whole_step": traffic_step,
                 "kernel": "pf::k_fused_strips (hipEvents on the launch stream around 16 back-to-back launches, / 16)" if fused
                           else "whole staged step (all launches)",
                 "algorithmic_bytes_per_launch": b_alg_launch, "launch_ms": launch_ms,
@@ -360,10 +426,8 @@ def main():
                              "gather+orb" if fused else "orb": ev_stage_ms[2]},
             },
         }
-        if world == 1 and not args.no_cpu_baseline and all(len(t) < 4 or t[3] == 0 for t in levels):
-            # (the oracle's whole-pyramid driver takes vertically stacked levels; the packed 1280x960
-            #  layout is covered by the parity tests, not by the timed CPU leg)
-            out["cpu_baseline"] = cpu_baseline(host, [tuple(t[:3]) for t in levels])
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(host, levels, budget_s=args.cpu_seconds)
         print(json.dumps(out))
     if world > 1:
         torch.distributed.barrier()

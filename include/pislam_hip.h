@@ -36,6 +36,7 @@ extern "C" {
 #define PISLAM_ERR_INVALID (-1) /* bad argument / violated precondition */
 #define PISLAM_ERR_HIP (-2)     /* HIP runtime error (no device, launch failure, ...) */
 #define PISLAM_ERR_NOMEM (-3)   /* device allocation failed */
+#define PISLAM_ERR_DIST (-4)    /* RCCL unavailable or a collective failed */
 
 #define PISLAM_ABI_VERSION 1
 
@@ -54,7 +55,8 @@ int pislam_ctx_set_stream(pislam_ctx *ctx, void *hip_stream);
  *   "strip_rows" fused strip height (0 = heuristic);  "run_len" strips per workgroup run (0 = by batch)
  *   "alias"      1 (default) score tile laid over the dead image rows + overflow pass, 0 separate tiles
  *   "xtile_cols" image x-tiles inside a strip (0 = full width);  "orb_chunks" gather+ORB workgroups per pyramid
- *   "wgs_per_cu", "lds_pad", "repeat_strips", "ablate"  profiling only (ablate != 0 gives INVALID results by design) */
+ *   "wgs_per_cu", "lds_pad", "repeat_strips", "ablate"  profiling only (ablate != 0 gives INVALID results by design)
+ *   "dist_rccl_single" test hook: pislam_dist_init(world = 1) still creates a 1-rank RCCL communicator */
 int pislam_ctx_set_option(pislam_ctx *ctx, const char *key, int value);
 int pislam_ctx_synchronize(pislam_ctx *ctx);
 const char *pislam_last_error(const pislam_ctx *ctx);
@@ -256,6 +258,66 @@ int pislam_match_hamming_batch(pislam_ctx *ctx, int words, const uint32_t *query
                                const uint32_t *qcounts, size_t q_stride, const uint32_t *train,
                                const uint32_t *tcounts, size_t t_stride, int batch, int32_t *idx,
                                uint32_t *dist, uint32_t *dist2);
+
+/* ---- multi-GPU: one process per GPU, pyramids sharded, ONE collective ---- */
+
+/* The reference is a single-threaded per-frame loop without cross-frame state
+ * (demo/demo.cpp:77-101, README.md:59-82), so a batch of pyramids shards across
+ * GPUs with no data-path exchange: rank r of `world` runs
+ * pislam_orb_frontend_batch on its own contiguous range of pyramids.  The only
+ * exchange is the all-gather of the per-pyramid keypoint counts (what a consumer
+ * needs to place every rank's keypoints in one global list) — ncclAllGather over
+ * RCCL/xGMI, 4 bytes per pyramid.  RCCL is bound at run time (librccl.so.1;
+ * override with the environment variable PISLAM_RCCL_LIB); world == 1 never
+ * touches it.
+ *
+ *   rank 0:   pislam_dist_get_unique_id(id);  -> hand `id` to every rank (file, socket, MPI, env ...)
+ *   all:      pislam_ctx_create(local_device, &ctx);  pislam_dist_init(ctx, id, rank, world);
+ *   per step: pislam_orb_frontend_batch(ctx, ..., counts_local);
+ *             pislam_dist_allgather_counts(ctx, counts_local, n_local, counts_all);
+ *   end:      pislam_dist_synchronize(ctx);  pislam_dist_finalize(ctx);
+ */
+#define PISLAM_DIST_ID_BYTES 128
+
+/* Contiguous split of `global_batch` pyramids: the first (global_batch % world)
+ * ranks take one more.  Pure arithmetic; no context, no GPU. */
+int pislam_dist_shard(int global_batch, int rank, int world, int *first, int *count);
+
+/* ncclGetUniqueId: call on ONE rank, distribute the bytes to all of them. */
+int pislam_dist_get_unique_id(uint8_t id[PISLAM_DIST_ID_BYTES]);
+
+/* ncclCommInitRank on the context's device (collective: every rank must call
+ * it with the same id and world).  Creates the context's collective stream.
+ * world == 1: no communicator, `id` may be NULL. */
+int pislam_dist_init(pislam_ctx *ctx, const uint8_t id[PISLAM_DIST_ID_BYTES], int rank, int world);
+int pislam_dist_rank(const pislam_ctx *ctx);
+int pislam_dist_world(const pislam_ctx *ctx);
+
+/* all_counts[r*n + i] = rank r's local_counts[i] (DEVICE pointers, n equal on
+ * every rank — pad ragged shards to the largest).  Enqueued on the context's
+ * COLLECTIVE stream, ordered after everything enqueued on the context stream so
+ * far; asynchronous to the host and to the context stream, so the next batch
+ * call overlaps it.  local_counts / all_counts must stay untouched until the
+ * collective has completed (pislam_dist_fence / pislam_dist_synchronize). */
+int pislam_dist_allgather_counts(pislam_ctx *ctx, const uint32_t *local_counts, size_t n,
+                                 uint32_t *all_counts);
+
+/* Makes the context stream wait (on the device, not the host) for the
+ * collective issued `back` calls ago (1 = the most recent, up to 4): call it
+ * before work that overwrites that collective's buffers.  With two alternating
+ * output sets, pislam_dist_fence(ctx, 2) before each batch call is enough. */
+int pislam_dist_fence(pislam_ctx *ctx, int back);
+
+/* Blocks the host until every collective issued on this context has completed. */
+int pislam_dist_synchronize(pislam_ctx *ctx);
+
+/* MAX of one host double over all ranks (ncclAllReduce; blocking; also a
+ * barrier) — the "slowest rank" reduction of a timed region. */
+int pislam_dist_allreduce_max(pislam_ctx *ctx, double *value);
+
+/* Destroys the communicator and the collective stream (pislam_ctx_destroy does
+ * this too). */
+int pislam_dist_finalize(pislam_ctx *ctx);
 
 #ifdef __cplusplus
 }

@@ -66,6 +66,14 @@ def lib():
             getattr(L, name).restype = None
         L.orc_fill_spiral.argtypes = [_i, _i, _i, _i, _i, c_u8p]
         L.orc_fill_spiral.restype = None
+        L.orc_fill_random.argtypes = [_i, _i, _i, c_u8p]
+        L.orc_fill_random.restype = None
+        L.orc_pyramid4.argtypes = L.orc_pyramid.argtypes
+        L.orc_pyramid4.restype = _sz
+        L.orc_pyramid_mt.argtypes = [_i, ctypes.c_double, _i, _i, _i, _i, ctypes.c_int32, _i, _i, _i, c_u8p, _sz, _i,
+                                     ctypes.c_void_p, _i, _sz, ctypes.POINTER(ctypes.c_ulonglong),
+                                     ctypes.POINTER(ctypes.c_double)]
+        L.orc_pyramid_mt.restype = ctypes.c_ulonglong
         L.orc_match_hamming.argtypes = [_i, ctypes.c_void_p, _sz, ctypes.c_void_p, _sz, ctypes.c_void_p,
                                         ctypes.c_void_p, ctypes.c_void_p]
         L.orc_match_hamming.restype = None
@@ -184,6 +192,51 @@ def fill_spiral(vstep, width, height, cx, cy, rows=None):
     buf = np.zeros((rows or height, vstep), np.uint8)
     lib().orc_fill_spiral(vstep, width, height, cx, cy, buf.ctypes.data)
     return buf
+
+
+def fill_random(vstep, width, height, rows=None):
+    """test/TestUtil.cpp:57-65 fill_random (default-seeded std::mt19937_64, one draw per pixel) into a fresh
+    zeroed [rows][vstep] buffer."""
+    buf = np.zeros((rows or height, vstep), np.uint8)
+    lib().orc_fill_random(vstep, width, height, buf.ctypes.data)
+    return buf
+
+
+def levels4(levels):
+    """(w, h, row0[, col0]) tuples -> contiguous int32 [n][4]."""
+    return np.ascontiguousarray(np.array([(t[0], t[1], t[2], t[3] if len(t) > 3 else 0) for t in levels], np.int32))
+
+
+def pyramid4(img, levels, fast_threshold=20, harris_threshold=1 << 15, border=16, log_bucket=0, bucket_limit=5,
+             words=8, cap=None):
+    """`pyramid` for levels placed anywhere in the buffer: (w, h, row0, col0) per level (packed layouts)."""
+    assert img.dtype == np.uint8 and img.flags.c_contiguous
+    lv = levels4(levels)
+    if cap is None:
+        cap = int(sum(((w + 1) // 2) * ((h + 1) // 2) for w, h, _, _ in lv.tolist()))
+    score = np.zeros_like(img)
+    kp = np.zeros(cap, np.uint32)
+    desc = np.zeros((cap, words), np.uint32)
+    lc = np.zeros(len(lv), np.uint32)
+    n = lib().orc_pyramid4(img.shape[1], border, fast_threshold, harris_threshold, log_bucket, bucket_limit, words,
+                           img.ctypes.data, score.ctypes.data, lv.ctypes.data, len(lv), kp.ctypes.data,
+                           desc.ctypes.data, cap, lc.ctypes.data)
+    m = min(n, cap)
+    return kp[:m].copy(), desc[:m].copy(), lc
+
+
+def pyramid_mt(imgs, levels, nthreads, min_seconds, fast_threshold=20, harris_threshold=1 << 15, border=16,
+               log_bucket=0, bucket_limit=5, words=8, cap=16384):
+    """The whole path on `nthreads` pthreads for >= min_seconds (timed in C): imgs uint8 [n][rows][vstep].
+    Returns (keypoints, pyramids, seconds)."""
+    assert imgs.dtype == np.uint8 and imgs.flags.c_contiguous and imgs.ndim == 3
+    lv = levels4(levels)
+    done, secs = ctypes.c_ulonglong(0), ctypes.c_double(0)
+    kps = lib().orc_pyramid_mt(nthreads, float(min_seconds), imgs.shape[2], imgs.shape[1], border, fast_threshold,
+                               harris_threshold, log_bucket, bucket_limit, words, imgs.ctypes.data,
+                               imgs.shape[1] * imgs.shape[2], imgs.shape[0], lv.ctypes.data, len(lv), cap,
+                               ctypes.byref(done), ctypes.byref(secs))
+    return int(kps), int(done.value), float(secs.value)
 
 
 def match_hamming(query, train):

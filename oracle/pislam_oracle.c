@@ -502,6 +502,106 @@ ORC_API size_t orc_pyramid(int vstep, int border, int fast_threshold, int32_t ha
   return n;
 }
 
+/* The same call sequence for levels placed anywhere in the buffer (packed layouts: levels side by side,
+ * BASELINE config 4): levels4 = (width, height, row0, col0) per level; README.md:78 adds the level's
+ * origin to the keypoint coordinates (x += col0, y += row0). */
+ORC_API size_t orc_pyramid4(int vstep, int border, int fast_threshold, int32_t harris_threshold,
+                            int logBucketSize, int bucketLimit, int words,
+                            const uint8_t *img, uint8_t *score,
+                            const int32_t *levels4, int nlevels,
+                            uint32_t *kp, uint32_t *desc, size_t cap, uint32_t *level_counts) {
+  size_t n = 0;
+  for (int l = 0; l < nlevels; l++) {
+    int w = levels4[4 * l], h = levels4[4 * l + 1], row0 = levels4[4 * l + 2], col0 = levels4[4 * l + 3];
+    const uint8_t *li = img + (ptrdiff_t)row0 * vstep + col0;
+    uint8_t *lo = score + (ptrdiff_t)row0 * vstep + col0;
+    orc_fast_detect(vstep, border, w, h, li, lo, fast_threshold);
+    orc_fast_score_harris(vstep, border, w, h, li, harris_threshold, lo);
+    size_t room = n < cap ? cap - n : 0;
+    size_t got = orc_fast_extract(vstep, border, logBucketSize, bucketLimit, w, h, lo,
+                                  kp + (n < cap ? n : cap), room);
+    size_t stored = got < room ? got : room;
+    for (size_t i = 0; i < stored; i++) kp[n + i] += ((uint32_t)col0 << 12) | (uint32_t)row0;
+    if (level_counts) level_counts[l] = (uint32_t)got;
+    n += got;
+  }
+  size_t stored = n < cap ? n : cap;
+  orc_orb_compute(vstep, words, img, kp, stored, desc);
+  return n;
+}
+
+/* cpu_baseline leg of bench.py: the same path on `nthreads` host threads, one pyramid
+ * per thread at a time, for at least `min_seconds` (every thread keeps taking pyramids, round robin over
+ * the `npyr` inputs, until the time is up).  Returns the keypoints produced; *pyramids_done and
+ * *seconds report the sample.  Each thread owns its score map and output buffers. */
+#include <pthread.h>
+#include <time.h>
+typedef struct {
+  int vstep, border, fast_threshold, logBucketSize, bucketLimit, words, nlevels, npyr, tid, nthreads;
+  int32_t harris_threshold;
+  const uint8_t *imgs;
+  size_t img_stride, rows, cap;
+  const int32_t *levels4;
+  double deadline, t_end;
+  unsigned long long kps, pyrs;
+} orc_mt_job;
+static double orc_now(void) {
+  struct timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+static void *orc_mt_worker(void *arg) {
+  orc_mt_job *j = (orc_mt_job *)arg;
+  uint8_t *score = (uint8_t *)calloc(j->rows * (size_t)j->vstep, 1);
+  uint32_t *kp = (uint32_t *)malloc(sizeof(uint32_t) * j->cap);
+  uint32_t *desc = (uint32_t *)malloc(sizeof(uint32_t) * j->cap * (size_t)j->words);
+  int i = j->tid % j->npyr;
+  do {
+    memset(score, 0, j->rows * (size_t)j->vstep);          /* Fast.h:42-44: `out` starts as zeros */
+    j->kps += orc_pyramid4(j->vstep, j->border, j->fast_threshold, j->harris_threshold, j->logBucketSize,
+                           j->bucketLimit, j->words, j->imgs + (size_t)i * j->img_stride, score, j->levels4,
+                           j->nlevels, kp, desc, j->cap, NULL);
+    j->pyrs++;
+    i = (i + j->nthreads) % j->npyr;
+  } while (orc_now() < j->deadline);
+  j->t_end = orc_now();
+  free(score);
+  free(kp);
+  free(desc);
+  return NULL;
+}
+ORC_API unsigned long long orc_pyramid_mt(int nthreads, double min_seconds, int vstep, int rows, int border,
+                                          int fast_threshold, int32_t harris_threshold, int logBucketSize,
+                                          int bucketLimit, int words, const uint8_t *imgs, size_t img_stride,
+                                          int npyr, const int32_t *levels4, int nlevels, size_t cap,
+                                          unsigned long long *pyramids_done, double *seconds) {
+  if (nthreads < 1) nthreads = 1;
+  orc_mt_job *jobs = (orc_mt_job *)calloc((size_t)nthreads, sizeof(orc_mt_job));
+  pthread_t *th = (pthread_t *)calloc((size_t)nthreads, sizeof(pthread_t));
+  const double t0 = orc_now();
+  for (int t = 0; t < nthreads; t++) {
+    orc_mt_job *j = &jobs[t];
+    j->vstep = vstep; j->border = border; j->fast_threshold = fast_threshold; j->logBucketSize = logBucketSize;
+    j->bucketLimit = bucketLimit; j->words = words; j->nlevels = nlevels; j->npyr = npyr; j->tid = t;
+    j->nthreads = nthreads; j->harris_threshold = harris_threshold; j->imgs = imgs; j->img_stride = img_stride;
+    j->rows = (size_t)rows; j->cap = cap; j->levels4 = levels4; j->deadline = t0 + min_seconds;
+    if (pthread_create(&th[t], NULL, orc_mt_worker, j) != 0) { nthreads = t; break; }
+  }
+  unsigned long long kps = 0, pyrs = 0;
+  double t_end = t0;
+  for (int t = 0; t < nthreads; t++) {
+    pthread_join(th[t], NULL);
+    kps += jobs[t].kps;
+    pyrs += jobs[t].pyrs;
+    if (jobs[t].t_end > t_end) t_end = jobs[t].t_end;
+  }
+  if (pyramids_done) *pyramids_done = pyrs;
+  if (seconds) *seconds = t_end - t0;
+  free(jobs);
+  free(th);
+  return kps;
+}
+
 /* ========================================================================= */
 /* "Next" tier: image preparation.  The reference's NEON/asm  */
 /* (Gaussian.h, Bilinear.h) cannot be built here; its OWN tests state the       */
@@ -600,6 +700,37 @@ ORC_API void orc_fill_spiral(int vstep, int width, int height, int cx, int cy, u
     j = (int)(-x + cx);
     if (0 <= i && i < vstep && 0 <= j && j < vstep && i < height) buffer[i * vstep + j] = 0xff;
   }
+}
+
+/* test/TestUtil.cpp:57-65 fill_random — the other fixture of BilinearTest (random7_8 / random13_16,
+ * BilinearTest.cpp:85-95,139-149) and GaussianTest: a default-constructed std::mt19937_64 (seed 5489,
+ * the C++11 standard's mersenne_twister_engine<uint64, 64,312,156,31, 0xb5026f5aa96619e9, 29,
+ * 0x5555555555555555, 17, 0x71d67fffeda60000, 37, 0xfff7eee000000000, 43, 6364136223846793005>),
+ * one draw per pixel in raster order, truncated to a byte.  PINNED against the reference's own
+ * TestUtil.cpp compiled into oracle/_ref/libtestutil_ref.so (tests/test_oracle.py). */
+ORC_API void orc_fill_random(int vstep, int width, int height, uint8_t *buffer) {
+  enum { NN = 312, MM = 156 };
+  static const uint64_t UM = 0xFFFFFFFF80000000ull, LM = 0x7FFFFFFFull, MATRIX_A = 0xB5026F5AA96619E9ull;
+  uint64_t mt[NN];
+  mt[0] = 5489ull;
+  for (int i = 1; i < NN; i++) mt[i] = 6364136223846793005ull * (mt[i - 1] ^ (mt[i - 1] >> 62)) + (uint64_t)i;
+  int mti = NN;
+  for (int i = 0; i < height; i++)
+    for (int j = 0; j < width; j++) {
+      if (mti >= NN) {
+        for (int k = 0; k < NN; k++) {
+          const uint64_t x = (mt[k] & UM) | (mt[(k + 1) % NN] & LM);
+          mt[k] = mt[(k + MM) % NN] ^ (x >> 1) ^ ((x & 1ull) ? MATRIX_A : 0ull);
+        }
+        mti = 0;
+      }
+      uint64_t x = mt[mti++];
+      x ^= (x >> 29) & 0x5555555555555555ull;
+      x ^= (x << 17) & 0x71D67FFFEDA60000ull;
+      x ^= (x << 37) & 0xFFF7EEE000000000ull;
+      x ^= (x >> 43);
+      buffer[(ptrdiff_t)i * vstep + j] = (uint8_t)x;
+    }
 }
 
 /* Brute-force Hamming matcher.  NOT a restatement of reference code: the

@@ -9,3 +9,7 @@
 extern "C" void ref_fill_spiral(int vstep, int width, int height, int cx, int cy, uint8_t *buffer) {
   test_util::fill_spiral(vstep, width, height, cx, cy, buffer);   // TestUtil.cpp:27
 }
+
+extern "C" void ref_fill_random(int vstep, int width, int height, uint8_t *buffer) {
+  test_util::fill_random(vstep, width, height, buffer);           // TestUtil.cpp:57
+}

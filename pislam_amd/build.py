@@ -10,9 +10,30 @@ CSRC = os.path.join(PKG, "csrc")
 LIBDIR = os.path.join(PKG, "lib")
 LIB = os.path.join(LIBDIR, "libpislam_hip.so")
 SOURCES = ["pislam_hip.hip"]
-HEADERS = ["pislam_dev.h", "pislam_stage_kernels.h", "pislam_fused_kernels.h", "pislam_prep_kernels.h", "brief_table.inc"]
+
+
+def _deps():
+    """Every header / table the sources include: all of csrc/*.h and *.inc, plus the public ABI header."""
+    import glob
+    d = [os.path.join(CSRC, f) for f in SOURCES]
+    d += sorted(glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(CSRC, "*.inc")))
+    d.append(os.path.join(os.path.dirname(PKG), "include", "pislam_hip.h"))
+    return d
+
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
          "-fvisibility=hidden"]
+
+
+def source_hash() -> str:
+    """SHA-256 (16 hex digits) over the kernel sources: profile files record it, so that a number measured
+    on older kernels is recognised as stale (bench.py `roofline.traffic`)."""
+    import hashlib
+    h = hashlib.sha256()
+    for d in _deps():
+        if os.path.exists(d) and not d.endswith("pislam_hip.h"):
+            h.update(os.path.basename(d).encode())
+            h.update(open(d, "rb").read())
+    return h.hexdigest()[:16]
 
 
 def hipcc() -> str:
@@ -26,9 +47,7 @@ def _stale() -> bool:
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS]
-    deps.append(os.path.join(os.path.dirname(PKG), "include", "pislam_hip.h"))
-    return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
+    return any(os.path.exists(d) and os.path.getmtime(d) > t for d in _deps())
 
 
 def build(force: bool = False, verbose: bool = False) -> str:

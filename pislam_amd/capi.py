@@ -65,6 +65,16 @@ SYMBOLS = {
     "pislam_frontend_last_stats": (_i, [_vp, ctypes.POINTER(ctypes.c_uint32 * 2)]),
     "pislam_match_hamming": (_i, [_vp, _i, _vp, _sz, _vp, _sz, _vp, _vp, _vp]),
     "pislam_match_hamming_batch": (_i, [_vp, _i, _vp, _vp, _sz, _vp, _vp, _sz, _i, _vp, _vp, _vp]),
+    "pislam_dist_shard": (_i, [_i, _i, _i, ctypes.POINTER(_i), ctypes.POINTER(_i)]),
+    "pislam_dist_get_unique_id": (_i, [ctypes.c_char_p]),
+    "pislam_dist_init": (_i, [_vp, ctypes.c_char_p, _i, _i]),
+    "pislam_dist_rank": (_i, [_vp]),
+    "pislam_dist_world": (_i, [_vp]),
+    "pislam_dist_allgather_counts": (_i, [_vp, _vp, _sz, _vp]),
+    "pislam_dist_fence": (_i, [_vp, _i]),
+    "pislam_dist_synchronize": (_i, [_vp]),
+    "pislam_dist_allreduce_max": (_i, [_vp, ctypes.POINTER(ctypes.c_double)]),
+    "pislam_dist_finalize": (_i, [_vp]),
 }
 
 _LIB = None
@@ -109,6 +119,23 @@ def load(rebuild_if_stale: bool = True):
 
 class PislamError(RuntimeError):
     pass
+
+
+def dist_unique_id() -> bytes:
+    """ncclGetUniqueId through the C ABI (call on one rank, hand the bytes to all)."""
+    buf = ctypes.create_string_buffer(128)
+    rc = load().pislam_dist_get_unique_id(buf)
+    if rc != PISLAM_OK:
+        raise PislamError(f"pislam_dist_get_unique_id failed ({rc}): RCCL not loadable?")
+    return buf.raw
+
+
+def dist_shard(global_batch: int, rank: int, world: int):
+    first, count = _i(0), _i(0)
+    rc = load().pislam_dist_shard(global_batch, rank, world, ctypes.byref(first), ctypes.byref(count))
+    if rc != PISLAM_OK:
+        raise PislamError(f"pislam_dist_shard failed ({rc})")
+    return first.value, first.value + count.value
 
 
 def ptr(a) -> int:
@@ -160,6 +187,29 @@ class Context:
 
     def set_stream(self, stream: int):
         self.check(self.lib.pislam_ctx_set_stream(self.h, _vp(stream)), "pislam_ctx_set_stream")
+
+    # ---- multi-GPU (pislam_dist_*): one process per GPU, one count all-gather over RCCL ----
+    def dist_init(self, unique_id: bytes | None, rank: int, world: int):
+        self.check(self.lib.pislam_dist_init(self.h, unique_id, rank, world), "pislam_dist_init")
+
+    def dist_allgather_counts(self, local_counts, all_counts):
+        """Device tensors: all_counts[r*n + i] = rank r's local_counts[i]; asynchronous (collective stream)."""
+        self.check(self.lib.pislam_dist_allgather_counts(self.h, ptr(local_counts), local_counts.numel(),
+                                                         ptr(all_counts)), "pislam_dist_allgather_counts")
+
+    def dist_fence(self, back: int = 1):
+        self.check(self.lib.pislam_dist_fence(self.h, back), "pislam_dist_fence")
+
+    def dist_synchronize(self):
+        self.check(self.lib.pislam_dist_synchronize(self.h), "pislam_dist_synchronize")
+
+    def dist_allreduce_max(self, value: float) -> float:
+        v = ctypes.c_double(value)
+        self.check(self.lib.pislam_dist_allreduce_max(self.h, ctypes.byref(v)), "pislam_dist_allreduce_max")
+        return float(v.value)
+
+    def dist_finalize(self):
+        self.check(self.lib.pislam_dist_finalize(self.h), "pislam_dist_finalize")
 
     def set_option(self, key: str, value: int):
         self.check(self.lib.pislam_ctx_set_option(self.h, key.encode(), int(value)), f"set_option({key})")

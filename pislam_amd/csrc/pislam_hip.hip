@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -78,9 +79,12 @@ struct DevBuf {
 
 }  // namespace
 
+struct pislam_dist_state;   // pislam_dist.inc
+
 struct pislam_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
+  pislam_dist_state *dist = nullptr;   // multi-GPU state (pislam_dist_init), nullptr for a single GPU
   std::string err;
   // staging for host-pointer calls
   DevBuf s_img, s_out, s_pts, s_desc, s_misc, s_rots, s_tmp;
@@ -89,8 +93,6 @@ struct pislam_ctx {
   // batch pipeline workspace
   DevBuf w_score, w_stage, w_stripcnt, w_work, w_prof, w_ovf;
   int num_cus = 0;
-  const void *pyr_zeroed = nullptr;   // pyramid buffer whose padding is known to be in its defined state
-  size_t pyr_zeroed_sig = 0;
   int opt_pipeline = 0;      // 0 auto, 1 staged (one launch group per level), 2 fused strips
   int opt_dump_score = 0;    // fused pipeline: also materialise the score map (parity hook)
   int opt_strip_rows = 0;    // fused pipeline: strip height override (0 = heuristic)
@@ -103,6 +105,7 @@ struct pislam_ctx {
   int opt_xtile_cols = 0;    // fused pipeline: max classified columns per image x-tile (0 = full width)
   int opt_lds_pad = 0;       // profiling only: extra dynamic LDS bytes per strip workgroup
   int opt_wgs_per_cu = 0;    // fused pipeline: if > 0, size strip heights for this many workgroups per CU
+  int opt_dist_rccl_single = 0;   // test hook: pislam_dist_init(world = 1) still creates a (1-rank) RCCL communicator
   int last_pipeline = 0;
   size_t score_bytes_valid = 0;   // bytes of w_score known to be in a consistent (zero-border) state
   pislam_frontend_params last_params{};
@@ -273,13 +276,13 @@ int check_level_args(pislam_ctx *c, int vstep, int border, int width, int height
 }
 
 // byte hull [lo, hi) of the image the reference's orbCompute reads for these points
-void orb_hull(const uint32_t *pts, size_t n, int vstep, int before, int after, ptrdiff_t *lo,
+void orb_hull(const uint32_t *pts, size_t n, int vstep, int before, int after_rows, int after_cols, ptrdiff_t *lo,
               ptrdiff_t *hi) {
   ptrdiff_t l = PTRDIFF_MAX, h = PTRDIFF_MIN;
   for (size_t i = 0; i < n; i++) {
     const int x = (pts[i] >> 12) & 0xfff, y = pts[i] & 0xfff;
     const ptrdiff_t a = (ptrdiff_t)(y - before) * vstep + (x - before);
-    const ptrdiff_t b = (ptrdiff_t)(y + after) * vstep + (x + after) + 1;
+    const ptrdiff_t b = (ptrdiff_t)(y + after_rows) * vstep + (x + after_cols) + 1;
     l = std::min(l, a);
     h = std::max(h, b);
   }
@@ -290,11 +293,12 @@ void orb_hull(const uint32_t *pts, size_t n, int vstep, int before, int after, p
 // Stage points + the image hull for the point-list entry points.  On return
 // *d_img_base is a device pointer such that d_img_base[y*vstep+x] is valid for
 // every byte the kernels touch.
-// `before`/`after`: how many rows/columns before/after a point the consumer reads
-// (ORB: 15 / 16 incl. the masked column x+16 of Orb.h:200-203; Harris 8x8: 3 / 4).
+// `before`: rows/columns before a point the consumer reads; `after_rows` / `after_cols`: rows / columns after it
+// (ORB: 15 before, rows y+15, columns x+16 incl. the masked column of Orb.h:200-203 — the reference never
+// touches row y+16, and with border = 15 that row may lie past the caller's image; Harris 8x8: 3 / 4 / 4).
 int stage_points_image(pislam_ctx *c, int vstep, const uint8_t *img, const uint32_t *points, size_t n,
                        const uint8_t **d_img_base, const uint32_t **d_pts, int before = 15,
-                       int after = 16) {
+                       int after_rows = 15, int after_cols = 16) {
   Staged sp;
   std::vector<uint32_t> host_pts;
   const bool pts_dev = is_device_ptr(points);
@@ -314,7 +318,7 @@ int stage_points_image(pislam_ctx *c, int vstep, const uint8_t *img, const uint3
     hp = host_pts.data();
   }
   ptrdiff_t lo, hi;
-  orb_hull(hp, n, vstep, before, after, &lo, &hi);
+  orb_hull(hp, n, vstep, before, after_rows, after_cols, &lo, &hi);
   if (lo < 0) return fail(c, PISLAM_ERR_INVALID, "point too close to the image origin for its patch");
   const size_t bytes = (size_t)(hi - lo);
   if (c->s_img.ensure(bytes) != PISLAM_OK) return fail(c, PISLAM_ERR_NOMEM, "hipMalloc(image hull)");
@@ -370,9 +374,12 @@ PISLAM_EXPORT int pislam_ctx_create(int device, pislam_ctx **out) {
   return PISLAM_OK;
 }
 
+PISLAM_EXPORT int pislam_dist_finalize(pislam_ctx *c);
+
 PISLAM_EXPORT int pislam_ctx_destroy(pislam_ctx *c) {
   if (!c) return PISLAM_ERR_INVALID;
   (void)hipSetDevice(c->device);
+  (void)pislam_dist_finalize(c);
   (void)hipStreamSynchronize(c->stream);
   for (DevBuf *b : {&c->s_img, &c->s_out, &c->s_pts, &c->s_desc, &c->s_misc, &c->s_rots, &c->s_tmp, &c->w_cnt,
                     &c->w_off, &c->w_total, &c->w_cellkp, &c->w_score, &c->w_stage, &c->w_stripcnt, &c->w_work, &c->w_prof, &c->w_ovf})
@@ -412,6 +419,8 @@ PISLAM_EXPORT int pislam_ctx_set_option(pislam_ctx *c, const char *key, int valu
   } else if (!strcmp(key, "wgs_per_cu")) {
     if (value < 0 || value > 8) return fail(c, PISLAM_ERR_INVALID, "wgs_per_cu must be 0..8");
     c->opt_wgs_per_cu = value;
+  } else if (!strcmp(key, "dist_rccl_single")) {
+    c->opt_dist_rccl_single = value != 0;
   } else if (!strcmp(key, "orb_chunks")) {
     if (value < 0 || value > 1024) return fail(c, PISLAM_ERR_INVALID, "orb_chunks must be 0..1024");
     c->opt_orb_chunks = value;
@@ -530,6 +539,7 @@ int orb_common(pislam_ctx *c, int mode, int vstep, int words, const uint8_t *img
     PCHK(stage_in(c, c->s_misc, centroids, n8 * sizeof(int32_t), &sc, false));
     if (n8) HIPCHK(c, hipMemsetAsync(sc.dev, 0, n8 * sizeof(int32_t), c->stream));
     if (n) {
+      if (!img || !points) return fail(c, PISLAM_ERR_INVALID, "null pointer");
       const uint8_t *d_img;
       const uint32_t *d_pts;
       PCHK(stage_points_image(c, vstep, img, points, n, &d_img, &d_pts));
@@ -617,7 +627,7 @@ PISLAM_EXPORT int pislam_harris_score_points(pislam_ctx *c, int vstep, const uin
   HIPCHK(c, hipSetDevice(c->device));
   const uint8_t *d_img;
   const uint32_t *d_pts;
-  PCHK(stage_points_image(c, vstep, img, points, n, &d_img, &d_pts, 3, 4));   // Harris.h:102-110
+  PCHK(stage_points_image(c, vstep, img, points, n, &d_img, &d_pts, 3, 4, 4));   // Harris.h:102-110
   Staged ss;
   PCHK(stage_in(c, c->s_rots, scores, n, &ss, false));
   hipLaunchKernelGGL(pk::k_harris_points, dim3(cdiv((int)n, 256)), dim3(256), 0, c->stream, d_img, vstep,
@@ -783,15 +793,34 @@ PISLAM_EXPORT int pislam_pyramid_build_batch(pislam_ctx *c, int nlevels, const i
     return fail(c, PISLAM_ERR_INVALID, "frame buffer too small");
   HIPCHK(c, hipSetDevice(c->device));
   // Padding bytes are read by the bilinear steps and by FAST's right-edge columns: they are defined as
-  // "the buffer was zero before the first build".  Re-building into the same buffer with the same
-  // layout rewrites exactly the same bytes, so the memset is only needed when either changes.
-  size_t sig = (size_t)vstep * 1315423911u ^ (size_t)rows * 2654435761u ^ pyramid_stride ^ ((size_t)batch << 40) ^ (size_t)blur;
-  for (int l = 0; l < nlevels; l++)
-    sig = sig * 31 + (size_t)levels[l].width * 7 + (size_t)levels[l].height * 13 + (size_t)levels[l].row0 + (l + 1 < nlevels ? steps[l] : 0);
-  if (c->pyr_zeroed != pyramids || c->pyr_zeroed_sig != sig) {
-    HIPCHK(c, hipMemsetAsync(pyramids, 0, pyramid_stride * (size_t)batch, c->stream));
-    c->pyr_zeroed = pyramids;
-    c->pyr_zeroed_sig = sig;
+  // zero.  Every build rewrites the same rectangle of each level's slot, so re-establishing that state
+  // means zeroing the complement of those rectangles — done on EVERY call (a caller may have scribbled
+  // over the buffer, or the allocator may hand out a recycled address), at the cost of the padding's size.
+  {
+    pp::ZeroPlan Z;
+    memset(&Z, 0, sizeof(Z));
+    Z.nlevels = nlevels;
+    Z.vstep = vstep;
+    Z.rows = rows;
+    for (int l = 0; l < nlevels; l++) {
+      Z.row0[l] = levels[l].row0;
+      Z.slot_rows[l] = (l + 1 < nlevels ? levels[l + 1].row0 : rows) - levels[l].row0;
+      if (l == 0) {
+        Z.ww[l] = levels[0].width;
+        Z.wh[l] = levels[0].height;
+      } else {
+        const int N = steps[l - 1] == 1 ? 8 : 16, M = steps[l - 1] == 1 ? 7 : 13;
+        Z.ww[l] = (levels[l - 1].width + N - 1) / N * M;
+        Z.wh[l] = (levels[l - 1].height + N - 1) / N * M;
+      }
+    }
+    if (levels[0].row0 > 0) {                         // rows above the first slot are never written
+      HIPCHK(c, hipMemset2DAsync(pyramids, pyramid_stride, 0, (size_t)levels[0].row0 * vstep, batch, c->stream));
+    }
+    const int vpr = (vstep + 15) / 16;
+    hipLaunchKernelGGL(pp::k_zero_outside, dim3(cdiv(rows * vpr, 256), batch), dim3(256), 0, c->stream, Z, pyramids,
+                       pyramid_stride);
+    PCHK(launch_ok(c, "k_zero_outside"));
   }
   const int w0 = levels[0].width, h0 = levels[0].height;
   if (blur) {
@@ -1328,3 +1357,6 @@ PISLAM_EXPORT int pislam_match_hamming_batch(pislam_ctx *c, int words, const uin
   return launch_match(c, words, query, qcounts, q_stride, 0, train, tcounts, t_stride, 0, batch, (uint32_t)q_stride,
                       idx, dist, dist2, q_stride);
 }
+
+// ---- multi-GPU: shard + count all-gather over RCCL -------------------------------
+#include "pislam_dist.inc"

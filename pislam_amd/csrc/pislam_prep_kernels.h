@@ -244,4 +244,34 @@ __global__ __launch_bounds__(256) void k_bilinear(const uint8_t *__restrict__ sr
   }
 }
 
+// ---------------------------------------------------------------------------
+// k_zero_outside — the pyramid builder's "padding is zero" state, re-established on every build:
+// level l's slot is rows [row0, row0 + slot_rows) of the buffer; the build rewrites its rectangle
+// [0, ww) x [0, wh) (level 0: the blurred frame; level l > 0: the whole M x M output blocks of the
+// reduction into it) and reads — bilinear padding (Bilinear.h:32,155), FAST's right-edge columns
+// (Fast.h:37-40) — bytes outside it, which are defined as zero.  One lane per 16-byte vector of a row;
+// vectors inside the rectangle are skipped, so the cost is the padding's size, not the buffer's.
+// ---------------------------------------------------------------------------
+struct ZeroPlan {
+  int nlevels, vstep, rows;
+  int row0[16], slot_rows[16], ww[16], wh[16];
+};
+__global__ __launch_bounds__(256) void k_zero_outside(const ZeroPlan Z, uint8_t *__restrict__ pyramids, size_t stride) {
+  const int vpr = (Z.vstep + 15) >> 4;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const int r = i / vpr, v = i - r * vpr;
+  if (r >= Z.rows) return;
+  int ww = 0;                                         // bytes of this row the build rewrites (0: none)
+  for (int l = 0; l < Z.nlevels; l++)
+    if (r >= Z.row0[l] && r < Z.row0[l] + Z.slot_rows[l]) ww = (r - Z.row0[l] < Z.wh[l]) ? Z.ww[l] : 0;
+  const int x0 = 16 * v, x1 = min(x0 + 16, Z.vstep);
+  if (x1 <= ww) return;
+  uint8_t *p = pyramids + (size_t)blockIdx.y * stride + (size_t)r * Z.vstep;
+  if (x0 >= ww && x1 == x0 + 16 && (((uintptr_t)(p + x0)) & 15) == 0) {
+    *(g_u32x4 *)(p + x0) = (g_u32x4)(0u);
+  } else {
+    for (int x = max(x0, ww); x < x1; x++) p[x] = 0;
+  }
+}
+
 }  // namespace pp

@@ -1,14 +1,21 @@
 """One process per GPU: shard a batch of independent pyramids, all-gather the keypoint counts.
 
-The ORB front-end has no cross-pyramid state, so the data path needs NO collective:
-rank r of G owns the contiguous pyramid range [r*B/G, (r+1)*B/G) (here: a fixed per-rank batch, weak
-scaling).  The only exchange is one all-gather of the per-pyramid keypoint counts (B/G uint32 per
-rank) so that every rank knows the global offsets/total — RCCL over xGMI on GPUs ("nccl" backend),
-gloo on CPU for the tests.
+The ORB front-end has no cross-pyramid state (the reference is a per-frame loop,
+demo.cpp:77-101), so the data path needs NO collective: rank r of G owns the contiguous pyramid range
+[r*B/G, (r+1)*B/G) (here: a fixed per-rank batch, weak scaling).  The only exchange is one all-gather of
+the per-pyramid keypoint counts (B/G uint32 per rank) so that every rank knows the global offsets/total.
+
+Data plane on GPUs: the C ABI's `pislam_dist_*` entry points (include/pislam_hip.h) — an RCCL communicator
+created with ncclCommInitRank from a unique id, ncclAllGather on the context's collective stream.  The same
+entry points serve a C++ host (tools/pislam_demo.cpp).  torch.distributed is only the
+control plane here: rendezvous, handing the unique id to every rank, barriers and the max-over-ranks of the
+timed region.  On CPU-only ranks, or when several test ranks share one GPU (RCCL refuses two ranks on one
+device), the exchange falls back to torch.distributed's own all-gather (gloo) — test mode only.
 """
 from __future__ import annotations
 
 import os
+import sys
 
 import torch
 import torch.distributed as dist
@@ -19,7 +26,7 @@ def env_world():
 
 
 def init(backend: str | None = None):
-    """Initialise torch.distributed from the torchrun environment (no-op for WORLD_SIZE=1)."""
+    """Initialise torch.distributed (the control plane) from the torchrun environment (no-op for WORLD_SIZE=1)."""
     rank, local_rank, world = env_world()
     if world > 1 and not dist.is_initialized():
         if backend is None:
@@ -35,17 +42,55 @@ def init(backend: str | None = None):
 
 
 def shard_range(global_batch: int, rank: int, world: int):
-    """Contiguous split; the first (global_batch % world) ranks take one extra pyramid."""
+    """Contiguous split; the first (global_batch % world) ranks take one extra pyramid
+    (the same arithmetic as the C ABI's pislam_dist_shard)."""
     base, rem = divmod(global_batch, world)
     lo = rank * base + min(rank, rem)
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def gather_counts(local_counts: torch.Tensor, world: int, shard_sizes=None) -> torch.Tensor:
-    """All-gather per-pyramid keypoint counts -> int32 [global_batch] in global pyramid order.
+def init_rccl(ctx, rank: int, world: int, device: torch.device | None = None) -> str | None:
+    """Create the context's RCCL communicator through the C ABI (pislam_dist_init): rank 0 draws the
+    unique id (pislam_dist_get_unique_id) and the control plane broadcasts it.  Returns None on success or
+    the reason the C-ABI path is unavailable — agreed on by ALL ranks, so that they take the same path."""
+    from . import capi
+    if world == 1:
+        ctx.dist_init(None, 0, 1)
+        return None
+    err = None
+    uid = torch.zeros(128, dtype=torch.uint8)
+    if rank == 0:
+        try:
+            uid = torch.frombuffer(bytearray(capi.dist_unique_id()), dtype=torch.uint8).clone()
+        except Exception as e:                      # noqa: BLE001
+            err = repr(e)
+    on_gpu = dist.get_backend() == "nccl"
+    t = uid.to(device) if on_gpu else uid
+    flag = torch.tensor([1 if err else 0], dtype=torch.int32, device=device if on_gpu else None)
+    dist.broadcast(t, src=0)
+    dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+    if int(flag.item()):
+        return err or "rank 0 could not draw an RCCL unique id"
+    try:
+        ctx.dist_init(bytes(t.cpu().numpy().tobytes()), rank, world)
+    except Exception as e:                          # noqa: BLE001
+        err = repr(e)
+    flag = torch.tensor([1 if err else 0], dtype=torch.int32, device=device if on_gpu else None)
+    dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+    if int(flag.item()):
+        try:
+            ctx.dist_finalize()
+        except Exception:                           # noqa: BLE001
+            pass
+        return err or "pislam_dist_init failed on another rank"
+    return None
 
-    Equal shards use one all_gather_into_tensor (a single small RCCL collective); ragged shards pad
-    to the largest shard and trim."""
+
+def gather_counts(local_counts: torch.Tensor, world: int, shard_sizes=None) -> torch.Tensor:
+    """torch.distributed all-gather of per-pyramid keypoint counts -> [global_batch] in global pyramid order
+    (control-plane / test path; the GPU data plane is CountExchange over the C ABI).
+
+    Equal shards use one all_gather_into_tensor; ragged shards pad to the largest shard and trim."""
     if world == 1:
         return local_counts
     if dist.get_backend() == "gloo" and local_counts.is_cuda:     # test mode: gloo moves host tensors
@@ -65,18 +110,45 @@ def gather_counts(local_counts: torch.Tensor, world: int, shard_sizes=None) -> t
 
 class CountExchange:
     """The per-step count all-gather taken OFF the critical path: step i's counts are gathered on the
-    collective's own stream while step i+1 computes into the other of two output sets (the all-gather is
-    latency-bound — 1 KiB per rank — and would otherwise add its ~tens of microseconds to every ~0.4 ms
-    step).  `start(counts)` after the step's kernels are enqueued; `finish()` returns the last gathered
-    tensor.  The caller alternates output sets, so counts[i] stays valid until step i+2, which first
-    waits for its all-gather."""
+    collective stream while step i+1 computes into the other of two output sets (the all-gather is
+    latency-bound — 1 KiB per rank — and would otherwise add its tens of microseconds to every ~0.3 ms step).
 
-    def __init__(self, world: int, always_collective: bool = False):
+        xchg.before_step()        # orders the reuse of the output set written two steps ago
+        <enqueue step i's kernels into output set i % 2>
+        xchg.start(counts_i)      # all-gather of step i's counts, asynchronous
+        ...
+        all_counts = xchg.finish()
+
+    `ctx` (a capi.Context on which init_rccl succeeded) selects the C-ABI RCCL path; without it the
+    exchange uses torch.distributed (gloo test mode, or the fallback bench.py reports as such)."""
+
+    def __init__(self, world: int, ctx=None, always_collective: bool = False):
         self.world = world
+        self.ctx = ctx
         self.always = always_collective      # tests: run the collective path on a 1-rank group too
-        self.pending = [None, None]          # (work, out) per output set
+        self.pending = [None, None]          # torch path: (work, out) per output set
+        self.outs = [None, None]             # C-ABI path: gathered counts per output set
         self.last = None
         self.i = 0
+
+    @property
+    def path(self) -> str:
+        if self.world == 1 and not self.always:
+            return "none (single GPU)"
+        return "pislam_dist_allgather_counts (C ABI, RCCL)" if self.ctx is not None else f"torch.distributed ({dist.get_backend()})"
+
+    def before_step(self):
+        """Call before enqueueing a step: the step overwrites the counts buffer whose all-gather was started
+        two steps ago, so the launch stream first waits (on the device) for that collective."""
+        if self.world == 1 and not self.always:
+            return
+        if self.ctx is not None:
+            self.ctx.dist_fence(2)
+            return
+        prev = self.pending[self.i & 1]
+        if prev is not None:
+            prev[0].wait()
+            self.pending[self.i & 1] = None
 
     def start(self, local_counts: torch.Tensor):
         slot = self.i & 1
@@ -84,24 +156,28 @@ class CountExchange:
         if self.world == 1 and not self.always:
             self.last = local_counts
             return
+        if self.ctx is not None:
+            n = local_counts.numel()
+            if self.outs[slot] is None or self.outs[slot].numel() != n * self.world:
+                self.outs[slot] = torch.empty(n * self.world, dtype=local_counts.dtype, device=local_counts.device)
+            self.ctx.dist_allgather_counts(local_counts, self.outs[slot])
+            self.last = self.outs[slot]
+            return
         if dist.get_backend() == "gloo":     # test mode (host tensors): synchronous
             self.last = gather_counts(local_counts, self.world)
             return
-        prev = self.pending[slot]
-        if prev is not None:
-            prev[0].wait()                   # two steps old: done long ago; orders the buffer reuse
         out = torch.empty(local_counts.numel() * self.world, dtype=local_counts.dtype, device=local_counts.device)
         work = dist.all_gather_into_tensor(out, local_counts, async_op=True)
         self.pending[slot] = (work, out)
-        self.last = (work, out)
+        self.last = out
 
     def finish(self) -> torch.Tensor:
-        for p in self.pending:
+        if self.ctx is not None and not (self.world == 1 and not self.always):
+            self.ctx.dist_synchronize()
+        for k, p in enumerate(self.pending):
             if p is not None:
                 p[0].wait()
-        self.pending = [None, None]
-        if isinstance(self.last, tuple):
-            return self.last[1]
+                self.pending[k] = None
         return self.last
 
 
@@ -109,3 +185,22 @@ def global_offsets(all_counts: torch.Tensor) -> torch.Tensor:
     """Exclusive prefix sum: where pyramid i's keypoints start in a global concatenation."""
     c = all_counts.to(torch.int64)
     return torch.cumsum(c, 0) - c
+
+
+def self_launch(argv, gpus: int, extra_env=None) -> int:
+    """`python bench.py --gpus N` without a torchrun environment: start the N ranks ourselves
+    (python -m torch.distributed.run --nnodes=1 --nproc-per-node N on 127.0.0.1 with a free port) and
+    pass rank 0's output through.  Returns the launcher's exit code."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC (RCCL across processes)
+    env.setdefault("OMP_NUM_THREADS", "1")
+    env.update(extra_env or {})
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port)] + list(argv)
+    return subprocess.call(cmd, env=env)

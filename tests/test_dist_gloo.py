@@ -41,6 +41,7 @@ WORKER = textwrap.dedent('''
         x = pdist.CountExchange(world)
         bufs = [torch.zeros(4, dtype=torch.int32) for _ in range(2)]
         for i in range(5):
+            x.before_step()                  # orders the reuse of bufs[i & 1] against its previous all-gather
             bufs[i & 1].fill_(10 * i + rank)
             x.start(bufs[i & 1])
         allc = x.finish()
@@ -86,3 +87,31 @@ def test_shard_ranges_cover_batch_exactly():
             assert r[0][0] == 0 and r[-1][1] == G
             assert all(r[i][1] == r[i + 1][0] for i in range(world - 1))
             assert max(b - a for a, b in r) - min(b - a for a, b in r) <= 1
+
+
+def test_c_abi_shard_equals_python_shard():
+    """pislam_dist_shard (the C++ host's split, include/pislam_hip.h) == pislam_amd.dist.shard_range."""
+    from pislam_amd import capi, dist as pdist
+    for G in (0, 1, 7, 8, 256, 2048, 2049):
+        for world in (1, 2, 3, 8):
+            for r in range(world):
+                assert capi.dist_shard(G, r, world) == pdist.shard_range(G, r, world)
+    with pytest.raises(capi.PislamError):
+        capi.dist_shard(8, 2, 2)
+
+
+def test_bench_self_launches_its_ranks():
+    """`python bench.py --gpus 2` WITHOUT a torchrun environment must start two ranks itself (the driver's plain
+    invocation) — here in the CPU self-test mode (launch + rendezvous + count exchange)."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--selftest-spawn"],
+                       capture_output=True, text=True, timeout=240, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 2 and d["exchange_ok"] is True
+    # a world size that contradicts --gpus is refused, never silently benchmarked as something else
+    env2 = dict(env, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--selftest-spawn"],
+                       capture_output=True, text=True, timeout=120, env=env2, cwd=ROOT)
+    assert r.returncode != 0 and "WORLD_SIZE=1" in r.stderr

@@ -586,6 +586,7 @@ def test_count_exchange_on_rccl_single_rank_group():
         x = pdist.CountExchange(1, always_collective=True)
         bufs = [torch.zeros(256, dtype=torch.int32, device=dev) for _ in range(2)]
         for i in range(7):
+            x.before_step()
             b = bufs[i & 1]
             b.fill_(i + 1)                    # "step i" writes its counts ...
             x.start(b)                        # ... and hands them to the exchange
@@ -594,6 +595,61 @@ def test_count_exchange_on_rccl_single_rank_group():
         assert out.shape == (256,) and (out.cpu().numpy() == 7).all()
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("rccl", [0, 1])
+def test_count_exchange_through_the_c_abi(rccl):
+    """pislam_dist_* (include/pislam_hip.h): communicator from a unique id, all-gather on the context's
+    collective stream ordered after the context stream, fences for buffer reuse, MAX all-reduce.  rccl=1
+    keeps the real RCCL path (a 1-rank communicator is all a 1-GPU box offers); rank>1 needs more GPUs."""
+    import os
+    import torch
+    from pislam_amd import capi, dist as pdist
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dev = torch.device("cuda:0")
+    s = torch.cuda.Stream(dev)
+    ctx = capi.Context(device=0, stream=s.cuda_stream)
+    try:
+        ctx.set_option("dist_rccl_single", rccl)
+        with pytest.raises(capi.PislamError):
+            ctx.dist_fence(1)                               # not initialised yet
+        ctx.dist_init(capi.dist_unique_id() if rccl else None, 0, 1)
+        assert ctx.lib.pislam_dist_world(ctx.h) == 1 and ctx.lib.pislam_dist_rank(ctx.h) == 0
+        x = pdist.CountExchange(1, ctx=ctx, always_collective=True)
+        assert "C ABI" in x.path
+        bufs = [torch.zeros(256, dtype=torch.int32, device=dev) for _ in range(2)]
+        with torch.cuda.stream(s):
+            for i in range(9):
+                x.before_step()
+                bufs[i & 1].fill_(i + 1)                    # "step i" writes its counts on the context stream ...
+                x.start(bufs[i & 1])                        # ... the all-gather follows it on the collective stream
+            out = x.finish()
+        torch.cuda.synchronize()
+        assert out.shape == (256,) and (out.cpu().numpy() == 9).all()
+        assert ctx.dist_allreduce_max(3.25) == 3.25
+        with pytest.raises(capi.PislamError):
+            ctx.dist_allgather_counts(torch.zeros(4, dtype=torch.int32), torch.zeros(4, dtype=torch.int32))   # host tensors
+        ctx.dist_finalize()
+        ctx.dist_finalize()                                 # idempotent
+    finally:
+        ctx.close()
+
+
+def test_bench_self_launch_two_ranks_sharing_this_gpu():
+    """Plain `python bench.py --gpus 2 --dist-backend gloo` (no torchrun environment): bench.py starts its two
+    ranks itself and rank 0 reports n_gpus 2."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1",
+                          "--batch", "8", "--dist-backend", "gloo", "--no-cpu-baseline", "--spin-s", "0.1"],
+                         capture_output=True, text=True, timeout=300, cwd=root, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["config"]["global_batch"] == 16
 
 
 @pytest.mark.parametrize("border", [16, 17, 19, 20, 32])

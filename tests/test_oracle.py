@@ -214,6 +214,53 @@ def test_fill_spiral_equals_real_reference_when_built(orc):
         assert (got == exp[:h]).all(), (vstep, w, h, cx, cy)
 
 
+def test_fill_random_equals_real_reference_when_built(orc):
+    """test_util::fill_random (TestUtil.cpp:57-65, the fixture of BilinearTest.random* / GaussianTest.random)
+    executed directly from oracle/_ref against the oracle's mt19937_64 restatement."""
+    so = os.path.join(os.path.dirname(GOLDEN), "..", "oracle", "_ref", "libtestutil_ref.so")
+    if not os.path.exists(so):
+        pytest.skip("oracle/_ref not built here")
+    ref = ctypes.CDLL(so)
+    if not hasattr(ref, "ref_fill_random"):
+        pytest.skip("oracle/_ref predates ref_fill_random")
+    ref.ref_fill_random.argtypes = [ctypes.c_int] * 3 + [ctypes.c_void_p]
+    for vstep, w, h in [(64, 1, 1), (64, 47, 47), (64, 13, 40), (640, 63, 63), (640, 16, 16), (640, 640, 480), (1280, 1280, 720)]:
+        exp = np.zeros((h, vstep), np.uint8)
+        ref.ref_fill_random(vstep, w, h, exp.ctypes.data)
+        assert (orc.fill_random(vstep, w, h) == exp).all(), (vstep, w, h)
+    # C++11 [rand.predef]: the 10000th draw of a default mt19937_64 is 9981545732273789042
+    assert int(orc.fill_random(10000, 10000, 1)[0, 9999]) == 9981545732273789042 & 0xff
+
+
+def test_pyramid4_packed_levels_equal_per_level_calls(orc):
+    """orc_pyramid4 (levels anywhere in the buffer, BASELINE config 4's packed layout) against the per-level
+    call sequence of README.md:67-82 with the level origin added (README.md:78)."""
+    from pislam_amd import synth
+    levels = synth.packed_level_table(320, 240)
+    rows = synth.pyramid_rows(levels)
+    img = synth.make_batch(5, 1, w0=320, h0=240, vstep=320, levels=levels, nshapes=40)[0]
+    kp, desc, lc = orc.pyramid4(img, levels)
+    assert any(t[3] != 0 for t in levels)
+    exp = []
+    for (w, h, r0, c0) in levels:
+        sub = np.ascontiguousarray(img.reshape(-1)[r0 * 320 + c0:])
+        pad = (-len(sub)) % 320
+        sub = np.concatenate([sub, np.zeros(pad, np.uint8)]).reshape(-1, 320)
+        out = np.zeros_like(sub)
+        orc.fast_detect(sub, out, w, h, 20)
+        orc.fast_score_harris(sub, out, w, h)
+        exp.append(orc.fast_extract(out, w, h) + np.uint32((c0 << 12) | r0))
+    assert lc.tolist() == [len(e) for e in exp]
+    exp = np.concatenate(exp)
+    assert (kp == exp).all() and len(kp) > 50
+    want = np.zeros((len(exp), 8), np.uint32)
+    orc.lib().orc_orb_compute(320, 8, img.ctypes.data, exp.ctypes.data, len(exp), want.ctypes.data)
+    assert (desc == want).all()
+    # the threaded driver of bench.py's cpu_baseline produces the same keypoint totals
+    n, done, secs = orc.pyramid_mt(img[None], levels, 2, 0.05)
+    assert done >= 2 and n == done * len(kp) and secs > 0 and rows == img.shape[0]
+
+
 def test_extract_edge_cases(orc):
     rng = np.random.default_rng(4)
     # empty map, tiny level, ties, capacity clipping

@@ -64,9 +64,11 @@ def test_gaussian5x5_reference_test_matrix(gpu_ctx, orc):
     sizes = [(w, h) for w in range(16, 64, 5) for h in range(16, 64, 7)] + [(63, 63), (16, 16), (640, 480), (1280, 720), (3, 3), (129, 17)]
     for w, h in sizes:
         vstep = 640 if w <= 640 else 1280
-        for kind in ("spiral", "random"):
+        for kind in ("spiral", "random", "rng"):
             if kind == "spiral":
                 a = orc.fill_spiral(vstep, w, h, vstep // 3, vstep // 3, rows=h + 2)
+            elif kind == "random":               # the reference's own fixture: test_util::fill_random (TestUtil.cpp:57)
+                a = orc.fill_random(vstep, w, h, rows=h + 2)
             else:
                 a = rng.integers(0, 256, (h + 2, vstep), dtype=np.uint8)
             exp = a.copy(); orc.gaussian5x5(exp, w, h)
@@ -84,8 +86,9 @@ def test_bilinear_reference_test_matrix(gpu_ctx, orc):
     for w in list(range(1, 48, 3)) + [47, 16, 32]:
         for h in list(range(1, 48, 5)) + [47, 16, 32]:
             sp = orc.fill_spiral(64, w, h, 21, 21, rows=64)
-            rd = rng.integers(0, 256, (64, 64), dtype=np.uint8)
-            for a in (sp, rd):
+            rd = orc.fill_random(64, w, h, rows=64)         # BilinearTest.cpp:95,149: test_util::fill_random
+            rg = rng.integers(0, 256, (64, 64), dtype=np.uint8)
+            for a in (sp, rd, rg):
                 for name, N, M in (("bilinear7_8", 8, 7), ("bilinear13_16", 16, 13)):
                     exp = a.copy(); getattr(orc, name)(exp, w, h)
                     g = a.copy(); getattr(fe, name)(w, h, g, g, ctx=gpu_ctx)

@@ -5,7 +5,9 @@ usage: tools/hbm_traffic.py <gpurun_out prefix> <out json> [note]
 FETCH_SIZE is reported in KiB and on gfx950 counts 64 B per 128-B request of a wide coalesced stream
 (MI355X_MICROARCH.md, HBM section): read bytes = 2 * FETCH_SIZE * 1024.  WRITE_SIZE (KiB) is uncorrected.
 """
-import collections, csv, json, sys
+import collections, csv, json, os, sys
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 
 
 def per_kernel(path):
@@ -36,7 +38,9 @@ def main():
             d["hbm_bytes_per_launch"] = d["read_bytes_corrected"] + d["write_bytes"]
         if d.get("TCC_HIT_sum") is not None and d.get("TCC_MISS_sum") is not None and d["TCC_HIT_sum"] + d["TCC_MISS_sum"] > 0:
             d["l2_hit_rate"] = d["TCC_HIT_sum"] / (d["TCC_HIT_sum"] + d["TCC_MISS_sum"])
-    json.dump({"source": "rocprofv3 --pmc, separate passes (FETCH_SIZE | WRITE_SIZE | TCC_*), tools/pmc_hbm.sh + "
+    from pislam_amd import build as _b
+    json.dump({"source_hash": _b.source_hash(),
+               "source": "rocprofv3 --pmc, separate passes (FETCH_SIZE | WRITE_SIZE | TCC_*), tools/pmc_hbm.sh + "
                          "tools/hbm_traffic.py; bench.py --steps 3 --warmup 1 (batch 256, synthetic VGA pyramids), MI355X. " + note,
                "note": "read bytes = 2 * FETCH_SIZE(KiB) * 1024 (gfx950 correction, MI355X_MICROARCH.md HBM section); "
                        "WRITE_SIZE (KiB) uncorrected; averages over the launches of each kernel",

@@ -1,0 +1,320 @@
+// tools/pislam_demo.cpp — the demo-equivalent tool: what reference demo/demo.cpp:51-117
+// does (load a stacked grey pyramid, fastDetect -> fastScoreHarris -> fastExtract per level, orbCompute,
+// print the time and "<n> features"), as a C++ host program over the drop-in headers include/pislam/*.h
+// and the C ABI include/pislam_hip.h — no libpng (raw or binary PGM in, a flat binary file out), no Python,
+// no torch in the process.
+//
+//   pislam_demo <pyramid.raw|pyramid.pgm> [--buckets] [--out result.bin]
+//       the reference's call sequence through the pislam:: templates (host arrays, staged per call), with
+//       the wall time of every stage — the equivalent of demo.cpp's "CPU  Time" line (demo.cpp:113-114)
+//   ... --batch N [--steps K]
+//       the measured path: N copies of the pyramid resident on the device, pislam_orb_frontend_batch
+//       K times, per-stage hipEvent times (pislam_frontend_last_timing)
+//   ... --batch N --world W [--rccl-single]
+//       one PROCESS per GPU (this program forks W ranks before touching HIP): rank 0 draws the RCCL
+//       unique id (pislam_dist_get_unique_id) and hands it over through a file, every rank runs its shard of
+//       the W*N pyramids and the per-pyramid counts are all-gathered (pislam_dist_allgather_counts) — the
+//       C++ binding of SURVEY §8e / INTEGRATION.md §4.  --rccl-single keeps the RCCL path for W = 1.
+//
+// result.bin: uint32 n, uint32 n_desc_words, keypoints[n], descriptors[n_desc_words]
+//
+// build: make -C tools   (plain g++ with -D__HIP_PLATFORM_AMD__ against include/, libpislam_hip.so and libamdhip64)
+#include <hip/hip_runtime_api.h>
+#include <sys/wait.h>
+#include <unistd.h>
+
+#include <chrono>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "pislam/Fast.h"
+#include "pislam/Orb.h"
+
+namespace {
+
+constexpr int IMG_W = 640, ROWS = 2210, NLEVELS = 8;
+struct Level { int width, height; };
+// the demo's level table (demo.cpp:38-47): round(640 / 1.2^k) x round(480 / 1.2^k)
+const Level kLevels[NLEVELS] = {{640, 480}, {533, 400}, {444, 333}, {370, 278}, {309, 231}, {257, 193}, {214, 161}, {179, 134}};
+
+uint8_t img[ROWS][IMG_W];
+uint8_t out[ROWS][IMG_W];
+
+double now_ms() {
+  using namespace std::chrono;
+  return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
+}
+
+// raw (exactly ROWS * IMG_W bytes) or binary PGM "P5 <w> <h> <maxval<=255>"
+bool load_pyramid(const char *path) {
+  FILE *f = fopen(path, "rb");
+  if (!f) return false;
+  char magic[3] = {0, 0, 0};
+  bool ok = false;
+  if (fread(magic, 1, 2, f) == 2 && magic[0] == 'P' && magic[1] == '5') {
+    int vals[3], got = 0, ch;
+    while (got < 3 && (ch = fgetc(f)) != EOF) {
+      if (ch == '#') {
+        while ((ch = fgetc(f)) != EOF && ch != '\n') {}
+      } else if (ch >= '0' && ch <= '9') {
+        int v = ch - '0';
+        while ((ch = fgetc(f)) != EOF && ch >= '0' && ch <= '9') v = 10 * v + (ch - '0');
+        vals[got++] = v;               // the single whitespace after maxval has just been consumed
+      }
+    }
+    ok = got == 3 && vals[0] == IMG_W && vals[1] == ROWS && vals[2] <= 255 && fread(img, 1, sizeof(img), f) == sizeof(img);
+  } else {
+    rewind(f);
+    ok = fread(img, 1, sizeof(img), f) == sizeof(img);
+  }
+  fclose(f);
+  return ok;
+}
+
+void write_result(const char *path, const std::vector<uint32_t> &kp, const std::vector<uint32_t> &desc) {
+  FILE *o = fopen(path, "wb");
+  if (!o) return;
+  const uint32_t n = (uint32_t)kp.size(), m = (uint32_t)desc.size();
+  fwrite(&n, 4, 1, o);
+  fwrite(&m, 4, 1, o);
+  fwrite(kp.data(), 4, n, o);
+  fwrite(desc.data(), 4, m, o);
+  fclose(o);
+}
+
+#define HIP_OK(call)                                                                     \
+  do {                                                                                   \
+    hipError_t e_ = (call);                                                              \
+    if (e_ != hipSuccess) {                                                              \
+      fprintf(stderr, "%s -> %s\n", #call, hipGetErrorString(e_));                        \
+      return 10;                                                                         \
+    }                                                                                    \
+  } while (0)
+#define PISLAM_OK_(ctx, call)                                                            \
+  do {                                                                                   \
+    int r_ = (call);                                                                     \
+    if (r_ != PISLAM_OK) {                                                               \
+      fprintf(stderr, "%s -> %d (%s)\n", #call, r_, pislam_last_error(ctx));              \
+      return 11;                                                                         \
+    }                                                                                    \
+  } while (0)
+
+// the reference's call sequence through the drop-in templates, timed per stage
+int run_dropin(bool buckets, const char *out_path) {
+  std::vector<uint32_t> points, descriptors;
+  pislam::detail::runtime();                          // device / library start-up outside the timed part
+  {
+    static uint8_t warm_in[64][IMG_W], warm_out[64][IMG_W];   // the first launch loads the code object
+    pislam::fastDetect<IMG_W, 16>(64, 64, warm_in, warm_out, 20);
+  }
+  double t_detect = 0, t_harris = 0, t_extract = 0, t_orb = 0;
+  const double begin = now_ms();
+  uint32_t pyramidRow = 0;
+  for (int l = 0; l < NLEVELS; l++) {
+    const int w = kLevels[l].width, h = kLevels[l].height;
+    uint8_t(*imgPtr)[IMG_W] = &img[pyramidRow];
+    uint8_t(*outPtr)[IMG_W] = &out[pyramidRow];
+    const double t0 = now_ms();
+    pislam::fastDetect<IMG_W, 16>(w, h, imgPtr, outPtr, 20);
+    const double t1 = now_ms();
+    pislam::fastScoreHarris<IMG_W, 16>(w, h, imgPtr, 1 << 15, outPtr);
+    const double t2 = now_ms();
+    const size_t oldSize = points.size();
+    if (buckets)
+      pislam::fastExtract<IMG_W, 16, 4, 3>(w, h, outPtr, points);     // README.md:45,76
+    else
+      pislam::fastExtract<IMG_W, 16>(w, h, outPtr, points);
+    const double t3 = now_ms();
+    for (size_t i = oldSize; i < points.size(); i++)                  // demo.cpp:92-97 / README.md:78
+      points[i] = pislam::encodeFast(pislam::decodeFastScore(points[i]), pislam::decodeFastX(points[i]),
+                                     pislam::decodeFastY(points[i]) + pyramidRow);
+    t_detect += t1 - t0;
+    t_harris += t2 - t1;
+    t_extract += t3 - t2;
+    pyramidRow += (uint32_t)h;
+  }
+  const double t4 = now_ms();
+  pislam::orbCompute<IMG_W, 8>(img, points, descriptors);
+  const double end = now_ms();
+  t_orb = end - t4;
+  printf("GPU  Time: %.3f ms  (fastDetect %.3f, fastScoreHarris %.3f, fastExtract %.3f, orbCompute %.3f; "
+         "host<->device staging of every call included)\n", end - begin, t_detect, t_harris, t_extract, t_orb);
+  printf("%zu features\n", points.size());
+  if (out_path) write_result(out_path, points, descriptors);
+  return 0;
+}
+
+// the measured path from C++: device-resident batch, optional shard over `world` processes
+int run_batch(int batch, int steps, bool buckets, const char *out_path, int rank, int world, const char *id_file,
+              bool rccl_single) {
+  int ndev = 0;
+  HIP_OK(hipGetDeviceCount(&ndev));
+  if (ndev < 1) {
+    fprintf(stderr, "no HIP device\n");
+    return 10;
+  }
+  if (world > ndev && !(world == 1)) {
+    fprintf(stderr, "--world %d needs %d GPUs (one process per GPU), %d visible\n", world, world, ndev);
+    return 12;
+  }
+  const int device = rank % ndev;
+  HIP_OK(hipSetDevice(device));
+  pislam_ctx *ctx = nullptr;
+  if (pislam_ctx_create(device, &ctx) != PISLAM_OK) return 11;
+  hipStream_t stream;
+  HIP_OK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+  PISLAM_OK_(ctx, pislam_ctx_set_stream(ctx, stream));
+
+  // ---- one process per GPU: communicator from a unique id handed over through a file ----
+  uint8_t id[PISLAM_DIST_ID_BYTES];
+  memset(id, 0, sizeof(id));
+  const bool need_id = world > 1 || rccl_single;
+  if (need_id) {
+    if (rank == 0) {
+      if (pislam_dist_get_unique_id(id) != PISLAM_OK) {
+        fprintf(stderr, "pislam_dist_get_unique_id failed (RCCL not loadable?)\n");
+        return 13;
+      }
+      const std::string tmp = std::string(id_file) + ".tmp";
+      FILE *f = fopen(tmp.c_str(), "wb");
+      if (!f || fwrite(id, 1, sizeof(id), f) != sizeof(id)) return 13;
+      fclose(f);
+      rename(tmp.c_str(), id_file);                    // atomic: readers never see a partial id
+    } else {
+      FILE *f = nullptr;
+      for (int tries = 0; tries < 6000 && !(f = fopen(id_file, "rb")); tries++) usleep(10000);
+      if (!f || fread(id, 1, sizeof(id), f) != sizeof(id)) {
+        fprintf(stderr, "rank %d: no unique id at %s\n", rank, id_file);
+        return 13;
+      }
+      fclose(f);
+    }
+    if (rccl_single) PISLAM_OK_(ctx, pislam_ctx_set_option(ctx, "dist_rccl_single", 1));
+  }
+  PISLAM_OK_(ctx, pislam_dist_init(ctx, need_id ? id : nullptr, rank, world));
+
+  // ---- this rank's shard of the world * batch pyramids (all copies of the one input here) ----
+  int first = 0, count = 0;
+  pislam_dist_shard(world * batch, rank, world, &first, &count);
+  pislam_level lv[NLEVELS];
+  int row = 0;
+  for (int l = 0; l < NLEVELS; l++) {
+    lv[l] = {kLevels[l].width, kLevels[l].height, row, 0};
+    row += kLevels[l].height;
+  }
+  pislam_frontend_params P = {IMG_W, ROWS, NLEVELS, 16, 20, 1 << 15, buckets ? 4 : 0, buckets ? 3 : 5, 8, 4096};
+  const size_t pyr_bytes = (size_t)ROWS * IMG_W;
+  uint8_t *d_pyr = nullptr;
+  uint32_t *d_kp = nullptr, *d_desc = nullptr, *d_counts = nullptr, *d_all = nullptr;
+  HIP_OK(hipMalloc(&d_pyr, pyr_bytes * count));
+  HIP_OK(hipMalloc(&d_kp, sizeof(uint32_t) * (size_t)P.max_keypoints * count));
+  HIP_OK(hipMalloc(&d_desc, sizeof(uint32_t) * (size_t)P.max_keypoints * P.words * count));
+  HIP_OK(hipMalloc(&d_counts, sizeof(uint32_t) * count));
+  HIP_OK(hipMalloc(&d_all, sizeof(uint32_t) * (size_t)count * world));
+  for (int b = 0; b < count; b++) HIP_OK(hipMemcpyAsync(d_pyr + b * pyr_bytes, img, pyr_bytes, hipMemcpyHostToDevice, stream));
+  PISLAM_OK_(ctx, pislam_frontend_reserve(ctx, &P, lv, count));
+  PISLAM_OK_(ctx, pislam_orb_frontend_batch(ctx, &P, lv, d_pyr, pyr_bytes, count, d_kp, d_desc, d_counts));   // warm-up
+  HIP_OK(hipStreamSynchronize(stream));
+
+  double barrier = 0;
+  PISLAM_OK_(ctx, pislam_dist_allreduce_max(ctx, &barrier));        // all ranks start together
+  const double t0 = now_ms();
+  for (int s = 0; s < steps; s++) {
+    PISLAM_OK_(ctx, pislam_dist_fence(ctx, 1));                      // one output set: wait for the previous all-gather
+    PISLAM_OK_(ctx, pislam_orb_frontend_batch(ctx, &P, lv, d_pyr, pyr_bytes, count, d_kp, d_desc, d_counts));
+    PISLAM_OK_(ctx, pislam_dist_allgather_counts(ctx, d_counts, (size_t)count, d_all));
+  }
+  HIP_OK(hipStreamSynchronize(stream));
+  PISLAM_OK_(ctx, pislam_dist_synchronize(ctx));
+  double dt = now_ms() - t0;
+  PISLAM_OK_(ctx, pislam_dist_allreduce_max(ctx, &dt));             // the slowest rank
+
+  float total_ms = 0, stage_ms[3] = {0, 0, 0};
+  PISLAM_OK_(ctx, pislam_frontend_last_timing(ctx, &total_ms, stage_ms));
+  std::vector<uint32_t> all((size_t)count * world);
+  HIP_OK(hipMemcpy(all.data(), d_all, all.size() * 4, hipMemcpyDeviceToHost));
+  unsigned long long total = 0;
+  for (uint32_t c : all) total += c < (uint32_t)P.max_keypoints ? c : (uint32_t)P.max_keypoints;
+  if (rank == 0) {
+    printf("GPU  Time: %.3f ms per batch of %d x %d pyramids  (device stages of the last call: detect+score+nms %.3f, "
+           "overflow pass %.3f, gather+orb %.3f ms; %d ranks, count all-gather: %s)\n",
+           dt / steps, world, count, stage_ms[0], stage_ms[1], stage_ms[2], world,
+           (world > 1 || rccl_single) ? "ncclAllGather via pislam_dist_allgather_counts" : "single GPU");
+    printf("%llu features in %d pyramids (%u per pyramid), %.3e features/s\n", total, world * count, all[0],
+           (double)total * steps / (dt * 1e-3));
+    if (out_path) {                                      // pyramid 0 of rank 0
+      const uint32_t n = all[0] < (uint32_t)P.max_keypoints ? all[0] : (uint32_t)P.max_keypoints;
+      std::vector<uint32_t> kp(n), desc((size_t)n * P.words);
+      HIP_OK(hipMemcpy(kp.data(), d_kp, n * 4, hipMemcpyDeviceToHost));
+      HIP_OK(hipMemcpy(desc.data(), d_desc, desc.size() * 4, hipMemcpyDeviceToHost));
+      write_result(out_path, kp, desc);
+    }
+  }
+  // every pyramid is the same image here, so every gathered count must be equal — on every rank
+  int bad = 0;
+  for (uint32_t c : all) bad += c != all[0];
+  pislam_dist_finalize(ctx);
+  pislam_ctx_destroy(ctx);
+  (void)hipFree(d_pyr); (void)hipFree(d_kp); (void)hipFree(d_desc); (void)hipFree(d_counts); (void)hipFree(d_all);
+  return bad ? 14 : 0;
+}
+
+}  // namespace
+
+int main(int argc, char **argv) {
+  if (argc < 2) {
+    fprintf(stderr, "Usage: %s pyramid.raw|pyramid.pgm [--buckets] [--out result.bin] [--batch N [--steps K] "
+                    "[--world W] [--rccl-single]]\n", argv[0]);
+    return 1;
+  }
+  bool buckets = false, rccl_single = false;
+  const char *out_path = nullptr;
+  int batch = 0, steps = 10, world = 1;
+  for (int i = 2; i < argc; i++) {
+    if (!strcmp(argv[i], "--buckets")) buckets = true;
+    else if (!strcmp(argv[i], "--rccl-single")) rccl_single = true;
+    else if (!strcmp(argv[i], "--out") && i + 1 < argc) out_path = argv[++i];
+    else if (!strcmp(argv[i], "--batch") && i + 1 < argc) batch = atoi(argv[++i]);
+    else if (!strcmp(argv[i], "--steps") && i + 1 < argc) steps = atoi(argv[++i]);
+    else if (!strcmp(argv[i], "--world") && i + 1 < argc) world = atoi(argv[++i]);
+    else {
+      fprintf(stderr, "unknown argument %s\n", argv[i]);
+      return 1;
+    }
+  }
+  if (!load_pyramid(argv[1])) {
+    fprintf(stderr, "%s: expected a raw or binary-PGM grey image of %d x %d (the demo's stacked 8-level pyramid)\n",
+            argv[1], IMG_W, ROWS);
+    return 2;
+  }
+  if (batch <= 0) return run_dropin(buckets, out_path);
+  if (world < 1 || steps < 1) return 1;
+  // one process per GPU: fork the ranks BEFORE the first HIP call (a forked HIP runtime is unusable)
+  char id_file[256];
+  snprintf(id_file, sizeof(id_file), "/tmp/pislam_demo_id_%d", (int)getpid());
+  unlink(id_file);
+  if (world == 1) {
+    const int rc = run_batch(batch, steps, buckets, out_path, 0, 1, id_file, rccl_single);
+    unlink(id_file);
+    return rc;
+  }
+  std::vector<pid_t> kids;
+  for (int r = 0; r < world; r++) {
+    const pid_t pid = fork();
+    if (pid < 0) return 20;
+    if (pid == 0) _exit(run_batch(batch, steps, buckets, out_path, r, world, id_file, false));
+    kids.push_back(pid);
+  }
+  int rc = 0;
+  for (pid_t k : kids) {
+    int st = 0;
+    waitpid(k, &st, 0);
+    if (!WIFEXITED(st) || WEXITSTATUS(st) != 0) rc = WIFEXITED(st) ? WEXITSTATUS(st) : 21;
+  }
+  unlink(id_file);
+  return rc;
+}
