@@ -88,6 +88,7 @@ def main():
     ap.add_argument("--xtile-cols", type=int, default=-1)
     ap.add_argument("--run-len", type=int, default=0)
     ap.add_argument("--alias", type=int, default=-1)
+    ap.add_argument("--orb-in-strip", type=int, default=-1, help="1: strips describe their own keypoints; 0 (default): one gather+ORB pass")
     ap.add_argument("--graph", type=int, default=1,
                     help="1 (default): capture the step's launches into a hipGraph (torch.cuda.CUDAGraph) per output set "
                          "and replay it — falls back to eager launches if the capture or its check fails; 0: eager")
@@ -171,6 +172,8 @@ def main():
     ctx.set_option("lds_pad", args.lds_pad)
     if args.alias >= 0:
         ctx.set_option("alias", args.alias)
+    if args.orb_in_strip >= 0:
+        ctx.set_option("orb_in_strip", args.orb_in_strip)
     if args.run_len:
         ctx.set_option("run_len", args.run_len)
     if args.xtile_cols >= 0:

@@ -48,8 +48,10 @@ constexpr int QH_SHARED = 1024;        // workgroup-shared queue of corners awai
 constexpr int QN_SHARED = 512;         // plain layout only: queue of pixels with a non-zero score (NMS candidates)
 constexpr int QS_SHARED = 256;         // survivors of one strip awaiting their rank
 constexpr int SHARED_Q = QH_SHARED + QN_SHARED;
-constexpr int NMS_SCRATCH = 3 * QS_SHARED;   // dwords: survivors, their keys, bucket keep flags (in the idle per-wave queues)
+constexpr int NMS_SCRATCH = 3 * QS_SHARED;   // dwords: survivors, their keys (then ranks), bucket keep flags (in the idle per-wave queues)
 static_assert(NMS_SCRATCH <= WAVES * QCAP, "NMS scratch must fit the per-wave queue area");
+static_assert(QS_SHARED <= NT, "one survivor per thread (ranks are held in a register across a barrier)");
+constexpr uint32_t STRIP_DESCRIBED = 0x80000000u;   // strip_count bit 31: the strip wrote its keypoints' descriptors
 
 struct FusedLevel {
   int w, h;          // level size
@@ -81,6 +83,8 @@ struct FusedParams {
   int32_t hthr;
   int batch;
   int lbs, limit;    // fastExtract logBucketSize (0 = none; fused path: 2..5) and bucketLimit
+  int words;         // orbCompute words (descriptor dwords per keypoint)
+  int orb_in_strip;  // ALIAS + 16-byte-aligned kernels: strips describe their own keypoints (strip_body phase E)
   int dump_score;    // debug: also write the score tile to the HBM score map
   int ablate;        // profiling only: bit0 stop after staging, bit1 pretest only, bit2 no Harris, bit3 no NMS
   FusedLevel lv[MAX_LEVELS];
@@ -135,11 +139,165 @@ __device__ __attribute__((noinline)) void harris_overflow(lds_u8 *tile, lds_u8 *
   }
 }
 
+// ===========================================================================
+// ORB for two keypoints per wave (one per 32-lane half) — orbCompute, Orb.h:396-441 — shared by the strip
+// kernel (keypoints described right after their strip's NMS, while the rows they need are still in the L2
+// that just served the strip) and by k_gather_orb (keypoints of strips that took a fallback path).
+//   lane r of a half owns patch row dy = r-15.  Each row's 48-byte window covering x-15..x+16 is fetched as
+//   three 16-byte chunks by ADJACENT lanes (one or two cache lines per row), parked in an LDS patch (pitch
+//   48) and read back patch-aligned with 9 aligned dwords + v_alignbyte; the circle mask (Orb.h:118-121,
+//   163-286) is a per-lane constant; the moments are v_dot4_u32_u8 dot products with the |dx| weights
+//   (Orb.h:123-126); rows are summed across the 32 lanes by DPP; every lane evaluates the angle bin
+//   (Orb.h:310-387); the 256 BRIEF tests (Brief.h:52) read the LDS patch through the precomputed offset
+//   table g_brief_ofs, 32 pairs per half-wave per round, one ballot = one descriptor word per keypoint.
+// ===========================================================================
+constexpr int OWAVES = 4;                           // waves per k_gather_orb workgroup
+constexpr int ORB_PITCH = 48;                       // one 48-byte (3 x 16 B) window per patch row
+constexpr int ORB_PATCH_BYTES = 32 * ORB_PITCH + 16;   // 31 rows (+1 idle) + slack for the byte shift
+
+// Sum over each 32-lane half of the wave, result in every lane of that half.  DPP row shifts
+// (zero fill) leave each 16-lane row's sum in its last lane, row_bcast:15 folds row 0 into row 1 and
+// row 2 into row 3, two v_readlane pick the totals up.
+__device__ __forceinline__ int half_sum(int v, int half) {
+  v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);   // row_shr:1
+  v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);   // row_shr:2
+  v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);   // row_shr:4
+  v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);   // row_shr:8
+  v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);  // row_bcast:15 into rows 1 and 3
+  const int s0 = __builtin_amdgcn_readlane(v, 31), s1 = __builtin_amdgcn_readlane(v, 63);
+  return half ? s1 : s0;
+}
+
+struct OrbWin {
+  uint4 w[3];
+};
+// Per-lane geometry of the pair scheme: slot j = lane + 64 j -> (keypoint half, patch row, 16-byte chunk) with
+// the three chunks of a row in ADJACENT lanes (the L1 processes a divergent load at about one distinct cache
+// line per cycle: one or two lines per row instead of three requests).
+struct OrbLane {
+  int half, r;                                      // r = patch row index, dy = r - 15 (r = 31 idle)
+  int sl_h[3], sl_park[3], sl_rel[3];
+  bool sl_on[3];
+  uint32_t cmask[8];                                // circle mask of this lane's row: byte j of the 32 covers dx = j - 15
+};
+__device__ __forceinline__ OrbLane orb_lane(int lane, int vstep) {
+  OrbLane G;
+  G.half = lane >> 5;
+  G.r = lane & 31;
+  const int dy = G.r - 15;
+  const int u = (G.r < 31) ? patch_umax(dy < 0 ? -dy : dy) : -1;
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    uint32_t m = 0;
+#pragma unroll
+    for (int b = 0; b < 4; b++) {
+      const int dx = 4 * k + b - 15, adx = dx < 0 ? -dx : dx;
+      if (adx <= u) m |= 0xffu << (8 * b);
+    }
+    G.cmask[k] = m;
+  }
+#pragma unroll
+  for (int j = 0; j < 3; j++) {
+    const int slot = lane + 64 * j;                 // 0..191, 186 used
+    const int h = slot >= 93 ? 1 : 0, within = slot - 93 * h;
+    const int row = within / 3, chunk = within - 3 * row;
+    G.sl_h[j] = h;
+    G.sl_on[j] = slot < 186;
+    G.sl_rel[j] = row * vstep + 16 * chunk;         // byte offset of the chunk relative to the patch origin (y-15, x-15)
+    G.sl_park[j] = h * ORB_PATCH_BYTES + row * ORB_PITCH + 16 * chunk;
+  }
+  return G;
+}
+// Issue the loads of one pair (p0 / p1: packed keypoints in stacked coordinates, 0 = absent).  vstep % 16 == 0
+// makes the byte shift row-independent.  A chunk that starts outside the pyramid (absent keypoint, idle slot,
+// window slack past the last row) holds no byte any patch uses — the buffer size is a multiple of 16 — so it
+// is simply clamped into the buffer instead of being zero-filled.  32-bit byte offsets: a pyramid is < 2 GiB;
+// a negative offset wraps to a huge unsigned value and is clamped too.
+__device__ __forceinline__ OrbWin orb_fetch(const OrbLane &G, uint32_t p0, uint32_t p1, const uint8_t *__restrict__ im,
+                                            int vstep, uint32_t img_bytes32) {
+  OrbWin f;
+  const int org0 = (decode_y(p0) - 15) * vstep + (decode_x(p0) - 15);
+  const int org1 = (decode_y(p1) - 15) * vstep + (decode_x(p1) - 15);
+#pragma unroll
+  for (int j = 0; j < 3; j++) {
+    const int org = G.sl_h[j] ? org1 : org0;
+    const uint32_t a = min((uint32_t)(org + G.sl_rel[j]) & ~15u, img_bytes32 - 16u);
+    f.w[j] = *(const uint4 *)(im + a);
+  }
+  return f;
+}
+// Park the fetched windows of a pair, then moments -> angle bin -> BRIEF.  `dst`: where this half's keypoint
+// keeps its `words` descriptor words (ignored when that keypoint is absent).  `wave_patches`: 2 x
+// ORB_PATCH_BYTES of LDS private to the wave.  `rtab`: the vrecpe estimate table in LDS.
+template <class TAB>
+__device__ __forceinline__ void orb_describe(const OrbLane &G, const OrbWin &cur, uint32_t p0, uint32_t p1,
+                                             lds_u8 *wave_patches, int vstep, const TAB *rtab, int words,
+                                             uint32_t *__restrict__ dst) {
+  const int half = G.half, r = G.r;
+  const uint32_t pme = half ? p1 : p0;
+  const bool valid = pme != 0;
+  const int x = decode_x(pme), y = decode_y(pme);
+  const uint32_t sh = (uint32_t)(((y - 15) * vstep + (x - 15)) & 15);   // same for every row
+#pragma unroll
+  for (int j = 0; j < 3; j++)
+    if (G.sl_on[j]) *(lds_u4 *)(wave_patches + G.sl_park[j]) = (u32x4){cur.w[j].x, cur.w[j].y, cur.w[j].z, cur.w[j].w};
+  lds_u8 *patch_l = wave_patches + half * ORB_PATCH_BYTES;
+  const lds_u8 *prow = patch_l + r * ORB_PITCH;
+  // read the row back aligned to the PATCH: 9 aligned dwords + v_alignbyte (byte-unaligned
+  // ds_read_b32 works on gfx950 but costs ~47 stall cycles each — SQ_LDS_UNALIGNED_STALL)
+  uint32_t row[8];
+  {
+    const lds_u8 *pa = prow + (sh & ~3u);
+    uint32_t in[9];
+#pragma unroll
+    for (int k = 0; k < 9; k++) in[k] = *(const lds_u32 *)(pa + 4 * k);
+#pragma unroll
+    for (int k = 0; k < 8; k++) row[k] = __builtin_amdgcn_alignbyte(in[k + 1], in[k], sh & 3u);
+  }
+  // moments of this row: sum v and sum |dx| v, left (dx<0) and right (dx>0) separately
+  uint32_t sv = 0, left = 0, right = 0;
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    const uint32_t v = row[k] & G.cmask[k];
+    sv = __builtin_amdgcn_udot4(v, 0x01010101u, sv, false);
+  }
+  left = __builtin_amdgcn_udot4(row[0] & G.cmask[0], 0x0c0d0e0fu, left, false);    // dx -15..-12
+  left = __builtin_amdgcn_udot4(row[1] & G.cmask[1], 0x08090a0bu, left, false);    // dx -11..-8
+  left = __builtin_amdgcn_udot4(row[2] & G.cmask[2], 0x04050607u, left, false);    // dx  -7..-4
+  left = __builtin_amdgcn_udot4(row[3] & G.cmask[3], 0x00010203u, left, false);    // dx  -3..0
+  right = __builtin_amdgcn_udot4(row[4] & G.cmask[4], 0x04030201u, right, false);  // dx   1..4
+  right = __builtin_amdgcn_udot4(row[5] & G.cmask[5], 0x08070605u, right, false);  // dx   5..8
+  right = __builtin_amdgcn_udot4(row[6] & G.cmask[6], 0x0c0b0a09u, right, false);  // dx   9..12
+  right = __builtin_amdgcn_udot4(row[7] & G.cmask[7], 0x000f0e0du, right, false);  // dx  13..15 (16 masked)
+  const int m10 = half_sum((int)right - (int)left, half);
+  const int m01 = half_sum((r - 15) * (int)sv, half);
+  const uint32_t rot = angle_bin_with(m10, m01, [&](float f) { return vrecpe_f32_tab(f, rtab); });
+  // BRIEF: pair k = 32*round + r of this half's keypoint -> bit r of word `round`
+  const uint32_t *tab = ::g_brief_ofs.v + rot * 256 + r;   // defined by the including TU
+  // the patch's byte (dy,dx) sits at (dy+15)*48 + sh + dx+15; sh is the same for every row
+  const lds_u8 *bp = patch_l + sh;
+  uint32_t myword = 0;
+  uint32_t ent[8];
+#pragma unroll
+  for (int round = 0; round < 8; round++) ent[round] = tab[32 * round];   // all 8 table loads in flight
+#pragma unroll
+  for (int round = 0; round < 8; round++) {
+    const uint32_t e = ent[round];
+    const uint32_t a = bp[e & 0xffffu], b = bp[e >> 16];
+    const uint64_t m = __ballot(a < b);                           // Brief.h:52
+    // lane `round` of either half keeps that half's word (rounds >= words are never stored)
+    const uint32_t w = half ? (uint32_t)(m >> 32) : (uint32_t)m;
+    if (r == round) myword = w;
+  }
+  if (valid && r < words) dst[r] = myword;
+}
+
 // Scalar copies of the kernel arguments the strip body needs (the by-value FusedParams must not be
 // captured by reference anywhere: hipcc then spills the whole 800-byte struct to scratch).
 struct StripArgs {
   int border, thr, ablate, dump_score, lbs, limit, vstep, slots_per_pyr, strips_per_pyr;
   int32_t hthr;
+  int words, orb;
 };
 
 // All phases of one strip.  The SCORE tile covers the full level width; the IMAGE tile is staged in
@@ -157,8 +315,13 @@ __device__ __forceinline__ void strip_body(const StripArgs A, const FusedLevel L
                                            size_t score_stride, const bool carry, const int tid,
                                            unsigned long long *__restrict__ prof, u32x4 (&pf)[PF_MAX],
                                            const bool pf_have, const bool pf_want, bool &pf_issued,
-                                           uint32_t *__restrict__ ovf, const uint32_t ovf_id) {
+                                           uint32_t *__restrict__ ovf, const uint32_t ovf_id,
+                                           uint32_t *__restrict__ stage_desc, const uint8_t *__restrict__ imb,
+                                           const uint32_t img_bytes32) {
   const int B = A.border;
+  // Phase E exists in the ALIAS kernels on 16-byte aligned layouts (vstep % 16 == 0 makes a patch's byte
+  // shift row-independent); elsewhere k_gather_orb describes the keypoints.
+  constexpr bool ORB = ALIAS && VEC16;
   const int pitch = L.pitch, tpitch = L.tpitch;
   lds_u8 *tile = tile0;                             // re-based per x-tile: tile + row*tpitch + x with level column x
   int cxa = B, cxb = L.xend;                        // classified columns [cxa, cxb) of the current x-tile
@@ -636,15 +799,46 @@ __device__ __forceinline__ void strip_body(const StripArgs A, const FusedLevel L
       const int ns = (int)sh_ctr[4];
       const size_t strip_slot = (size_t)pyr * A.slots_per_pyr + L.slot0 + (size_t)s * (L.R >> 1) * L.nbx;
       const uint32_t add_xy = ((uint32_t)L.col0 << 12) | (uint32_t)L.row0;      // README.md:78
+      // ---- phase E: orbCompute (Orb.h:396-441) for this strip's keypoints, while the image rows they
+      // need (y-15 .. y+15: this strip's rows, the strip above and the rows prefetched for the strip below)
+      // are still in the L2 that just served them.  Descriptors go to the strip's staging slots in rank
+      // order (rank = position among the strip's keypoints); k_gather_orb moves them to their final place.
+      // LDS of this phase (all dead by now): [survivors | ranks | keep][8 patches][vrecpe table].
+      const bool orb = ORB && A.orb != 0;
+      auto describe_strip = [&](const int n, const uint32_t my_rank) {
+        lds_u8 *patches = (lds_u8 *)queues + NMS_SCRATCH * 4;
+        lds_u8 *rtab = patches + WAVES * 2 * ORB_PATCH_BYTES;
+        lds_barrier();                                // every thread has read the keys it ranks against
+        if (tid < n) shq_k[tid] = my_rank;            // (QS_SHARED <= NT: one survivor per thread)
+        rtab[tid] = ::g_vrecpe_tab.v[tid & 255];
+        lds_barrier();
+        const OrbLane G = orb_lane(lane, A.vstep);
+        lds_u8 *wave_patches = patches + wave * 2 * ORB_PATCH_BYTES;
+        uint32_t *dbase = stage_desc + ((size_t)pyr * A.strips_per_pyr + L.strip0 + s) * (size_t)(QS_SHARED * A.words);
+        for (int it = wave; 2 * it < n; it += WAVES) {
+          const int i0 = 2 * it, i1 = min(i0 + 1, n - 1);
+          const uint32_t r0 = shq_k[i0], r1 = i0 + 1 < n ? shq_k[i1] : 0xffffffffu;
+          const uint32_t p0 = r0 != 0xffffffffu ? shq_s[i0] + add_xy : 0u;
+          const uint32_t p1 = r1 != 0xffffffffu ? shq_s[i1] + add_xy : 0u;
+          if ((p0 | p1) == 0) continue;               // (bucket mode: both dropped)
+          const OrbWin w = orb_fetch(G, p0, p1, imb, A.vstep, img_bytes32);
+          orb_describe(G, w, p0, p1, wave_patches, A.vstep, (const lds_u8 *)rtab, A.words,
+                       dbase + (size_t)(G.half ? r1 : r0) * A.words);
+        }
+      };
       if (A.lbs == 0) {
+        uint32_t my_rank = 0;
         for (int i = tid; i < ns; i += NT) {
           const uint32_t key = shq_k[i];
           int rank = 0;
           for (int j = 0; j < ns; j++) rank += shq_k[j] < key;
           stage_kp[strip_slot + rank] = shq_s[i] + add_xy;
+          my_rank = (uint32_t)rank;
         }
-        if (tid == 0) strip_count[(size_t)pyr * A.strips_per_pyr + L.strip0 + s] = (uint32_t)ns;
+        if (tid == 0)
+          strip_count[(size_t)pyr * A.strips_per_pyr + L.strip0 + s] = (uint32_t)ns | (orb ? STRIP_DESCRIBED : 0u);
         mark(4);
+        if (orb && ns > 0) describe_strip(ns, my_rank);
         return;
       }
       // Buckets (Fast.h:314-352): a cell = one bucket x one flush interval = 2^lbs x 2^lbs pixels of
@@ -668,6 +862,7 @@ __device__ __forceinline__ void strip_body(const StripArgs A, const FusedLevel L
       }
       lds_barrier();
       int kept_here = 0;
+      uint32_t my_rank = 0xffffffffu;                 // (dropped by its cell's top-`limit`: not described)
       for (int i = tid; i < ns; i += NT) {
         if (!keep[i]) continue;
         const uint32_t v = shq_s[i], cell = shq_k[i];
@@ -675,11 +870,13 @@ __device__ __forceinline__ void strip_body(const StripArgs A, const FusedLevel L
         for (int j = 0; j < ns; j++)
           rank += keep[j] & ((shq_k[j] < cell) | ((shq_k[j] == cell) & (shq_s[j] < v)));
         stage_kp[strip_slot + rank] = v + add_xy;
+        my_rank = (uint32_t)rank;
         kept_here++;
       }
       if (kept_here) atomicAdd(&sh_ctr[5], (uint32_t)kept_here);
       lds_barrier();
-      if (tid == 0) strip_count[(size_t)pyr * A.strips_per_pyr + L.strip0 + s] = sh_ctr[5];
+      if (tid == 0) strip_count[(size_t)pyr * A.strips_per_pyr + L.strip0 + s] = sh_ctr[5] | (orb ? STRIP_DESCRIBED : 0u);
+      if (orb && ns > 0) describe_strip(ns, my_rank);
       return;
     }
   }
@@ -850,7 +1047,7 @@ __global__ __launch_bounds__(NT) void k_fused_strips(
     const FusedParams P, const uint8_t *__restrict__ pyramids, size_t pyr_stride,
     uint32_t *__restrict__ stage_kp, uint32_t *__restrict__ strip_count,
     uint8_t *__restrict__ score_dump, size_t score_stride, unsigned long long *__restrict__ prof,
-    uint32_t *__restrict__ ovf) {
+    uint32_t *__restrict__ ovf, uint32_t *__restrict__ stage_desc) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   __shared__ uint32_t sh_ctr[8];
   // XCD-aware mapping: workgroup b runs on XCD b%8; keep all strips of one pyramid on one XCD so
@@ -894,14 +1091,15 @@ __global__ __launch_bounds__(NT) void k_fused_strips(
     // bytes of this pyramid's buffer that may be read from the level's origin
     const ptrdiff_t lim = (ptrdiff_t)P.rows * P.vstep - ((ptrdiff_t)L.row0 * P.vstep + L.col0);
     StripArgs A{P.border, P.thr, P.ablate, P.dump_score, P.lbs, P.limit, P.vstep, P.slots_per_pyr,
-                P.strips_per_pyr, P.hthr};
+                P.strips_per_pyr, P.hthr, P.words, P.orb_in_strip};
     asm volatile("" : "+s"(A.border), "+s"(A.thr), "+s"(A.lbs), "+s"(A.limit), "+s"(A.vstep), "+s"(A.slots_per_pyr),
-                 "+s"(A.strips_per_pyr), "+s"(A.hthr));
+                 "+s"(A.strips_per_pyr), "+s"(A.hthr), "+s"(A.words), "+s"(A.orb));
     const int ys = A.border + s * L.R;              // first block-row y of the strip
     const int ye = min(ys + L.R, L.h - A.border);   // one past the last row owned
     strip_body<VEC16, HOOKS, ALIAS>(A, L, pyr, s, ys, ye, m.tile, m.sc, m.queues, m.shq, sh_ctr, im, lim, stage_kp,
                                     strip_count, score_dump, score_stride, carry, tid_o, prof, pf, pf_have, s + 1 < s1,
-                                    pf_have, ovf, ((uint32_t)pyr << 16) | (uint32_t)(L.strip0 + s));
+                                    pf_have, ovf, ((uint32_t)pyr << 16) | (uint32_t)(L.strip0 + s), stage_desc,
+                                    pyramids + (size_t)pyr * pyr_stride, (uint32_t)((size_t)P.rows * P.vstep));
     if (s + 1 < s1) {
       lds_barrier();                                // every read of this strip's LDS state is done
       // (a scan fallback scribbles over the tiles, a deferred strip leaves no scores: start afresh)
@@ -942,13 +1140,13 @@ __global__ __launch_bounds__(NT) void k_fused_overflow(
     const ptrdiff_t lim = (ptrdiff_t)P.rows * P.vstep - ((ptrdiff_t)L.row0 * P.vstep + L.col0);
     // (ablate bit 512 forces the ALIAS kernel to defer; here it would force the scan fallbacks too — keep it)
     const StripArgs A{P.border, P.thr, P.ablate, P.dump_score, P.lbs, P.limit, P.vstep, P.slots_per_pyr,
-                      P.strips_per_pyr, P.hthr};
+                      P.strips_per_pyr, P.hthr, P.words, 0};
     const int ys = A.border + s * L.R;
     const int ye = min(ys + L.R, L.h - A.border);
     bool issued = false;
     strip_body<VEC16, HOOKS, false>(A, L, pyr_o, s, ys, ye, m.tile, m.sc, m.queues, m.shq, sh_ctr, im, lim, stage_kp,
                                     strip_count, score_dump, score_stride, false, tid_o, nullptr, pf, false, false, issued,
-                                    nullptr, 0u);
+                                    nullptr, 0u, nullptr, nullptr, 0u);
     lds_barrier();
   }
 }
@@ -977,7 +1175,7 @@ __global__ __launch_bounds__(256) void k_gather(const FusedParams P,
   __syncthreads();
   for (int base = 0; base < S; base += 256) {
     const int i = base + tid;
-    const uint32_t v = i < S ? cnt[i] : 0;
+    const uint32_t v = i < S ? (cnt[i] & 0x7fffffffu) : 0;     // (bit 31: STRIP_DESCRIBED, irrelevant here)
     uint32_t incl = v;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
@@ -1015,44 +1213,28 @@ __global__ __launch_bounds__(256) void k_gather(const FusedParams P,
 
 
 // ===========================================================================
-// k_gather_orb — strip offsets -> final keypoint order, then orbCompute on them.
+// k_gather_orb — strip offsets -> final keypoint order; descriptors copied from the strips' staging slots,
+// or computed here for the strips that could not describe their own keypoints.
 //
 // grid (NCH, batch): workgroup (ch, pyr) owns keypoints [ch*per, (ch+1)*per) of pyramid pyr.
-// Every workgroup redoes the (tiny) exclusive scan of the pyramid's strip counts, pulls its
-// range of keypoints out of the strip staging buffer into LDS (and writes them to the final
-// keypoint array), then describes them, TWO keypoints per wave iteration (one per half-wave):
-//   lane r of a half owns patch row dy = r-15: 9 dword loads + v_alignbyte funnel shift give the
-//   32 bytes x-15..x+16 dword-aligned; the circle mask (Orb.h:118-121,163-286) is a per-lane
-//   constant; the moments are v_dot4_u32_u8 dot products with the |dx| weights (Orb.h:123-126);
-//   the rows are summed across the 32 lanes; every lane evaluates the angle bin (Orb.h:310-387);
-//   the aligned rows are parked in LDS and the 256 BRIEF tests (Brief.h:52) read them back,
-//   32 pairs per half-wave per round, one ballot = one descriptor word for each keypoint.
+// Every workgroup redoes the (tiny) exclusive scan of the pyramid's strip counts, pulls its range of
+// keypoints out of the strip staging buffer (one thread per keypoint, strip found by binary search), writes
+// them to the final keypoint array, and
+//   - copies the descriptor of every keypoint whose strip described it (strip count bit 31, see strip_body
+//     phase E) from the strip's descriptor slots to its final position;
+//   - describes the others (overflow strips, separate-tile layout) itself: orb_fetch / orb_describe, two
+//     keypoints per wave iteration, the next pair's loads in flight while the current pair is processed.
 // ===========================================================================
-constexpr int OWAVES = 4;                           // waves per k_gather_orb workgroup
-constexpr int ORB_PITCH = 48;                       // one 48-byte (3 x 16 B) window per patch row
-constexpr int ORB_PATCH_BYTES = 32 * ORB_PITCH + 16;   // 31 rows (+1 idle) + slack for the byte shift
-
-// Sum over each 32-lane half of the wave, result in every lane of that half.  DPP row shifts
-// (zero fill) leave each 16-lane row's sum in its last lane, row_bcast:15 folds row 0 into row 1 and
-// row 2 into row 3, two v_readlane pick the totals up.
-__device__ __forceinline__ int half_sum(int v, int half) {
-  v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);   // row_shr:1
-  v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);   // row_shr:2
-  v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);   // row_shr:4
-  v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);   // row_shr:8
-  v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);  // row_bcast:15 into rows 1 and 3
-  const int s0 = __builtin_amdgcn_readlane(v, 31), s1 = __builtin_amdgcn_readlane(v, 63);
-  return half ? s1 : s0;
-}
-
 __global__ __launch_bounds__(256) void k_gather_orb(
     const FusedParams P, const uint8_t *__restrict__ pyramids, size_t pyr_stride,
     const uint32_t *__restrict__ stage_kp, const uint32_t *__restrict__ strip_count,
+    const uint32_t *__restrict__ stage_desc,
     uint32_t *__restrict__ kp, size_t kp_stride, uint32_t cap, uint32_t *__restrict__ counts,
-    uint32_t *__restrict__ desc, size_t desc_stride, int words, uint32_t *__restrict__ ovf_reset) {
+    uint32_t *__restrict__ desc, size_t desc_stride, int words, uint32_t per_max, uint32_t *__restrict__ ovf_reset) {
   extern __shared__ __attribute__((aligned(16))) uint8_t osm[];
   __shared__ uint32_t wsum[4];
   __shared__ uint32_t carry;
+  __shared__ uint32_t ntodo;
   __shared__ uint8_t sh_rtab[256];                  // vrecpe estimate table (256 threads: one entry each)
   sh_rtab[threadIdx.x] = ::g_vrecpe_tab.v[threadIdx.x];
   const lds_u8 *rtab = (const lds_u8 *)sh_rtab;
@@ -1065,19 +1247,25 @@ __global__ __launch_bounds__(256) void k_gather_orb(
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int S = P.strips_per_pyr;
-  // LDS carve: patches (4 waves x 2 x 1 KiB) | strip offsets (S+1) | this chunk's keypoints
+  // LDS carve: patches (4 waves x 2 x 1.5 KiB) | strip offsets (S+1) | staging slot base of every strip (S) |
+  // this chunk's keypoints | their descriptor staging index (bit 31: described) | indices still to describe
   uint8_t *patches = osm;
   uint32_t *soff = (uint32_t *)(osm + OWAVES * 2 * ORB_PATCH_BYTES);
-  uint32_t *sslot = soff + ((S + 1 + 3) & ~3);       // staging slot base of every strip
+  uint32_t *sslot = soff + ((S + 1 + 3) & ~3);
   uint32_t *kpl = sslot + ((S + 3) & ~3);
+  uint32_t *ksrc = kpl + per_max;
+  uint32_t *todo = ksrc + per_max;
 
   // ---- exclusive scan of the strip counts (strip order = reference push_back order) ----
   const uint32_t *cnt = strip_count + (size_t)pyr * S;
-  if (tid == 0) carry = 0;
+  if (tid == 0) {
+    carry = 0;
+    ntodo = 0;
+  }
   __syncthreads();
   for (int base = 0; base < S; base += 256) {
     const int i = base + tid;
-    const uint32_t v = i < S ? cnt[i] : 0;
+    const uint32_t v = i < S ? (cnt[i] & ~STRIP_DESCRIBED) : 0;
     uint32_t incl = v;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
@@ -1105,7 +1293,7 @@ __global__ __launch_bounds__(256) void k_gather_orb(
   }
   __syncthreads();
   const uint32_t nkp = min(total, cap);
-  const uint32_t per = (nkp + nch - 1) / nch;        // <= ceil(cap / nch): the size kpl was carved for
+  const uint32_t per = (nkp + nch - 1) / nch;        // <= ceil(cap / nch) = per_max: the size kpl was carved for
   const uint32_t lo = min((uint32_t)ch * per, nkp), hi = min(lo + per, nkp);
   if (lo >= hi) return;
 
@@ -1117,167 +1305,57 @@ __global__ __launch_bounds__(256) void k_gather_orb(
       const int m = (a + b) >> 1;
       if (soff[m] <= pos) a = m; else b = m;
     }
-    const uint32_t v = stage_kp[(size_t)pyr * P.slots_per_pyr + sslot[a] + (pos - soff[a])];
+    const uint32_t k = pos - soff[a];
+    const uint32_t v = stage_kp[(size_t)pyr * P.slots_per_pyr + sslot[a] + k];
     kpl[pos - lo] = v;
     kp[(size_t)pyr * kp_stride + pos] = v;
+    const bool described = (cnt[a] & STRIP_DESCRIBED) != 0;
+    ksrc[pos - lo] = described ? (STRIP_DESCRIBED | ((uint32_t)a * QS_SHARED + k)) : 0u;
+    if (!described) todo[atomicAdd(&ntodo, 1u)] = pos - lo;     // (order irrelevant: results are positional)
   }
   __syncthreads();
-
-  // ---- describe: two keypoints per wave iteration ----
-  const uint8_t *im = pyramids + (size_t)pyr * pyr_stride;
-  const ptrdiff_t img_bytes = (ptrdiff_t)P.rows * P.vstep;
-  const int vstep = P.vstep;
-  const int half = lane >> 5, r = lane & 31;          // r = patch row index, dy = r - 15 (r = 31 idle)
-  const int dy = r - 15;
-  // per-lane circle mask for its row: byte j of the 32 covers dx = j - 15
-  uint32_t cmask[8];
-  {
-    const int u = (r < 31) ? patch_umax(dy < 0 ? -dy : dy) : -1;
-#pragma unroll
-    for (int k = 0; k < 8; k++) {
-      uint32_t m = 0;
-#pragma unroll
-      for (int b = 0; b < 4; b++) {
-        const int dx = 4 * k + b - 15, adx = dx < 0 ? -dx : dx;
-        if (adx <= u) m |= 0xffu << (8 * b);
-      }
-      cmask[k] = m;
-    }
-  }
-  uint8_t *patch = patches + (wv * 2 + half) * ORB_PATCH_BYTES;
   uint32_t *dsc = desc + (size_t)pyr * desc_stride;
-  const uint32_t npairs = (hi - lo + 1) >> 1;
-  // Each patch row needs the 48-byte window [a16, a16+48) covering its 32 bytes x-15..x+16.  The L1
-  // processes a divergent load at about one distinct cache line per cycle, so the loads are laid out
-  // for coalescing: slot = lane + 64 j  ->  (keypoint half, row, 16-byte chunk) with the three chunks
-  // of a row in ADJACENT lanes (one or two lines per row instead of three requests).  Each lane
-  // parks its chunk in the LDS patch; the moments then read whole rows back (lane = row).
-  // vstep % 16 == 0 makes the byte shift row-independent.  The loads of the NEXT pair are issued
-  // before the current pair is processed (software prefetch).
-  struct Win {
-    uint4 w[3];
-  };
-  // loop-invariant slot geometry of this lane: slot j -> keypoint half, byte offset of its 16-byte
-  // chunk relative to the patch origin (y-15, x-15), and where it is parked in the LDS patch
-  int sl_h[3], sl_park[3];
-  ptrdiff_t sl_rel[3];
-  bool sl_on[3];
-#pragma unroll
-  for (int j = 0; j < 3; j++) {
-    const int slot = lane + 64 * j;                   // 0..191, 186 used
-    const int h = slot >= 93 ? 1 : 0, within = slot - 93 * h;
-    const int row = within / 3, chunk = within - 3 * row;
-    sl_h[j] = h;
-    sl_on[j] = slot < 186;
-    sl_rel[j] = (ptrdiff_t)row * vstep + 16 * chunk;
-    sl_park[j] = h * ORB_PATCH_BYTES + row * ORB_PITCH + 16 * chunk;
+  // ---- descriptors the strips already computed: one thread per (keypoint, word) ----
+  {
+    const uint32_t *sd = stage_desc + (size_t)pyr * S * QS_SHARED * words;
+    const uint32_t nw = (hi - lo) * (uint32_t)words;
+    for (uint32_t i = tid; i < nw; i += 256) {
+      const uint32_t k = i / (uint32_t)words, w = i - k * (uint32_t)words;
+      const uint32_t src = ksrc[k];
+      if (src & STRIP_DESCRIBED) dsc[(size_t)(lo + k) * words + w] = sd[(size_t)(src & ~STRIP_DESCRIBED) * words + w];
+    }
   }
+  const uint32_t nt = ntodo;
+  if (nt == 0 || (P.ablate & 64)) return;
+
+  // ---- describe the rest: two keypoints per wave iteration ----
+  const uint8_t *im = pyramids + (size_t)pyr * pyr_stride;
+  const uint32_t img_bytes32 = (uint32_t)((size_t)P.rows * P.vstep);
+  const int vstep = P.vstep;
+  const OrbLane G = orb_lane(lane, vstep);
   lds_u8 *wave_patches = (lds_u8 *)(patches + (wv * 2) * ORB_PATCH_BYTES);
-  const lds_u32 *kpl_l = (const lds_u32 *)kpl;
-  // the two keypoints of pair `it`: packed words (0 when absent)
-  auto pair_of = [&](uint32_t it, uint32_t &p0, uint32_t &p1) {
-    const uint32_t i0 = lo + 2 * it;
-    p0 = (it < npairs) ? kpl_l[i0 - lo] : 0u;
-    p1 = (it < npairs && i0 + 1 < hi) ? kpl_l[i0 + 1 - lo] : 0u;
-  };
-  // (32-bit byte offsets inside the pyramid: a pyramid is far below 2 GiB; a negative offset wraps to a
-  //  huge unsigned value and fails the single bounds test)
-  const uint32_t img_bytes32 = (uint32_t)img_bytes;
-  auto fetch = [&](uint32_t p0, uint32_t p1) {
-    Win f;
-    // byte offset of the patch origin (row y-15, column x-15) of either keypoint
-    const int org0 = (decode_y(p0) - 15) * vstep + (decode_x(p0) - 15);
-    const int org1 = (decode_y(p1) - 15) * vstep + (decode_x(p1) - 15);
-#pragma unroll
-    for (int j = 0; j < 3; j++) {
-      const int org = sl_h[j] ? org1 : org0;
-      // vstep % 16 == 0: row offsets keep the alignment.  A chunk that starts outside the pyramid (absent
-      // keypoint, idle slot, window slack past the last row) holds no byte any patch uses — the buffer
-      // size is a multiple of 16 — so it is simply clamped into the buffer instead of being zero-filled.
-      const uint32_t a = min((uint32_t)(org + (int)sl_rel[j]) & ~15u, img_bytes32 - 16u);
-      f.w[j] = *(const uint4 *)(im + a);
-    }
-    return f;
-  };
-  if (P.ablate & 64) return;                        // profiling only: prologue cost
-  lds_u8 *patch_l = wave_patches + half * ORB_PATCH_BYTES;
-  // one pair: park the fetched windows, moments, angle, BRIEF, store
-  auto describe = [&](const Win &cur, const uint32_t p0, const uint32_t p1, const uint32_t it) {
-    const uint32_t idx = lo + 2 * it + half;
-    const uint32_t pme = half ? p1 : p0;
-    const bool valid = pme != 0;
-    const int x = decode_x(pme), y = decode_y(pme);
-    const uint32_t sh = (uint32_t)(((ptrdiff_t)(y - 15) * vstep + (x - 15)) & 15);   // same for every row
-#pragma unroll
-    for (int j = 0; j < 3; j++)
-      if (sl_on[j]) *(lds_u4 *)(wave_patches + sl_park[j]) = (u32x4){cur.w[j].x, cur.w[j].y, cur.w[j].z, cur.w[j].w};
-    const lds_u8 *prow = patch_l + r * ORB_PITCH;
-    // read the row back aligned to the PATCH: 9 aligned dwords + v_alignbyte (byte-unaligned
-    // ds_read_b32 works on gfx950 but costs ~47 stall cycles each — SQ_LDS_UNALIGNED_STALL)
-    uint32_t row[8];
-    {
-      const lds_u8 *pa = prow + (sh & ~3u);
-      uint32_t in[9];
-#pragma unroll
-      for (int k = 0; k < 9; k++) in[k] = *(const lds_u32 *)(pa + 4 * k);
-#pragma unroll
-      for (int k = 0; k < 8; k++) row[k] = __builtin_amdgcn_alignbyte(in[k + 1], in[k], sh & 3u);
-    }
-    // moments of this row: sum v and sum |dx| v, left (dx<0) and right (dx>0) separately
-    uint32_t sv = 0, left = 0, right = 0;
-#pragma unroll
-    for (int k = 0; k < 8; k++) {
-      const uint32_t v = row[k] & cmask[k];
-      sv = __builtin_amdgcn_udot4(v, 0x01010101u, sv, false);
-    }
-    left = __builtin_amdgcn_udot4(row[0] & cmask[0], 0x0c0d0e0fu, left, false);    // dx -15..-12
-    left = __builtin_amdgcn_udot4(row[1] & cmask[1], 0x08090a0bu, left, false);    // dx -11..-8
-    left = __builtin_amdgcn_udot4(row[2] & cmask[2], 0x04050607u, left, false);    // dx  -7..-4
-    left = __builtin_amdgcn_udot4(row[3] & cmask[3], 0x00010203u, left, false);    // dx  -3..0
-    right = __builtin_amdgcn_udot4(row[4] & cmask[4], 0x04030201u, right, false);  // dx   1..4
-    right = __builtin_amdgcn_udot4(row[5] & cmask[5], 0x08070605u, right, false);  // dx   5..8
-    right = __builtin_amdgcn_udot4(row[6] & cmask[6], 0x0c0b0a09u, right, false);  // dx   9..12
-    right = __builtin_amdgcn_udot4(row[7] & cmask[7], 0x000f0e0du, right, false);  // dx  13..15 (16 masked)
-    const int m10 = half_sum((int)right - (int)left, half);
-    const int m01 = half_sum(dy * (int)sv, half);
-    const uint32_t rot = (P.ablate & 16384) ? 0u                          // (profiling only)
-                                             : angle_bin_with(m10, m01, [&](float f) { return vrecpe_f32_tab(f, rtab); });
-    if (P.ablate & 32768) {                          // profiling only: no BRIEF
-      if (valid && r < words) dsc[(size_t)idx * words + r] = rot + sv;
-      return;
-    }
-    // BRIEF: pair k = 32*round + r of this half's keypoint -> bit r of word `round`
-    const uint32_t *tab = ::g_brief_ofs.v + rot * 256 + r;   // defined by the including TU
-    // the patch's byte (dy,dx) sits at (dy+15)*48 + sh + dx+15; sh is the same for every row
-    const lds_u8 *bp = patch_l + sh;
-    uint32_t myword = 0;
-    uint32_t ent[8];
-#pragma unroll
-    for (int round = 0; round < 8; round++) ent[round] = tab[32 * round];   // all 8 table loads in flight
-#pragma unroll
-    for (int round = 0; round < 8; round++) {
-      const uint32_t e = ent[round];
-      const uint32_t a = bp[e & 0xffffu], b = bp[e >> 16];
-      const uint64_t m = __ballot(a < b);                           // Brief.h:52
-      // lane `round` of either half keeps that half's word (v_writelane: rounds >= words are never stored)
-      const uint32_t w = half ? (uint32_t)(m >> 32) : (uint32_t)m;
-      if (r == round) myword = w;
-    }
-    if (valid && r < words) dsc[(size_t)idx * words + r] = myword;
+  const lds_u32 *kpl_l = (const lds_u32 *)kpl, *todo_l = (const lds_u32 *)todo;
+  const uint32_t npairs = (nt + 1) >> 1;
+  // the two keypoints of pair `it`: packed words (0 when absent) and their local indices
+  auto pair_of = [&](uint32_t it, uint32_t &p0, uint32_t &p1, uint32_t &i0, uint32_t &i1) {
+    i0 = (it < npairs) ? todo_l[2 * it] : 0u;
+    i1 = (it < npairs && 2 * it + 1 < nt) ? todo_l[2 * it + 1] : 0u;
+    p0 = (it < npairs) ? kpl_l[i0] : 0u;
+    p1 = (it < npairs && 2 * it + 1 < nt) ? kpl_l[i1] : 0u;
   };
   // Two register sets (A, B) in ping-pong: the loads of the next pair are in flight while the current one
   // is described, without copying 12 registers per iteration.
-  uint32_t a0, a1, b0, b1;
-  pair_of(wv, a0, a1);
-  Win wa = fetch(a0, a1), wb;
+  uint32_t a0, a1, b0, b1, ia0, ia1, ib0, ib1;
+  pair_of(wv, a0, a1, ia0, ia1);
+  OrbWin wa = orb_fetch(G, a0, a1, im, vstep, img_bytes32), wb;
   for (uint32_t it = wv; it < npairs; it += 2 * OWAVES) {
-    pair_of(it + OWAVES, b0, b1);
-    wb = fetch(b0, b1);
-    describe(wa, a0, a1, it);
+    pair_of(it + OWAVES, b0, b1, ib0, ib1);
+    wb = orb_fetch(G, b0, b1, im, vstep, img_bytes32);
+    orb_describe(G, wa, a0, a1, wave_patches, vstep, rtab, words, dsc + (size_t)(lo + (G.half ? ia1 : ia0)) * words);
     if (it + OWAVES >= npairs) break;
-    pair_of(it + 2 * OWAVES, a0, a1);
-    wa = fetch(a0, a1);
-    describe(wb, b0, b1, it + OWAVES);
+    pair_of(it + 2 * OWAVES, a0, a1, ia0, ia1);
+    wa = orb_fetch(G, a0, a1, im, vstep, img_bytes32);
+    orb_describe(G, wb, b0, b1, wave_patches, vstep, rtab, words, dsc + (size_t)(lo + (G.half ? ib1 : ib0)) * words);
   }
 }
 

