@@ -37,7 +37,7 @@ typedef __attribute__((address_space(3))) uint32_t lds_u32;
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));   // plain clang vector (uint4 is a class)
 typedef __attribute__((address_space(3))) u32x4 lds_u4;
 
-constexpr int MAX_LEVELS = 16;
+constexpr int MAX_LEVELS = 24;              // plan entries: levels, wide ones cut into x-tiles (see FusedLevel::gn)
 constexpr int WAVES = 4;               // waves per strip workgroup
 constexpr int NT = WAVES * 64;         // threads per strip workgroup
 constexpr int QCAP_G = 128;            // 4-pixel groups that passed the SAD prefilter (< 64 before a <= 64 push)
@@ -74,6 +74,15 @@ struct FusedLevel {
                      // fallbacks' survivor / per-cell buffers — larger only with narrow x-tiles)
   uint32_t vpr_recip; // ceil(2^32 / (tpitch/16)): row = umulhi(i, vpr_recip) for i < 2^16
   int st_dr, st_dv;  // staging step of a thread: NT / (tpitch/16) rows and NT % (tpitch/16) vectors
+  // A plan entry is a whole pyramid level, or one X-TILE of a wide level: a column range handled by its own
+  // workgroups like a level of its own (w / col0 describe the tile plus a halo of real image columns in place
+  // of the border), so that the LDS footprint — and with it the number of resident workgroups — does not grow
+  // with the level width.  Tiles classify and score a few columns beyond the blocks they own (the NMS of a
+  // boundary block reads its neighbours' scores), emit only the blocks whose origin lies in [ex0, ex1), and
+  // k_gather_orb merges the tiles' per-strip lists back into the level's block-raster order.
+  int ex0, ex1;      // block origins (entry-relative x) this entry emits: [ex0, ex1)   (whole level: [B, w-B))
+  int xscore;        // entry-relative x of the level's w-B: columns at / beyond it keep 0xff (Fast.h:172)
+  int gfirst, gn;    // the entries gfirst .. gfirst+gn-1 are the tiles of this entry's level (same R, nstrips)
 };
 
 struct FusedParams {
@@ -440,7 +449,7 @@ __device__ __forceinline__ void strip_body(const StripArgs A, const FusedLevel L
     //  both sides, so nearly every 64-lane batch needed the second pass and it was slower)
     if (valid) corner = fast9_mm(tile + (r + 3) * tpitch + x, tpitch, thr);
     // Fast.h:172: only x < w-B is scored; over-classified columns keep 0xff
-    const bool toh = corner && x < Lw - B;
+    const bool toh = corner && x < L.xscore;
     if (!ALIAS) {
       if (corner && !toh) sc[r * pitch + x] = 0xff;
       push_nonzero(corner && !toh, e);
@@ -753,13 +762,13 @@ __device__ __forceinline__ void strip_body(const StripArgs A, const FusedLevel L
     const int tn = (int)sh_ctr[ALIAS ? 0 : 2];
     const lds_u32 *nq = ALIAS ? shq_h : shq_n;      // ALIAS: the one queue; entries with score 0 are skipped
     const int own_rows = ye - ys;                   // owned score rows r = 1 .. own_rows
-    const int xlimq = Lw - B;
+    const int ex0q = L.ex0, ex1q = L.ex1;             // block origins this entry owns
     for (int c0 = wave * 64; c0 < tn; c0 += WAVES * 64) {
       const uint32_t e = nq[min(c0 + lane, tn - 1)];
       const bool valid = c0 + lane < tn && (!ALIAS || (e >> 24) != 0);
       const int x = e & 0xffff, r = (e >> 16) & 0xff;
       const int bx = B + ((x - B) & ~1), rb = 1 + ((r - 1) & ~1);   // block origin (column, score row)
-      const bool owned = valid && r >= 1 && r <= own_rows && bx < xlimq;
+      const bool owned = valid && r >= 1 && r <= own_rows && bx >= ex0q && bx < ex1q;
       uint32_t res = 0;
       if (owned) {
         const int cb = (bx - 1) & ~3;               // aligned dword holding column bx-1
@@ -889,16 +898,17 @@ __device__ __forceinline__ void strip_body(const StripArgs A, const FusedLevel L
   if (A.lbs != 0) {
     // Bucket mode: one wave per cell, top-`limit` by repeated wave-max over the cell's blocks.
     const int lbs = A.lbs, limit = A.limit, bs = 1 << lbs, hb = bs >> 1;
-    const int ncx = (Lw - 2 * B - 1) / bs + 1;                     // Fast.h:201 numBuckets
+    const int cx0 = (L.ex0 - B) >> lbs;                             // first bucket of this entry (x-tiles start on bucket boundaries)
+    const int ncx = (L.ex1 - B - 1) / bs + 1 - cx0;                 // Fast.h:201 numBuckets (of the owned column range)
     const int ncy = (ye - ys + bs - 1) / bs;
     const int ncell = ncx * ncy, nblk = hb * hb;
     const int capc = min(limit, nblk);                              // survivors a cell can keep
     lds_u32 *cellres = (lds_u32 *)tile0;                            // ncell x capc  (<= #blocks dwords)
     lds_u32 *cellcnt = cellres + ncell * capc;                      // ncell
     lds_u32 *cand = queues + wave * QCAP;                           // per-wave scratch: nblk <= 256 dwords
-    const int xlimc = Lw - B;
+    const int xlimc = L.ex1;
     for (int cell = wave; cell < ncell; cell += WAVES) {
-      const int cy = cell / ncx, cx = cell - cy * ncx;
+      const int cy = cell / ncx, cx = cx0 + (cell - cy * ncx);
       for (int i = lane; i < nblk; i += 64) {
         const int by = i / hb, bxi = i - by * hb;
         const int x = B + cx * bs + 2 * bxi, y = ys + cy * bs + 2 * by;
@@ -943,7 +953,7 @@ __device__ __forceinline__ void strip_body(const StripArgs A, const FusedLevel L
   // then (after a barrier) the rows are copied out back to back = block-raster order of the strip.
   __shared__ uint32_t rowcnt[64];
   const int nbr = (ye - ys + 1) >> 1;               // block rows in this strip
-  const int xlim = Lw - B;                         // block origins are x = B, B+2, ... < xlim
+  const int xlim = L.ex1, xfirst = L.ex0;          // block origins are x = xfirst, xfirst+2, ... < xlim
   const int nbx = L.nbx;
   lds_u32 *rowbuf = (lds_u32 *)tile0;               // nbr x nbx dwords <= R/2 * w/2 * 4 B < the tile
   // One lane looks at 4 score columns x 2 rows = two horizontally adjacent 2x2 blocks with two
@@ -968,13 +978,13 @@ __device__ __forceinline__ void strip_body(const StripArgs A, const FusedLevel L
       if (x0 + 2 < xlim) rb = nms_block_regs(b0, b1, b2, b3, x0 + 2, y);
     }
   };
-  const bool pairs = (B & 3) == 0;                  // block origins dword-aligned in pairs
+  const bool pairs = (xfirst & 3) == 0;             // block origins dword-aligned in pairs
   for (int br = wave; br < nbr; br += WAVES) {
     const lds_u8 *srow = sc + (2 * br + 1) * pitch;
     lds_u32 *rb_out = rowbuf + br * nbx;
     uint32_t cnt = 0;
     if (pairs) {
-      for (int x0 = B + 4 * lane; x0 - 4 * lane < xlim; x0 += 256) {
+      for (int x0 = xfirst + 4 * lane; x0 - 4 * lane < xlim; x0 += 256) {
         uint32_t ra, rb;
         nms_pair(srow, x0, ys + 2 * br, ra, rb);
         const uint64_t ma = __ballot(ra != 0), mb = __ballot(rb != 0);
@@ -989,7 +999,7 @@ __device__ __forceinline__ void strip_body(const StripArgs A, const FusedLevel L
       for (int bx0 = 0; bx0 < nbx; bx0 += 64) {
         const int bx = bx0 + lane;
         uint32_t res = 0;
-        if (bx < nbx) res = nms_block(srow + B + 2 * bx, pitch, B + 2 * bx, ys + 2 * br);
+        if (xfirst + 2 * bx < xlim) res = nms_block(srow + xfirst + 2 * bx, pitch, xfirst + 2 * bx, ys + 2 * br);
         const uint64_t m = __ballot(res != 0);
         if (res) rb_out[cnt + ballot_rank(m)] = res;
         cnt += __popcll(m);
@@ -1151,9 +1161,57 @@ __global__ __launch_bounds__(NT) void k_fused_overflow(
   }
 }
 
-// One workgroup per pyramid: exclusive scan of the strip counts in strip order (= level order,
-// then top-to-bottom = the reference's push_back order), copy staged keypoints to their final
-// positions, publish the total.
+// ---------------------------------------------------------------------------
+// From strip lists to the reference's keypoint order (both gather kernels).
+// Plan strips are stored entry-major (plan entry, then strip top to bottom); `soff` is the exclusive prefix of
+// their counts in that order.  For a whole-level entry that IS the reference's push_back order (level order,
+// block-raster inside a level, Fast.h:228-320).  A level cut into x-tiles (FusedLevel::gn > 1) emits, per
+// strip, one list per tile, each in block-raster order of its own columns; the level's order interleaves them
+// by block row (bucket mode: by cell row, Fast.h:211-226): tile t's keypoint of row-key r comes after every
+// keypoint of tiles < t with key <= r and of tiles > t with key < r.
+// ---------------------------------------------------------------------------
+struct PlanStrip {
+  int li;            // plan entry
+  int s;             // strip index inside the entry
+};
+__device__ __forceinline__ PlanStrip plan_strip(const FusedParams &P, int i) {
+  int li = 0;
+  while (li + 1 < P.nlevels && i >= P.lv[li + 1].strip0) li++;
+  return {li, i - P.lv[li].strip0};
+}
+__device__ __forceinline__ uint32_t strip_slot_of(const FusedParams &P, int li, int s) {
+  return (uint32_t)(P.lv[li].slot0 + s * (P.lv[li].R >> 1) * P.lv[li].nbx);
+}
+// final index (within the pyramid) of the k-th keypoint `v` of plan strip (li, s); soff in LDS or global,
+// stage = this pyramid's staging slots
+template <class OFF>
+__device__ __forceinline__ uint32_t final_position(const FusedParams &P, const OFF *soff, const uint32_t *__restrict__ stage,
+                                                   int li, int s, uint32_t k, uint32_t v) {
+  const int gn = P.lv[li].gn;
+  if (gn == 1) return soff[P.lv[li].strip0 + s] + k;
+  const int g0 = P.lv[li].gfirst;
+  const int shift = P.lbs ? P.lbs : 1;
+  const int r = (decode_y(v) - P.lv[li].row0 - P.border) >> shift;      // block row (cell row) inside the level
+  uint32_t pos = soff[P.lv[g0].strip0] + k;       // everything before this level ...
+  for (int t = 0; t < gn; t++) {
+    const int e = g0 + t, j = P.lv[e].strip0 + s;
+    pos += soff[j] - soff[P.lv[e].strip0];          // ... + the level's strips above this one (all tiles)
+    if (e == li) continue;
+    // keypoints of tile t's list that precede: row key < r, or == r when the tile lies to the left
+    const int lim = r + (e < li ? 1 : 0);
+    const uint32_t *list = stage + strip_slot_of(P, e, s);
+    uint32_t lo = 0, hi = soff[j + 1] - soff[j];
+    while (lo < hi) {
+      const uint32_t m = (lo + hi) >> 1;
+      if (((decode_y(list[m]) - P.lv[e].row0 - P.border) >> shift) < lim) lo = m + 1; else hi = m;
+    }
+    pos += lo;
+  }
+  return pos;
+}
+
+// One workgroup per pyramid: exclusive scan of the strip counts, copy staged keypoints to their final
+// positions, publish the total (layouts the fused gather + ORB kernel does not take: vstep % 16 != 0).
 __global__ __launch_bounds__(256) void k_gather(const FusedParams P,
                                                 const uint32_t *__restrict__ stage_kp,
                                                 const uint32_t *__restrict__ strip_count,
@@ -1175,7 +1233,7 @@ __global__ __launch_bounds__(256) void k_gather(const FusedParams P,
   __syncthreads();
   for (int base = 0; base < S; base += 256) {
     const int i = base + tid;
-    const uint32_t v = i < S ? (cnt[i] & 0x7fffffffu) : 0;     // (bit 31: STRIP_DESCRIBED, irrelevant here)
+    const uint32_t v = i < S ? (cnt[i] & ~STRIP_DESCRIBED) : 0;
     uint32_t incl = v;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
@@ -1196,34 +1254,33 @@ __global__ __launch_bounds__(256) void k_gather(const FusedParams P,
     counts[pyr] = carry;
   }
   __syncthreads();
+  const uint32_t *stage = stage_kp + (size_t)pyr * P.slots_per_pyr;
   // one wave per strip
   for (int st = wv; st < S; st += 4) {
     const uint32_t n = soff[st + 1] - soff[st];
     if (n == 0) continue;
-    int li = 0;
-    while (li + 1 < P.nlevels && st >= P.lv[li + 1].strip0) li++;
-    const FusedLevel &L = P.lv[li];
-    const size_t slot = (size_t)pyr * P.slots_per_pyr + L.slot0 + (size_t)(st - L.strip0) * (L.R >> 1) * L.nbx;
+    const PlanStrip ps = plan_strip(P, st);
+    const uint32_t *list = stage + strip_slot_of(P, ps.li, ps.s);
     for (uint32_t k = lane; k < n; k += 64) {
-      const uint32_t pos = soff[st] + k;
-      if (pos < cap) kp[(size_t)pyr * kp_stride + pos] = stage_kp[slot + k];
+      const uint32_t v = list[k];
+      const uint32_t pos = final_position(P, soff, stage, ps.li, ps.s, k, v);
+      if (pos < cap) kp[(size_t)pyr * kp_stride + pos] = v;
     }
   }
 }
 
-
 // ===========================================================================
-// k_gather_orb — strip offsets -> final keypoint order; descriptors copied from the strips' staging slots,
-// or computed here for the strips that could not describe their own keypoints.
+// k_gather_orb — strip lists -> final keypoint order; descriptors copied from the strips' staging slots,
+// or computed here for the strips that did not describe their own keypoints.
 //
-// grid (NCH, batch): workgroup (ch, pyr) owns keypoints [ch*per, (ch+1)*per) of pyramid pyr.
-// Every workgroup redoes the (tiny) exclusive scan of the pyramid's strip counts, pulls its range of
-// keypoints out of the strip staging buffer (one thread per keypoint, strip found by binary search), writes
-// them to the final keypoint array, and
-//   - copies the descriptor of every keypoint whose strip described it (strip count bit 31, see strip_body
-//     phase E) from the strip's descriptor slots to its final position;
-//   - describes the others (overflow strips, separate-tile layout) itself: orb_fetch / orb_describe, two
-//     keypoints per wave iteration, the next pair's loads in flight while the current pair is processed.
+// grid (NCH, batch): workgroup (ch, pyr) owns the staged keypoints [ch*per, (ch+1)*per) of pyramid pyr in
+// storage order.  Every workgroup redoes the (tiny) exclusive scan of the pyramid's strip counts, then, per
+// keypoint (one thread each, its strip found by binary search): final position (final_position), keypoint
+// written there, and
+//   - the descriptor copied from the strip's descriptor slots when the strip described it (strip count
+//     bit 31, see strip_body phase E);
+//   - otherwise queued and described here: orb_fetch / orb_describe, two keypoints per wave iteration, the
+//     next pair's loads in flight while the current pair is processed.
 // ===========================================================================
 __global__ __launch_bounds__(256) void k_gather_orb(
     const FusedParams P, const uint8_t *__restrict__ pyramids, size_t pyr_stride,
@@ -1247,21 +1304,16 @@ __global__ __launch_bounds__(256) void k_gather_orb(
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int S = P.strips_per_pyr;
-  // LDS carve: patches (4 waves x 2 x 1.5 KiB) | strip offsets (S+1) | staging slot base of every strip (S) |
-  // this chunk's keypoints | their descriptor staging index (bit 31: described) | indices still to describe
+  // LDS carve: patches (4 waves x 2 x 1.5 KiB) | strip offsets (S+1) | this round's keypoints still to describe |
+  // their final positions
   uint8_t *patches = osm;
   uint32_t *soff = (uint32_t *)(osm + OWAVES * 2 * ORB_PATCH_BYTES);
-  uint32_t *sslot = soff + ((S + 1 + 3) & ~3);
-  uint32_t *kpl = sslot + ((S + 3) & ~3);
-  uint32_t *ksrc = kpl + per_max;
-  uint32_t *todo = ksrc + per_max;
+  uint32_t *kpl = soff + ((S + 1 + 3) & ~3);
+  uint32_t *kpos = kpl + per_max;
 
-  // ---- exclusive scan of the strip counts (strip order = reference push_back order) ----
+  // ---- exclusive scan of the strip counts (storage order) ----
   const uint32_t *cnt = strip_count + (size_t)pyr * S;
-  if (tid == 0) {
-    carry = 0;
-    ntodo = 0;
-  }
+  if (tid == 0) carry = 0;
   __syncthreads();
   for (int base = 0; base < S; base += 256) {
     const int i = base + tid;
@@ -1276,12 +1328,7 @@ __global__ __launch_bounds__(256) void k_gather_orb(
     __syncthreads();
     uint32_t pre = carry;
     for (int w = 0; w < wv; w++) pre += wsum[w];
-    if (i < S) {
-      soff[i] = pre + incl - v;
-      int li = 0;
-      while (li + 1 < P.nlevels && i >= P.lv[li + 1].strip0) li++;
-      sslot[i] = (uint32_t)(P.lv[li].slot0 + (i - P.lv[li].strip0) * (P.lv[li].R >> 1) * P.lv[li].nbx);
-    }
+    if (i < S) soff[i] = pre + incl - v;
     __syncthreads();
     if (tid == 255) carry = pre + incl;
     __syncthreads();
@@ -1292,70 +1339,75 @@ __global__ __launch_bounds__(256) void k_gather_orb(
     if (ch == 0) counts[pyr] = total;
   }
   __syncthreads();
-  const uint32_t nkp = min(total, cap);
-  const uint32_t per = (nkp + nch - 1) / nch;        // <= ceil(cap / nch) = per_max: the size kpl was carved for
-  const uint32_t lo = min((uint32_t)ch * per, nkp), hi = min(lo + per, nkp);
+  const uint32_t per = (total + nch - 1) / nch;
+  const uint32_t lo = min((uint32_t)ch * per, total), hi = min(lo + per, total);
   if (lo >= hi) return;
 
-  // ---- pull this chunk's keypoints out of the staging buffer: one thread per keypoint, its strip
-  // found by binary search in the strip offsets ----
-  for (uint32_t pos = lo + tid; pos < hi; pos += 256) {
-    int a = 0, b = S;                                  // largest st with soff[st] <= pos
-    while (b - a > 1) {
-      const int m = (a + b) >> 1;
-      if (soff[m] <= pos) a = m; else b = m;
-    }
-    const uint32_t k = pos - soff[a];
-    const uint32_t v = stage_kp[(size_t)pyr * P.slots_per_pyr + sslot[a] + k];
-    kpl[pos - lo] = v;
-    kp[(size_t)pyr * kp_stride + pos] = v;
-    const bool described = (cnt[a] & STRIP_DESCRIBED) != 0;
-    ksrc[pos - lo] = described ? (STRIP_DESCRIBED | ((uint32_t)a * QS_SHARED + k)) : 0u;
-    if (!described) todo[atomicAdd(&ntodo, 1u)] = pos - lo;     // (order irrelevant: results are positional)
-  }
-  __syncthreads();
+  const uint32_t *stage = stage_kp + (size_t)pyr * P.slots_per_pyr;
+  const uint32_t *sd = stage_desc + (size_t)pyr * S * QS_SHARED * words;
   uint32_t *dsc = desc + (size_t)pyr * desc_stride;
-  // ---- descriptors the strips already computed: one thread per (keypoint, word) ----
-  {
-    const uint32_t *sd = stage_desc + (size_t)pyr * S * QS_SHARED * words;
-    const uint32_t nw = (hi - lo) * (uint32_t)words;
-    for (uint32_t i = tid; i < nw; i += 256) {
-      const uint32_t k = i / (uint32_t)words, w = i - k * (uint32_t)words;
-      const uint32_t src = ksrc[k];
-      if (src & STRIP_DESCRIBED) dsc[(size_t)(lo + k) * words + w] = sd[(size_t)(src & ~STRIP_DESCRIBED) * words + w];
-    }
-  }
-  const uint32_t nt = ntodo;
-  if (nt == 0 || (P.ablate & 64)) return;
-
-  // ---- describe the rest: two keypoints per wave iteration ----
   const uint8_t *im = pyramids + (size_t)pyr * pyr_stride;
   const uint32_t img_bytes32 = (uint32_t)((size_t)P.rows * P.vstep);
   const int vstep = P.vstep;
-  const OrbLane G = orb_lane(lane, vstep);
   lds_u8 *wave_patches = (lds_u8 *)(patches + (wv * 2) * ORB_PATCH_BYTES);
-  const lds_u32 *kpl_l = (const lds_u32 *)kpl, *todo_l = (const lds_u32 *)todo;
-  const uint32_t npairs = (nt + 1) >> 1;
-  // the two keypoints of pair `it`: packed words (0 when absent) and their local indices
-  auto pair_of = [&](uint32_t it, uint32_t &p0, uint32_t &p1, uint32_t &i0, uint32_t &i1) {
-    i0 = (it < npairs) ? todo_l[2 * it] : 0u;
-    i1 = (it < npairs && 2 * it + 1 < nt) ? todo_l[2 * it + 1] : 0u;
-    p0 = (it < npairs) ? kpl_l[i0] : 0u;
-    p1 = (it < npairs && 2 * it + 1 < nt) ? kpl_l[i1] : 0u;
-  };
-  // Two register sets (A, B) in ping-pong: the loads of the next pair are in flight while the current one
-  // is described, without copying 12 registers per iteration.
-  uint32_t a0, a1, b0, b1, ia0, ia1, ib0, ib1;
-  pair_of(wv, a0, a1, ia0, ia1);
-  OrbWin wa = orb_fetch(G, a0, a1, im, vstep, img_bytes32), wb;
-  for (uint32_t it = wv; it < npairs; it += 2 * OWAVES) {
-    pair_of(it + OWAVES, b0, b1, ib0, ib1);
-    wb = orb_fetch(G, b0, b1, im, vstep, img_bytes32);
-    orb_describe(G, wa, a0, a1, wave_patches, vstep, rtab, words, dsc + (size_t)(lo + (G.half ? ia1 : ia0)) * words);
-    if (it + OWAVES >= npairs) break;
-    pair_of(it + 2 * OWAVES, a0, a1, ia0, ia1);
-    wa = orb_fetch(G, a0, a1, im, vstep, img_bytes32);
-    orb_describe(G, wb, b0, b1, wave_patches, vstep, rtab, words, dsc + (size_t)(lo + (G.half ? ib1 : ib0)) * words);
+  const lds_u32 *kpl_l = (const lds_u32 *)kpl, *kpos_l = (const lds_u32 *)kpos;
+  // rounds of at most per_max keypoints (one round unless the pyramid holds more keypoints than max_keypoints)
+  for (uint32_t c0 = lo; c0 < hi; c0 += per_max) {
+    const uint32_t c1 = min(c0 + per_max, hi);
+    if (tid == 0) ntodo = 0;
+    __syncthreads();
+    // ---- one thread per staged keypoint: strip by binary search, final position, keypoint + descriptor ----
+    for (uint32_t e = c0 + tid; e < c1; e += 256) {
+      int a = 0, b = S;                                // largest strip index with soff[a] <= e
+      while (b - a > 1) {
+        const int m = (a + b) >> 1;
+        if (soff[m] <= e) a = m; else b = m;
+      }
+      const uint32_t k = e - soff[a];
+      const PlanStrip ps = plan_strip(P, a);
+      const uint32_t v = stage[strip_slot_of(P, ps.li, ps.s) + k];
+      const uint32_t pos = final_position(P, soff, stage, ps.li, ps.s, k, v);
+      if (pos >= cap) continue;                        // beyond the caller's capacity: counted, not stored
+      kp[(size_t)pyr * kp_stride + pos] = v;
+      if (cnt[a] & STRIP_DESCRIBED) {
+        const uint32_t *src = sd + ((size_t)a * QS_SHARED + k) * words;
+        for (int w = 0; w < words; w++) dsc[(size_t)pos * words + w] = src[w];
+      } else {
+        const uint32_t slot = atomicAdd(&ntodo, 1u);   // (order irrelevant: results are positional)
+        kpl[slot] = v;
+        kpos[slot] = pos;
+      }
+    }
+    __syncthreads();
+    const uint32_t nt = ntodo;
+    if (nt != 0 && !(P.ablate & 64)) {
+      // ---- describe the rest: two keypoints per wave iteration ----
+      const OrbLane G = orb_lane(lane, vstep);
+      const uint32_t npairs = (nt + 1) >> 1;
+      // the two keypoints of pair `it`: packed words (0 when absent) and their final positions
+      auto pair_of = [&](uint32_t it, uint32_t &p0, uint32_t &p1, uint32_t &q0, uint32_t &q1) {
+        const bool h0 = it < npairs, h1 = it < npairs && 2 * it + 1 < nt;
+        p0 = h0 ? kpl_l[2 * it] : 0u;
+        q0 = h0 ? kpos_l[2 * it] : 0u;
+        p1 = h1 ? kpl_l[2 * it + 1] : 0u;
+        q1 = h1 ? kpos_l[2 * it + 1] : 0u;
+      };
+      // Two register sets (A, B) in ping-pong: the loads of the next pair are in flight while the current one
+      // is described, without copying 12 registers per iteration.
+      uint32_t a0, a1, b0, b1, qa0, qa1, qb0, qb1;
+      pair_of(wv, a0, a1, qa0, qa1);
+      OrbWin wa = orb_fetch(G, a0, a1, im, vstep, img_bytes32), wb;
+      for (uint32_t it = wv; it < npairs; it += 2 * OWAVES) {
+        pair_of(it + OWAVES, b0, b1, qb0, qb1);
+        wb = orb_fetch(G, b0, b1, im, vstep, img_bytes32);
+        orb_describe(G, wa, a0, a1, wave_patches, vstep, rtab, words, dsc + (size_t)(G.half ? qa1 : qa0) * words);
+        if (it + OWAVES >= npairs) break;
+        pair_of(it + 2 * OWAVES, a0, a1, qa0, qa1);
+        wa = orb_fetch(G, a0, a1, im, vstep, img_bytes32);
+        orb_describe(G, wb, b0, b1, wave_patches, vstep, rtab, words, dsc + (size_t)(G.half ? qb1 : qb0) * words);
+      }
+    }
+    __syncthreads();                                  // kpl / kpos / todo are reused by the next round
   }
 }
 

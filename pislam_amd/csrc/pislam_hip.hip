@@ -105,6 +105,7 @@ struct pislam_ctx {
   int opt_xtile_cols = 0;    // fused pipeline: max classified columns per image x-tile (0 = full width)
   int opt_lds_pad = 0;       // profiling only: extra dynamic LDS bytes per strip workgroup
   int opt_wgs_per_cu = 0;    // fused pipeline: if > 0, size strip heights for this many workgroups per CU
+  int opt_tile_cols = 0;     // fused pipeline: levels with more classified columns are cut into x-tiles (0 = 704, < 0 = never)
   int opt_orb_in_strip = 0;  // fused pipeline: 1 = strips describe their own keypoints (measured slower: DESIGN.md §8), 0 = k_gather_orb describes all
   int opt_dist_rccl_single = 0;   // test hook: pislam_dist_init(world = 1) still creates a (1-rank) RCCL communicator
   int last_pipeline = 0;
@@ -421,6 +422,9 @@ PISLAM_EXPORT int pislam_ctx_set_option(pislam_ctx *c, const char *key, int valu
   } else if (!strcmp(key, "wgs_per_cu")) {
     if (value < 0 || value > 8) return fail(c, PISLAM_ERR_INVALID, "wgs_per_cu must be 0..8");
     c->opt_wgs_per_cu = value;
+  } else if (!strcmp(key, "tile_cols")) {
+    if (value > 0 && value < 64) return fail(c, PISLAM_ERR_INVALID, "tile_cols must be 0 (default), < 0 (never) or >= 64");
+    c->opt_tile_cols = value;
   } else if (!strcmp(key, "orb_in_strip")) {
     c->opt_orb_in_strip = value != 0;
   } else if (!strcmp(key, "dist_rccl_single")) {
@@ -886,7 +890,6 @@ bool build_fused_plan(const pislam_ctx *c, const pislam_frontend_params *p, cons
                       int batch, pf::FusedParams *F, size_t *lds_bytes, size_t *lds_alias_bytes) {
   if (p->nlevels > pf::MAX_LEVELS) return false;
   memset(F, 0, sizeof(*F));
-  F->nlevels = p->nlevels;
   F->vstep = p->vstep;
   F->rows = p->rows;
   F->border = p->border;
@@ -903,12 +906,80 @@ bool build_fused_plan(const pislam_ctx *c, const pislam_frontend_params *p, cons
   F->ablate = c->opt_ablate;
   int strips = 0, slots = 0, runs = 0;
   size_t lds = 0, lds_alias = 0;
-  for (int l = 0; l < p->nlevels; l++) {
+  // ALIAS layout, heuristic strip height for a level under a residency target of `wgs` workgroups per CU:
+  // ~16k pixels per strip, 16..28 rows, capped so that queues + tile + the minimum shared queue fit
+  // 160 KiB / wgs where 16 rows allow it (VGA at 5 per CU: 24 rows at level 0, 28 below; measured 0.293 ms
+  // vs 0.311 ms with 16-row strips).
+  auto alias_rows = [&](int xend_l, int w, int wgs) -> int {
+    const int tpitch_l = (xend_l - p->border + ((p->border - 4) & 15) + 4 + 8 + 15) & ~15;
+    const long budget = 160 * 1024 / wgs - (long)(pf::WAVES * pf::QCAP + pf::QH_SHARED) * 4;
+    const int rcap = (int)(budget / tpitch_l - 10) & ~1;
+    if (wgs != 5 && rcap < 10) return 0;              // (an explicit residency request falls back to the generic rule)
+    return std::max(16, std::min(std::min(28, std::max(16, (16384 / w) & ~1)), rcap));
+  };
+  // Residency target of the heuristic: 5 workgroups per CU.  (A search over 5 / 4 / 3 per CU with a cost model
+  // "pixels * (R + 4) / R / measured throughput at that residency" was tried for the 1280-wide levels of BASELINE
+  // config 4 — 12-row strips at 4 per CU instead of 16 rows at 3 — and measured no better: 1.24 vs 1.21 ms at
+  // batch 256; forcing 5 per CU with 8-row strips and no halo carry gave 1.16 ms.  Option "wgs_per_cu" overrides.)
+  const int alias_wgs = c->opt_wgs_per_cu > 0 ? c->opt_wgs_per_cu : 5;
+  // Plan entries: a level, or the x-tiles of a wide level (pf::FusedLevel).  A level with more than `tile_max`
+  // classified columns is cut into tiles of T block-origin columns (T a multiple of 32: tiles start on
+  // bucket boundaries for every fused bucket size); tile t > 0 starts HALO = 32 columns to the left of its
+  // first block origin, so that, seen as a level of its own with the same border B, it classifies and scores
+  // the columns its boundary blocks' NMS reads, and every tile but the last ends 2 columns past its last
+  // owned block origin.
+  struct Entry {
+    int w, h, row0, col0, ex0, ex1, xscore, gfirst, gn, wmax;
+  };
+  std::vector<Entry> entries;
+  {
+    const int B = p->border, HALO = 32;
+    const int tile_max = c->opt_tile_cols > 0 ? c->opt_tile_cols : (c->opt_tile_cols < 0 ? 1 << 30 : 704);
+    for (int l = 0; l < p->nlevels; l++) {
+      const int w = lv[l].width, nx = w - 2 * B, ny = lv[l].height - 2 * B;
+      int nt = 1;
+      if (nx > 0 && ny > 0 && 16 * cdiv(nx, 16) > tile_max) nt = cdiv(nx, std::max(64, std::min(tile_max, 640)));
+      const int T = nt > 1 ? (cdiv(nx, nt) + 31) & ~31 : 0;
+      nt = nt > 1 ? cdiv(nx, T) : 1;
+      const int g0 = (int)entries.size();
+      int wmax = 0;
+      for (int t = 0; t < nt; t++) {
+        Entry e;
+        if (nt == 1) {
+          e = {w, lv[l].height, lv[l].row0, lv[l].col0, B, w - B, w - B, g0, 1, w};
+        } else {
+          const int o = t == 0 ? 0 : t * T - HALO;                 // level column of the entry's origin
+          const int E = std::min(B + (t + 1) * T, w - B);           // one past the last owned block origin (level x)
+          e.w = t == nt - 1 ? w - o : E - o + 2 + B;
+          e.h = lv[l].height;
+          e.row0 = lv[l].row0;
+          e.col0 = lv[l].col0 + o;
+          e.ex0 = t == 0 ? B : B + HALO;
+          e.ex1 = E - o;
+          e.xscore = (w - B) - o;
+          e.gfirst = g0;
+          e.gn = nt;
+        }
+        wmax = std::max(wmax, e.w);
+        entries.push_back(e);
+      }
+      for (int t = 0; t < nt; t++) entries[g0 + t].wmax = wmax;
+    }
+    if ((int)entries.size() > pf::MAX_LEVELS) return false;
+  }
+  F->nlevels = (int)entries.size();
+  for (int l = 0; l < F->nlevels; l++) {
     pf::FusedLevel &L = F->lv[l];
-    L.w = lv[l].width;
-    L.h = lv[l].height;
-    L.row0 = lv[l].row0;
-    L.col0 = lv[l].col0;
+    const Entry &en = entries[l];
+    L.w = en.w;
+    L.h = en.h;
+    L.row0 = en.row0;
+    L.col0 = en.col0;
+    L.ex0 = en.ex0;
+    L.ex1 = en.ex1;
+    L.xscore = en.xscore;
+    L.gfirst = en.gfirst;
+    L.gn = en.gn;
     const int nx = L.w - 2 * p->border, ny = L.h - 2 * p->border;
     L.strip0 = strips;
     L.slot0 = slots;
@@ -920,20 +991,14 @@ bool build_fused_plan(const pislam_ctx *c, const pislam_frontend_params *p, cons
       L.pitch = 16;
       continue;
     }
-    const int xend_l = p->border + 16 * cdiv(nx, 16), pitch_l = (xend_l + 4 + 15) & ~15;
+    // (the strip height comes from the widest tile of the level: all its tiles must cut the same strips)
+    const int nx_r = en.wmax - 2 * p->border;
+    const int xend_l = p->border + 16 * cdiv(nx_r, 16), pitch_l = (xend_l + 4 + 15) & ~15;
     const size_t qbytes = (pf::WAVES * pf::QCAP + pf::SHARED_Q) * sizeof(uint32_t);
     int R = c->opt_strip_rows;
-    if (R == 0 && c->opt_alias) {
-      // ~16k pixels per strip, 16..28 rows, capped so that 5 workgroups stay resident per CU with the
-      // ALIAS layout (VGA: 24 rows at level 0, 28 below; measured 0.293 ms vs 0.311 ms with 16-row strips)
-      R = std::min(28, std::max(16, (16384 / L.w) & ~1));
-      const int tpitch_l = (xend_l - p->border + ((p->border - 4) & 15) + 4 + 8 + 15) & ~15;
-      const long budget = 160 * 1024 / 5 - (long)(pf::WAVES * pf::QCAP + pf::QH_SHARED) * 4;
-      const int rcap = (int)(budget / tpitch_l - 10) & ~1;
-      R = std::max(16, std::min(R, rcap));
-    }
+    if (R == 0 && c->opt_alias) R = alias_rows(xend_l, en.wmax, alias_wgs);
     if (R == 0) {
-      R = (8192 / L.w) & ~1;             // ~8k pixels per strip ...
+      R = (8192 / en.wmax) & ~1;         // ~8k pixels per strip ...
       R = std::min(32, std::max(16, R));
       if (c->opt_wgs_per_cu > 0) {       // ... capped so that tiles + queues fit 160 KiB / wgs_per_cu
         const size_t budget = (size_t)(160 * 1024) / (size_t)c->opt_wgs_per_cu;
@@ -989,7 +1054,7 @@ bool build_fused_plan(const pislam_ctx *c, const pislam_frontend_params *p, cons
       // leaves under the 5-workgroups-per-CU budget (narrow levels of a textured photo are the dense ones)
       const long fixed = (long)pf::WAVES * pf::QCAP * 4 + L.apad + (long)(R + 10) * L.tpitch;
       // (margin of 1280 B: static LDS + allocation granule — with 512 B the kernel measurably lost its 5th workgroup)
-      const long spare = (160 * 1024 / 5 - 1280 - fixed) / 4;
+      const long spare = (160 * 1024 / alias_wgs - 1280 - fixed) / 4;
       L.qh = (int)std::min<long>(4096, std::max<long>(pf::QH_SHARED, spare & ~3L));
       lds_alias = std::max(lds_alias, (size_t)fixed + (size_t)L.qh * 4);
     }
@@ -1000,7 +1065,7 @@ bool build_fused_plan(const pislam_ctx *c, const pislam_frontend_params *p, cons
   F->run_len = c->opt_run_len > 0 ? c->opt_run_len
                                   : (int)std::min<long long>(8, std::max<long long>(1, (long long)strips * batch /
                                                                                       (12LL * std::max(1, c->num_cus))));
-  for (int l = 0; l < p->nlevels; l++) {
+  for (int l = 0; l < F->nlevels; l++) {
     F->lv[l].run0 = runs;
     F->lv[l].nruns = cdiv(F->lv[l].nstrips, F->run_len);
     runs += F->lv[l].nruns;
@@ -1128,8 +1193,7 @@ int run_fused(pislam_ctx *c, const pislam_frontend_params *p, const pf::FusedPar
   int nch = c->opt_orb_chunks > 0 ? c->opt_orb_chunks : std::min(64, std::max(16, 4096 / batch));
   const size_t per_max = ((size_t)p->max_keypoints + nch - 1) / nch;
   size_t olds = (size_t)pf::OWAVES * 2 * pf::ORB_PATCH_BYTES + sizeof(uint32_t) * (((size_t)F.strips_per_pyr + 1 + 3) & ~(size_t)3) +
-                sizeof(uint32_t) * (((size_t)F.strips_per_pyr + 3) & ~(size_t)3) +
-                sizeof(uint32_t) * 3 * per_max;        // keypoints, descriptor sources, to-describe list
+                sizeof(uint32_t) * 2 * per_max;        // keypoints to describe here and their final positions
   if (olds > 150 * 1024) return fail(c, PISLAM_ERR_INVALID, "max_keypoints too large for the fused ORB kernel");
   if (olds > 64 * 1024)
     HIPCHK(c, hipFuncSetAttribute((const void *)pf::k_gather_orb, hipFuncAttributeMaxDynamicSharedMemorySize, (int)olds));

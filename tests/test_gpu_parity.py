@@ -93,6 +93,46 @@ def test_batch_path_on_reference_demo_pyramid(gpu_ctx, demo, pipeline):
     assert c[0] == 1315 and sha16(kp.cpu().numpy().view(np.uint32)[0, :1315]) == SURVEY_PINS["kp_bucket43"]
 
 
+@pytest.mark.parametrize("tile_cols,alias,orb_in_strip", [(64, 1, 0), (128, 1, 1), (200, 0, 0), (320, 1, 0)])
+def test_x_tiles_as_work_items_reproduce_reference_order(gpu_ctx, demo, tile_cols, alias, orb_in_strip):
+    """Levels cut into x-tiles that separate workgroups process like levels of their own (option tile_cols; the
+    default cuts levels wider than 704 classified columns — BASELINE config 4): the tiles' per-strip lists must
+    merge back into the reference's block-raster order (Fast.h:228-320) / bucket flush order (Fast.h:211-226),
+    boundary blocks must see their neighbours' scores, and the right-edge 0xff columns (Fast.h:172) stay with
+    the last tile.  Checked on the reference's demo photo (SURVEY pins) and a dense variant (overflow pass)."""
+    import torch
+    from pislam_amd.frontend import OrbFrontend
+    from oracle import orc
+    img = demo["img"]
+    dev = torch.device("cuda:0")
+    noisy = (img.astype(np.int32) + np.random.default_rng(7).integers(-40, 41, img.shape)).clip(0, 255).astype(np.uint8)
+    pyr = torch.from_numpy(np.stack([img, noisy])).to(dev)
+    for k, v in dict(tile_cols=tile_cols, alias=alias, orb_in_strip=orb_in_strip).items():
+        gpu_ctx.set_option(k, v)
+    try:
+        for lbs, lim, n, pin in ((0, 5, 1754, "kp"), (4, 3, 1315, "kp_bucket43"), (5, 2, None, None), (2, 1, None, None)):
+            fe = OrbFrontend(demo["levels"], vstep=640, rows=2210, max_keypoints=16384, log_bucket_size=lbs,
+                             bucket_limit=lim, ctx=gpu_ctx)
+            kp, desc, counts = fe.alloc_outputs(2, dev)
+            fe(pyr, kp, desc, counts)
+            torch.cuda.synchronize()
+            c = counts.cpu().numpy().view(np.uint32)
+            k = kp.cpu().numpy().view(np.uint32)
+            d = desc.cpu().numpy().view(np.uint32)
+            if n is not None:
+                assert c[0] == n and sha16(k[0, :n]) == SURVEY_PINS[pin]
+                if lbs == 0:
+                    assert sha16(d[0, :n]) == SURVEY_PINS["desc"]
+            for b, im in enumerate((img, noisy)):
+                okp, odesc, _ = orc.pyramid(im, demo["levels"], log_bucket=lbs, bucket_limit=lim)
+                m = min(len(okp), 16384)
+                assert c[b] == len(okp), (b, lbs, c[b], len(okp))
+                assert (k[b, :m] == okp[:m]).all() and (d[b, :m] == odesc[:m]).all(), (b, lbs)
+    finally:
+        for k, v in dict(tile_cols=0, alias=1, orb_in_strip=0).items():
+            gpu_ctx.set_option(k, v)
+
+
 @pytest.mark.parametrize("orb_in_strip", [0, 1])
 def test_product_kernels_on_reference_demo_pyramid(gpu_ctx, demo, orb_in_strip):
     """The product instantiations (no debug hooks) with either ORB placement — one gather+ORB pass (default) or
