@@ -336,11 +336,10 @@ __device__ __forceinline__ uint32_t angle_bin_with(int32_t x, int32_t y, RECIP r
   const float t1 = __fadd_rn(c1, __fmul_rn(c2, z));
   const float t3 = __fmul_rn(__fsub_rn(z, 1.0f), t1);
   const float af = __fmul_rn(z, __fsub_rn(c0, t3));            // Orb.h:345
-  int32_t angle;                                               // vcvt.s32.f32, Orb.h:348
-  if (af != af) angle = 0;
-  else if (af >= 2147483648.0f) angle = INT32_MAX;
-  else if (af <= -2147483648.0f) angle = INT32_MIN;
-  else angle = (int32_t)af;
+  // vcvt.s32.f32 (Orb.h:348) truncates, saturates and maps NaN to 0 — exactly what v_cvt_i32_f32 does
+  // (CDNA ISA: "out-of-range values saturate, NaN is converted to 0"; the (0,0) padding slots reach it as NaN)
+  int32_t angle;
+  asm("v_cvt_i32_f32 %0, %1" : "=v"(angle) : "v"(af));
   const uint32_t ax = x < 0 ? 0u - (uint32_t)x : (uint32_t)x;
   const uint32_t ay = y < 0 ? 0u - (uint32_t)y : (uint32_t)y;
   if (ax > ay) {                                               // Orb.h:355-364

@@ -315,7 +315,7 @@ struct StripArgs {
 // bound kernel is measurably sensitive — does not grow with the level width.  Per x-tile: stage,
 // prefilter / pretest / FAST (scores of over-classified columns and corner queue), Harris for the
 // tile's corners.  NMS runs once per strip on the full-width score tile.
-template <bool VEC16, bool HOOKS, bool ALIAS>
+template <bool VEC16, bool HOOKS, bool ALIAS, bool ORBK>
 __device__ __forceinline__ void strip_body(const StripArgs A, const FusedLevel L, const int pyr, const int s,
                                            const int ys, const int ye, lds_u8 *tile0, lds_u8 *sc, lds_u32 *queues,
                                            lds_u32 *shq, uint32_t *sh_ctr, const uint8_t *__restrict__ im, const ptrdiff_t lim,
@@ -328,9 +328,10 @@ __device__ __forceinline__ void strip_body(const StripArgs A, const FusedLevel L
                                            uint32_t *__restrict__ stage_desc, const uint8_t *__restrict__ imb,
                                            const uint32_t img_bytes32) {
   const int B = A.border;
-  // Phase E exists in the ALIAS kernels on 16-byte aligned layouts (vstep % 16 == 0 makes a patch's byte
-  // shift row-independent); elsewhere k_gather_orb describes the keypoints.
-  constexpr bool ORB = ALIAS && VEC16;
+  // Phase E exists in the ORBK instantiations of the ALIAS kernels on 16-byte aligned layouts (vstep % 16 == 0
+  // makes a patch's byte shift row-independent; option "orb_in_strip"); elsewhere k_gather_orb describes the
+  // keypoints.  (Compiled out of the default kernels: its registers would cost them 10 VGPRs.)
+  constexpr bool ORB = ALIAS && VEC16 && ORBK;
   const int pitch = L.pitch, tpitch = L.tpitch;
   lds_u8 *tile = tile0;                             // re-based per x-tile: tile + row*tpitch + x with level column x
   int cxa = B, cxb = L.xend;                        // classified columns [cxa, cxb) of the current x-tile
@@ -672,6 +673,9 @@ __device__ __forceinline__ void strip_body(const StripArgs A, const FusedLevel L
         if (!(ablate & 16)) pretest_batch(true, qg[ng + lane]);
       }
     };
+    // (Unrolling the full steps so that their 256-byte strides become immediate DS offsets instead of three
+    //  pointer increments was tried: every copy of the step inlines the pretest / FAST batch code behind it,
+    //  4859 -> 6481 instructions for 3 VALU per step.)
     for (int r = r_lo + wave; r < r_hi; r += WAVES) {
       const lds_u8 *pc = tile + (r + 3) * tpitch + xs + 4 * lane;
       const lds_u8 *pu = pc - 3 * tpitch, *pd = pc + 3 * tpitch;
@@ -1052,7 +1056,7 @@ __device__ __forceinline__ StripLds strip_lds(uint8_t *smem, const FusedLevel &L
   return m;
 }
 
-template <bool VEC16, bool HOOKS, bool ALIAS>
+template <bool VEC16, bool HOOKS, bool ALIAS, bool ORBK = false>
 __global__ __launch_bounds__(NT) void k_fused_strips(
     const FusedParams P, const uint8_t *__restrict__ pyramids, size_t pyr_stride,
     uint32_t *__restrict__ stage_kp, uint32_t *__restrict__ strip_count,
@@ -1106,7 +1110,7 @@ __global__ __launch_bounds__(NT) void k_fused_strips(
                  "+s"(A.strips_per_pyr), "+s"(A.hthr), "+s"(A.words), "+s"(A.orb));
     const int ys = A.border + s * L.R;              // first block-row y of the strip
     const int ye = min(ys + L.R, L.h - A.border);   // one past the last row owned
-    strip_body<VEC16, HOOKS, ALIAS>(A, L, pyr, s, ys, ye, m.tile, m.sc, m.queues, m.shq, sh_ctr, im, lim, stage_kp,
+    strip_body<VEC16, HOOKS, ALIAS, ORBK>(A, L, pyr, s, ys, ye, m.tile, m.sc, m.queues, m.shq, sh_ctr, im, lim, stage_kp,
                                     strip_count, score_dump, score_stride, carry, tid_o, prof, pf, pf_have, s + 1 < s1,
                                     pf_have, ovf, ((uint32_t)pyr << 16) | (uint32_t)(L.strip0 + s), stage_desc,
                                     pyramids + (size_t)pyr * pyr_stride, (uint32_t)((size_t)P.rows * P.vstep));
@@ -1154,7 +1158,7 @@ __global__ __launch_bounds__(NT) void k_fused_overflow(
     const int ys = A.border + s * L.R;
     const int ye = min(ys + L.R, L.h - A.border);
     bool issued = false;
-    strip_body<VEC16, HOOKS, false>(A, L, pyr_o, s, ys, ye, m.tile, m.sc, m.queues, m.shq, sh_ctr, im, lim, stage_kp,
+    strip_body<VEC16, HOOKS, false, false>(A, L, pyr_o, s, ys, ye, m.tile, m.sc, m.queues, m.shq, sh_ctr, im, lim, stage_kp,
                                     strip_count, score_dump, score_stride, false, tid_o, nullptr, pf, false, false, issued,
                                     nullptr, 0u, nullptr, nullptr, 0u);
     lds_barrier();

@@ -1116,7 +1116,10 @@ int run_fused(pislam_ctx *c, const pislam_frontend_params *p, const pf::FusedPar
         pf::k_fused_strips<false, true, false>,  pf::k_fused_strips<false, true, true>,
         pf::k_fused_strips<true, false, false>,  pf::k_fused_strips<true, false, true>,
         pf::k_fused_strips<true, true, false>,   pf::k_fused_strips<true, true, true>};
-    const KernT kern = kerns[(vec ? 4 : 0) | (hooks ? 2 : 0) | (alias ? 1 : 0)];
+    // strips describing their own keypoints (option "orb_in_strip"): separate instantiations of the aligned ALIAS kernels
+    static const KernT kerns_orb[2] = {pf::k_fused_strips<true, false, true, true>, pf::k_fused_strips<true, true, true, true>};
+    const KernT kern = (F.orb_in_strip && vec && alias) ? kerns_orb[hooks ? 1 : 0]
+                                                        : kerns[(vec ? 4 : 0) | (hooks ? 2 : 0) | (alias ? 1 : 0)];
     const size_t klds = alias ? lds_alias : lds;
     if (klds > 150 * 1024) return fail(c, PISLAM_ERR_INVALID, "level too wide for the strip kernel's LDS tiles");
     if (klds > 64 * 1024)
