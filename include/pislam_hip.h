@@ -182,12 +182,18 @@ typedef struct pislam_frontend_params {
  * frame (blur != 0) or the frame itself.  pislam_pyramid_layout computes the level table of a vertically
  * stacked pyramid (dimensions round down, every level's slot keeps the padding rows its reduction
  * reads); pislam_pyramid_build_batch fills `batch` pyramids from `batch` device-resident frames.
- * The result equals running the reference functions level by level on a zero-initialised buffer. */
+ * Every byte a consumer reads — the levels, the whole output blocks of each reduction, the next reduction's
+ * block padding and FAST's right-edge columns (a margin of 32 columns / 16 rows around each level's
+ * rewritten rectangle, zeroed on every call) — equals running the reference functions level by level on a
+ * zero-initialised buffer; bytes beyond those margins are left untouched. */
 int pislam_pyramid_layout(int width, int height, int nlevels, const int32_t *steps, int vstep_min,
                           pislam_level *levels, int32_t *vstep, int32_t *rows);
+#define PISLAM_BUILD_BLUR 1          /* level 0 = gaussian5x5 of the frame (else the frame itself)              */
+#define PISLAM_BUILD_MARGINS_CLEAN 2 /* the margins are already zero: this function filled `pyramids` before with */
+                                     /* the same layout and nothing else wrote to it since — skip re-zeroing them */
 int pislam_pyramid_build_batch(pislam_ctx *ctx, int nlevels, const int32_t *steps, const pislam_level *levels,
                                const uint8_t *frames, int frame_vstep, size_t frame_stride, int batch,
-                               uint8_t *pyramids, int vstep, int rows, size_t pyramid_stride, int blur);
+                               uint8_t *pyramids, int vstep, int rows, size_t pyramid_stride, int flags);
 
 /* Runs, for every pyramid b in [0,batch) and every level l (in order), the
  * call sequence of reference demo/demo.cpp:77-101 / README.md:67-82:

@@ -778,7 +778,8 @@ PISLAM_EXPORT int pislam_pyramid_layout(int width, int height, int nlevels, cons
 PISLAM_EXPORT int pislam_pyramid_build_batch(pislam_ctx *c, int nlevels, const int32_t *steps,
                                              const pislam_level *levels, const uint8_t *frames, int frame_vstep,
                                              size_t frame_stride, int batch, uint8_t *pyramids, int vstep,
-                                             int rows, size_t pyramid_stride, int blur) {
+                                             int rows, size_t pyramid_stride, int flags) {
+  const bool blur = (flags & PISLAM_BUILD_BLUR) != 0;
   if (!c) return PISLAM_ERR_INVALID;
   if (!levels || !frames || !pyramids || batch <= 0 || nlevels < 1 || nlevels > 16 || (nlevels > 1 && !steps))
     return fail(c, PISLAM_ERR_INVALID, "bad argument");
@@ -800,16 +801,18 @@ PISLAM_EXPORT int pislam_pyramid_build_batch(pislam_ctx *c, int nlevels, const i
   if (levels[0].width > frame_vstep || frame_stride < (size_t)levels[0].height * frame_vstep)
     return fail(c, PISLAM_ERR_INVALID, "frame buffer too small");
   HIPCHK(c, hipSetDevice(c->device));
-  // Padding bytes are read by the bilinear steps and by FAST's right-edge columns: they are defined as
-  // zero.  Every build rewrites the same rectangle of each level's slot, so re-establishing that state
-  // means zeroing the complement of those rectangles — done on EVERY call (a caller may have scribbled
-  // over the buffer, or the allocator may hand out a recycled address), at the cost of the padding's size.
-  {
+  // Padding bytes are read by the bilinear steps (block padding) and by FAST's right-edge columns: they are
+  // defined as zero.  Every build rewrites the same rectangle of each level's slot and zeroes the margins
+  // around it that those consumers read (pp::k_zero_margins) — on EVERY call: a caller may have scribbled over
+  // the buffer, or the allocator may hand out a recycled address — unless the caller vouches for them
+  // (PISLAM_BUILD_MARGINS_CLEAN: a buffer this function filled before with the same layout and nobody wrote
+  // to since; the margin pass costs ~20 us per 64 720p frames).  Bytes beyond the margins are nobody's input
+  // and are left untouched (zero-initialise the buffer once if they must be defined).
+  if (!(flags & PISLAM_BUILD_MARGINS_CLEAN)) {
     pp::ZeroPlan Z;
     memset(&Z, 0, sizeof(Z));
     Z.nlevels = nlevels;
     Z.vstep = vstep;
-    Z.rows = rows;
     for (int l = 0; l < nlevels; l++) {
       Z.row0[l] = levels[l].row0;
       Z.slot_rows[l] = (l + 1 < nlevels ? levels[l + 1].row0 : rows) - levels[l].row0;
@@ -822,13 +825,8 @@ PISLAM_EXPORT int pislam_pyramid_build_batch(pislam_ctx *c, int nlevels, const i
         Z.wh[l] = (levels[l - 1].height + N - 1) / N * M;
       }
     }
-    if (levels[0].row0 > 0) {                         // rows above the first slot are never written
-      HIPCHK(c, hipMemset2DAsync(pyramids, pyramid_stride, 0, (size_t)levels[0].row0 * vstep, batch, c->stream));
-    }
-    const int vpr = (vstep + 15) / 16;
-    hipLaunchKernelGGL(pp::k_zero_outside, dim3(cdiv(rows * vpr, 256), batch), dim3(256), 0, c->stream, Z, pyramids,
-                       pyramid_stride);
-    PCHK(launch_ok(c, "k_zero_outside"));
+    hipLaunchKernelGGL(pp::k_zero_margins, dim3(2 * nlevels, batch), dim3(256), 0, c->stream, Z, pyramids, pyramid_stride);
+    PCHK(launch_ok(c, "k_zero_margins"));
   }
   const int w0 = levels[0].width, h0 = levels[0].height;
   if (blur) {
@@ -843,6 +841,10 @@ PISLAM_EXPORT int pislam_pyramid_build_batch(pislam_ctx *c, int nlevels, const i
       HIPCHK(c, hipMemcpy2DAsync(pyramids + b * pyramid_stride + (size_t)levels[0].row0 * vstep, vstep,
                                  frames + b * frame_stride, frame_vstep, w0, h0, hipMemcpyDeviceToDevice, c->stream));
   }
+  // (Fusing two chained reductions per launch — a 128-tile of level k maps onto whole blocks of 13/16 then 7/8,
+  //  level k+1 kept in LDS — was built and measured: 184 vs 167 us per 64 frames, 667 vs 584 us per 256.  The
+  //  64-frame pyramid set fits the 256 MiB Infinity Cache, so the re-read the fusion saves never reaches HBM,
+  //  and the LDS round trips cost more than k_bilinear4's register-only path.)
   for (int l = 0; l + 1 < nlevels; l++) {
     const uint8_t *src = pyramids + (size_t)levels[l].row0 * vstep;
     uint8_t *dst = pyramids + (size_t)levels[l + 1].row0 * vstep;

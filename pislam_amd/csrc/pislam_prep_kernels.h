@@ -245,33 +245,44 @@ __global__ __launch_bounds__(256) void k_bilinear(const uint8_t *__restrict__ sr
 }
 
 // ---------------------------------------------------------------------------
-// k_zero_outside — the pyramid builder's "padding is zero" state, re-established on every build:
-// level l's slot is rows [row0, row0 + slot_rows) of the buffer; the build rewrites its rectangle
-// [0, ww) x [0, wh) (level 0: the blurred frame; level l > 0: the whole M x M output blocks of the
-// reduction into it) and reads — bilinear padding (Bilinear.h:32,155), FAST's right-edge columns
-// (Fast.h:37-40) — bytes outside it, which are defined as zero.  One lane per 16-byte vector of a row;
-// vectors inside the rectangle are skipped, so the cost is the padding's size, not the buffer's.
+// k_zero_margins — the zero padding the pyramid's consumers read, re-established on every build.
+// The build rewrites, in level l's slot, the rectangle [0, ww) x [0, wh) (level 0: the blurred frame; level
+// l > 0: the whole M x M output blocks of the reduction into it).  What is read OUTSIDE it: the next
+// reduction's block padding (up to 15 columns / rows past the level, Bilinear.h:32,155) and FAST's right-edge
+// columns (Fast.h:37-40; up to 3 past the level, whole 16-byte vectors when staged).  So a margin of 32 columns
+// to the right (rows [0, hA)) and 16 rows below (columns [0, ww + 32)) is zeroed; bytes beyond the margins are
+// nobody's input and are left alone.  grid (2 * nlevels, batch): x = 2 l + {0: right, 1: bottom}; one workgroup
+// walks its rectangle.
 // ---------------------------------------------------------------------------
 struct ZeroPlan {
-  int nlevels, vstep, rows;
-  int row0[16], slot_rows[16], ww[16], wh[16];
+  int nlevels, vstep;
+  int row0[16], ww[16], wh[16], slot_rows[16];
 };
-__global__ __launch_bounds__(256) void k_zero_outside(const ZeroPlan Z, uint8_t *__restrict__ pyramids, size_t stride) {
-  const int vpr = (Z.vstep + 15) >> 4;
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  const int r = i / vpr, v = i - r * vpr;
-  if (r >= Z.rows) return;
-  int ww = 0;                                         // bytes of this row the build rewrites (0: none)
-  for (int l = 0; l < Z.nlevels; l++)
-    if (r >= Z.row0[l] && r < Z.row0[l] + Z.slot_rows[l]) ww = (r - Z.row0[l] < Z.wh[l]) ? Z.ww[l] : 0;
-  const int x0 = 16 * v, x1 = min(x0 + 16, Z.vstep);
-  if (x1 <= ww) return;
-  uint8_t *p = pyramids + (size_t)blockIdx.y * stride + (size_t)r * Z.vstep;
-  if (x0 >= ww && x1 == x0 + 16 && (((uintptr_t)(p + x0)) & 15) == 0) {
-    *(g_u32x4 *)(p + x0) = (g_u32x4)(0u);
+constexpr int ZM_COLS = 32, ZM_ROWS = 16;
+__global__ __launch_bounds__(256) void k_zero_margins(const ZeroPlan Z, uint8_t *__restrict__ pyramids, size_t stride) {
+  const int l = blockIdx.x >> 1, bottom = blockIdx.x & 1;
+  const int ww = Z.ww[l], wh = Z.wh[l];
+  const int rows_all = min(Z.slot_rows[l], wh + ZM_ROWS);
+  int x0, x1, r0, r1;                                 // the rectangle [x0, x1) x [r0, r1) inside the slot
+  if (!bottom) {
+    x0 = ww; x1 = min(Z.vstep, ww + ZM_COLS); r0 = 0; r1 = min(wh, rows_all);
   } else {
-    for (int x = max(x0, ww); x < x1; x++) p[x] = 0;
+    x0 = 0; x1 = min(Z.vstep, ww + ZM_COLS); r0 = min(wh, rows_all); r1 = rows_all;
+  }
+  if (x1 <= x0 || r1 <= r0) return;
+  const int v0 = x0 >> 4, nv = ((x1 + 15) >> 4) - v0;  // 16-byte vectors the rectangle touches per row
+  uint8_t *base = pyramids + (size_t)blockIdx.y * stride + (size_t)Z.row0[l] * Z.vstep;
+  for (int i = threadIdx.x; i < (r1 - r0) * nv; i += 256) {
+    const int r = r0 + i / nv, v = v0 + i % nv;
+    uint8_t *p = base + (size_t)r * Z.vstep;
+    const int a = max(16 * v, x0), b = min(16 * v + 16, x1);
+    if (a == 16 * v && b == 16 * v + 16 && (((uintptr_t)(p + a)) & 15) == 0) {
+      *(g_u32x4 *)(p + a) = (g_u32x4)(0u);
+    } else {
+      for (int x = a; x < b; x++) p[x] = 0;
+    }
   }
 }
+
 
 }  // namespace pp

@@ -250,13 +250,16 @@ class PyramidBuilder:
         self.vstep, self.rows, self.blur = vs.value, rows.value, bool(blur)
         self.levels = [(l.width, l.height, l.row0, l.col0) for l in self.levels_c]
 
-    def __call__(self, frames, pyramids):
+    def __call__(self, frames, pyramids, margins_clean: bool = False):
+        """margins_clean: the caller vouches that `pyramids` was last filled by this builder with this layout and
+        not written to since (PISLAM_BUILD_MARGINS_CLEAN) — the zero margins are then not re-established."""
         c = self.ctx
         batch = int(frames.shape[0])
+        flags = (1 if self.blur else 0) | (2 if margins_clean else 0)
         c.check(c.lib.pislam_pyramid_build_batch(c.h, self.nlevels, self.steps, self.levels_c, ptr(frames),
                                                  int(frames.shape[2]), int(frames.shape[1]) * int(frames.shape[2]),
                                                  batch, ptr(pyramids), self.vstep, self.rows, self.rows * self.vstep,
-                                                 int(self.blur)), "pislam_pyramid_build_batch")
+                                                 flags), "pislam_pyramid_build_batch")
 
 
 # ---- the measured path ---------------------------------------------------------

@@ -199,10 +199,14 @@ def test_random_pyramid_builds_match_the_oracle(gpu_ctx, orc):
         ran += 1
         batch = int(rng.integers(1, 4))
         frames = rng.integers(0, 256, (batch, h0, w0), dtype=np.uint8)
-        d_pyr = torch.empty((batch, pb.rows, pb.vstep), dtype=torch.uint8, device="cuda")
+        d_pyr = torch.full((batch, pb.rows, pb.vstep), 0x5C, dtype=torch.uint8, device="cuda")    # a dirty buffer
         pb(torch.from_numpy(frames).cuda(), d_pyr)
         torch.cuda.synchronize()
         got = d_pyr.cpu().numpy()
+        from test_prep import build_defined_mask
+        mask = build_defined_mask(pb, steps)
+        assert (got[:, ~mask] == 0x5C).all(), (t, w0, h0, steps)      # nothing outside the defined bytes is touched
+        got = np.where(mask[None], got, 0)
         for b in range(batch):
             exp = np.zeros((pb.rows, pb.vstep), np.uint8)
             w, h, r0, _ = pb.levels[0]

@@ -109,6 +109,23 @@ def test_bilinear_reference_test_matrix(gpu_ctx, orc):
         assert (d_out.cpu().numpy()[:480 * M // N, :640 * M // N] == exp[:480 * M // N, :640 * M // N]).all()
 
 
+def build_defined_mask(pb, steps):
+    """Bytes a pyramid build defines: per level the rectangle it rewrites (level 0: the frame; level l > 0: the whole
+    output blocks of the reduction into it) plus the zeroed margins its consumers read (32 columns to the right,
+    16 rows below — include/pislam_hip.h, pislam_pyramid_build_batch).  Everything else is left untouched."""
+    mask = np.zeros((pb.rows, pb.vstep), bool)
+    for l, (w, h, r0, _) in enumerate(pb.levels):
+        slot = (pb.levels[l + 1][2] if l + 1 < len(pb.levels) else pb.rows) - r0
+        if l == 0:
+            ww, wh = w, h
+        else:
+            N, M = (8, 7) if steps[l - 1] == 1 else (16, 13)
+            pw, ph = pb.levels[l - 1][0], pb.levels[l - 1][1]
+            ww, wh = -(-pw // N) * M, -(-ph // N) * M
+        mask[r0:r0 + min(slot, wh + 16), :min(pb.vstep, ww + 32)] = True
+    return mask
+
+
 @pytest.mark.gpu
 def test_pyramid_build_equals_reference_functions_in_sequence(gpu_ctx, orc):
     """config 5 builder: gaussian5x5 then the 13/16, 7/8 chain on a zeroed stacked buffer == the oracle
@@ -123,10 +140,21 @@ def test_pyramid_build_equals_reference_functions_in_sequence(gpu_ctx, orc):
         frames = np.stack([synth.make_level0(50 + i, w0, h0) if i else rng.integers(0, 256, (h0, w0), dtype=np.uint8)
                            for i in range(B)])
         d_fr = torch.from_numpy(frames).cuda()
-        d_pyr = torch.empty((B, pb.rows, pb.vstep), dtype=torch.uint8, device="cuda")
+        # a dirty buffer: the build must define everything its consumers read and leave the rest alone
+        d_pyr = torch.full((B, pb.rows, pb.vstep), 0xAB, dtype=torch.uint8, device="cuda")
         pb(d_fr, d_pyr)
         torch.cuda.synchronize()
         got = d_pyr.cpu().numpy()
+        mask = build_defined_mask(pb, steps)
+        assert (got[:, ~mask] == 0xAB).all()
+        # refill of the same buffer with the margins vouched for (PISLAM_BUILD_MARGINS_CLEAN): identical bytes
+        snap = d_pyr.clone()
+        d_pyr[:, :, :] = torch.where(torch.from_numpy(mask).cuda()[None], d_pyr, torch.zeros_like(d_pyr) + 0xCD)
+        lvl_only = torch.zeros_like(d_pyr, dtype=torch.bool)
+        pb(d_fr, d_pyr, margins_clean=True)
+        torch.cuda.synchronize()
+        assert torch.equal(torch.where(torch.from_numpy(mask).cuda()[None], d_pyr, snap), snap) and not lvl_only.any()
+        got = np.where(mask[None], got, 0)
         for b in range(B):
             exp = np.zeros((pb.rows, pb.vstep), np.uint8)
             w, h, r0, _ = pb.levels[0]
