@@ -69,6 +69,9 @@ def main():
                     help="distinct synthetic pyramids generated per GPU (0 = all of the batch)")
     ap.add_argument("--max-keypoints", type=int, default=0,
                     help="keypoint / descriptor capacity per pyramid (0 = 4096 for vga, 8192 for the larger workloads)")
+    ap.add_argument("--force-exchange", action="store_true",
+                    help="testing only (N=1): run the per-step count all-gather anyway, through a 1-rank RCCL communicator "
+                         "created by the C ABI (pislam_dist_*), so that the N>1 data path is exercised on a 1-GPU box")
     ap.add_argument("--selftest-spawn", action="store_true",
                     help="testing only: exercise launch + rendezvous + count exchange with fake counts on the CPU "
                          "(no GPU work, value is null)")
@@ -228,7 +231,13 @@ def main():
         rccl_err = pdist.init_rccl(ctx, rank, world, dev)
         if rccl_err and rank == 0:
             print(f"[bench] C-ABI RCCL path unavailable, using torch.distributed: {rccl_err}", file=sys.stderr)
-    xchg = pdist.CountExchange(world, ctx=ctx if (world > 1 and rccl_err is None) else None)
+    force = args.force_exchange and world == 1
+    if force:
+        from pislam_amd import capi
+        ctx.set_option("dist_rccl_single", 1)
+        ctx.dist_init(capi.dist_unique_id(), 0, 1)
+        outs.append(fe.alloc_outputs(B, dev))           # two output sets, as with N > 1
+    xchg = pdist.CountExchange(world, ctx=ctx if ((world > 1 and rccl_err is None) or force) else None, always_collective=force)
     nstep = [0]
 
     def launches(k_, d_, c_):

@@ -1,9 +1,11 @@
 // pislam/detail/Runtime.h — process-wide pislam_ctx used by the drop-in templates.
 //
-// The reference's functions are stateless free functions, so the wrappers keep
-// one lazily created context (current HIP device, null stream) and serialise
-// calls on it.  Errors from the C ABI become std::runtime_error (the reference
-// itself never reports errors; there is deliberately no CPU fallback).
+// The reference's functions are stateless, re-entrant free functions, so the
+// wrappers keep one lazily created context PER THREAD (current HIP device, a
+// stream of its own): calls from different threads run on different contexts
+// and streams and do not serialise each other; calls of one thread are ordered.
+// Errors from the C ABI become std::runtime_error (the reference itself never
+// reports errors; there is deliberately no CPU fallback).
 #ifndef PISLAM_DETAIL_RUNTIME_H_
 #define PISLAM_DETAIL_RUNTIME_H_
 
@@ -24,6 +26,7 @@ struct Runtime {
     if (rc != PISLAM_OK)
       throw std::runtime_error("pislam: no usable MI355X/HIP device (pislam_ctx_create = " +
                                std::to_string(rc) + ")");
+    (void)pislam_ctx_set_option(ctx, "own_stream", 1);   // not the (process-wide, synchronising) null stream
   }
   ~Runtime() {
     if (ctx) pislam_ctx_destroy(ctx);
@@ -33,7 +36,7 @@ struct Runtime {
 };
 
 inline Runtime &runtime() {
-  static Runtime r;
+  static thread_local Runtime r;
   return r;
 }
 

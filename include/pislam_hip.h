@@ -50,6 +50,7 @@ int pislam_ctx_destroy(pislam_ctx *ctx);
 /* hip_stream is a hipStream_t passed as void*; NULL = null stream. */
 int pislam_ctx_set_stream(pislam_ctx *ctx, void *hip_stream);
 /* Tuning / test hooks; results never depend on them.  Keys:
+ *   "own_stream" 1: issue on a non-blocking stream created (and destroyed) by the context instead of the null stream
  *   "pipeline"   0 auto, 1 staged (one launch group per reference call, HBM score map), 2 fused strips
  *   "dump_score" fused pipeline also materialises the score map (pislam_frontend_get_score_map)
  *   "strip_rows" fused strip height (0 = heuristic);  "run_len" strips per workgroup run (0 = by batch)

@@ -109,7 +109,7 @@ __device__ __forceinline__ void lds_barrier() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 
-constexpr int PF_MAX = 3;              // 16-byte vectors a thread can hold for the next strip's prefetch
+constexpr int PF_MAX = 4;              // 16-byte vectors a thread can hold for the next strip's prefetch
 
 // candidate coordinates packed as x | (tile_row << 16)
 __device__ __forceinline__ uint32_t pack_xy(int x, int r) { return (uint32_t)x | ((uint32_t)r << 16); }

@@ -84,6 +84,7 @@ struct pislam_dist_state;   // pislam_dist.inc
 struct pislam_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
+  hipStream_t own_stream = nullptr;    // option "own_stream": a non-blocking stream created and destroyed by the context
   pislam_dist_state *dist = nullptr;   // multi-GPU state (pislam_dist_init), nullptr for a single GPU
   std::string err;
   // staging for host-pointer calls
@@ -389,6 +390,7 @@ PISLAM_EXPORT int pislam_ctx_destroy(pislam_ctx *c) {
     b->release();
   for (auto &e : c->ev)
     if (e) (void)hipEventDestroy(e);
+  if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   delete c;
   return PISLAM_OK;
 }
@@ -399,11 +401,29 @@ PISLAM_EXPORT int pislam_ctx_set_stream(pislam_ctx *c, void *s) {
   return PISLAM_OK;
 }
 
+namespace {
+int use_own_stream(pislam_ctx *c, bool on) {
+  HIPCHK(c, hipSetDevice(c->device));
+  if (on) {
+    if (!c->own_stream) HIPCHK(c, hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
+    c->stream = c->own_stream;
+  } else if (c->own_stream) {
+    HIPCHK(c, hipStreamSynchronize(c->own_stream));
+    if (c->stream == c->own_stream) c->stream = nullptr;
+    HIPCHK(c, hipStreamDestroy(c->own_stream));
+    c->own_stream = nullptr;
+  }
+  return PISLAM_OK;
+}
+}  // namespace
+
 PISLAM_EXPORT int pislam_ctx_set_option(pislam_ctx *c, const char *key, int value) {
   if (!c || !key) return PISLAM_ERR_INVALID;
   if (!strcmp(key, "pipeline")) {
     if (value < 0 || value > 2) return fail(c, PISLAM_ERR_INVALID, "pipeline must be 0 (auto), 1 (staged) or 2 (fused)");
     c->opt_pipeline = value;
+  } else if (!strcmp(key, "own_stream")) {
+    return use_own_stream(c, value != 0);
   } else if (!strcmp(key, "dump_score")) {
     c->opt_dump_score = value != 0;
   } else if (!strcmp(key, "xtile_cols")) {

@@ -711,6 +711,28 @@ def test_count_exchange_through_the_c_abi(rccl):
         ctx.close()
 
 
+def test_bench_step_with_the_c_abi_exchange_on_one_rank():
+    """bench.py's N>1 step structure on this 1-GPU box: two output sets, hipGraph replays on the launch stream,
+    the count all-gather of every step through pislam_dist_* on the collective stream (a 1-rank RCCL
+    communicator), fences for buffer reuse — and the same keypoint totals as the plain run."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict({k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    res = []
+    for extra in ([], ["--force-exchange"]):
+        out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "7", "--warmup", "2", "--batch", "16",
+                              "--no-cpu-baseline", "--spin-s", "0.1"] + extra, capture_output=True, text=True, timeout=300,
+                             cwd=root, env=env)
+        assert out.returncode == 0, out.stderr[-2000:]
+        res.append(json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1]))
+    assert "C ABI" in res[1]["config"]["count_allgather"] and "none" in res[0]["config"]["count_allgather"]
+    assert res[0]["config"]["keypoints_per_pyramid"] == res[1]["config"]["keypoints_per_pyramid"] > 100
+    assert res[1]["config"]["launch"] == res[0]["config"]["launch"]
+
+
 def test_bench_self_launch_two_ranks_sharing_this_gpu():
     """Plain `python bench.py --gpus 2 --dist-backend gloo` (no torchrun environment): bench.py starts its two
     ranks itself and rank 0 reports n_gpus 2."""

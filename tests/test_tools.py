@@ -66,6 +66,20 @@ def test_cpp_tool_dropin_sequence_reproduces_reference_pins(tmp_path, demo_files
 
 
 @pytest.mark.gpu
+def test_cpp_tool_dropin_templates_from_several_threads(tmp_path, demo_files):
+    """The reference's functions are stateless and re-entrant; the drop-in templates keep one context and one
+    stream per thread (include/pislam/detail/Runtime.h), so concurrent callers neither serialise nor disturb
+    each other: 4 threads, identical results, the reference's pins."""
+    exe = build_tool()
+    out = tmp_path / "res.bin"
+    r = subprocess.run([exe, str(demo_files[0]), "--threads", "4", "--out", str(out)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, (r.stdout, r.stderr)
+    assert r.stdout.count("1754 features") == 4 and "4 threads agree" in r.stdout
+    kp, desc = read_result(out)
+    assert sha16(kp) == SURVEY_PINS["kp"] and sha16(desc) == SURVEY_PINS["desc"]
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("rccl", [False, True])
 def test_cpp_tool_batch_path_and_rccl_binding(tmp_path, demo_files, rccl):
     """The measured path from a C++ host: device-resident batch through pislam_orb_frontend_batch, the counts

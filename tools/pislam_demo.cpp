@@ -7,6 +7,9 @@
 //   pislam_demo <pyramid.raw|pyramid.pgm> [--buckets] [--out result.bin]
 //       the reference's call sequence through the pislam:: templates (host arrays, staged per call), with
 //       the wall time of every stage — the equivalent of demo.cpp's "CPU  Time" line (demo.cpp:113-114)
+//   ... --threads T
+//       the same call sequence from T host threads at once (the reference's functions are re-entrant; the
+//       drop-in templates keep one context + stream per thread): every thread must report the same result
 //   ... --batch N [--steps K]
 //       the measured path: N copies of the pyramid resident on the device, pislam_orb_frontend_batch
 //       K times, per-stage hipEvent times (pislam_frontend_last_timing)
@@ -29,6 +32,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "pislam/Fast.h"
@@ -42,7 +46,6 @@ struct Level { int width, height; };
 const Level kLevels[NLEVELS] = {{640, 480}, {533, 400}, {444, 333}, {370, 278}, {309, 231}, {257, 193}, {214, 161}, {179, 134}};
 
 uint8_t img[ROWS][IMG_W];
-uint8_t out[ROWS][IMG_W];
 
 double now_ms() {
   using namespace std::chrono;
@@ -104,8 +107,10 @@ void write_result(const char *path, const std::vector<uint32_t> &kp, const std::
   } while (0)
 
 // the reference's call sequence through the drop-in templates, timed per stage
-int run_dropin(bool buckets, const char *out_path) {
+int run_dropin(bool buckets, const char *out_path, std::vector<uint32_t> *points_out = nullptr) {
   std::vector<uint32_t> points, descriptors;
+  std::vector<uint8_t> out_buf((size_t)ROWS * IMG_W, 0);     // the score map `out`, zero-initialised (Fast.h:42-44)
+  uint8_t(*out)[IMG_W] = (uint8_t(*)[IMG_W])out_buf.data();
   pislam::detail::runtime();                          // device / library start-up outside the timed part
   {
     static uint8_t warm_in[64][IMG_W], warm_out[64][IMG_W];   // the first launch loads the code object
@@ -145,6 +150,10 @@ int run_dropin(bool buckets, const char *out_path) {
          "host<->device staging of every call included)\n", end - begin, t_detect, t_harris, t_extract, t_orb);
   printf("%zu features\n", points.size());
   if (out_path) write_result(out_path, points, descriptors);
+  if (points_out) {
+    *points_out = points;
+    points_out->insert(points_out->end(), descriptors.begin(), descriptors.end());
+  }
   return 0;
 }
 
@@ -273,7 +282,7 @@ int main(int argc, char **argv) {
   }
   bool buckets = false, rccl_single = false;
   const char *out_path = nullptr;
-  int batch = 0, steps = 10, world = 1;
+  int batch = 0, steps = 10, world = 1, threads = 1;
   for (int i = 2; i < argc; i++) {
     if (!strcmp(argv[i], "--buckets")) buckets = true;
     else if (!strcmp(argv[i], "--rccl-single")) rccl_single = true;
@@ -281,6 +290,7 @@ int main(int argc, char **argv) {
     else if (!strcmp(argv[i], "--batch") && i + 1 < argc) batch = atoi(argv[++i]);
     else if (!strcmp(argv[i], "--steps") && i + 1 < argc) steps = atoi(argv[++i]);
     else if (!strcmp(argv[i], "--world") && i + 1 < argc) world = atoi(argv[++i]);
+    else if (!strcmp(argv[i], "--threads") && i + 1 < argc) threads = atoi(argv[++i]);
     else {
       fprintf(stderr, "unknown argument %s\n", argv[i]);
       return 1;
@@ -290,6 +300,21 @@ int main(int argc, char **argv) {
     fprintf(stderr, "%s: expected a raw or binary-PGM grey image of %d x %d (the demo's stacked 8-level pyramid)\n",
             argv[1], IMG_W, ROWS);
     return 2;
+  }
+  if (batch <= 0 && threads > 1) {
+    std::vector<std::vector<uint32_t>> res((size_t)threads);
+    std::vector<int> rc((size_t)threads, 0);
+    std::vector<std::thread> pool;
+    for (int t = 0; t < threads; t++)
+      pool.emplace_back([&, t] { rc[t] = run_dropin(buckets, t == 0 ? out_path : nullptr, &res[t]); });
+    for (auto &th : pool) th.join();
+    for (int t = 0; t < threads; t++)
+      if (rc[t] != 0 || res[t] != res[0]) {
+        fprintf(stderr, "thread %d disagrees with thread 0\n", t);
+        return 15;
+      }
+    printf("%d threads agree\n", threads);
+    return 0;
   }
   if (batch <= 0) return run_dropin(buckets, out_path);
   if (world < 1 || steps < 1) return 1;
