@@ -1215,7 +1215,25 @@ int run_fused(pislam_ctx *c, const pislam_frontend_params *p, const pf::FusedPar
     return launch_ok(c, "k_orb<batch>");
   }
   // gather + orbCompute in one launch: (chunks, batch) workgroups
-  int nch = c->opt_orb_chunks > 0 ? c->opt_orb_chunks : std::min(64, std::max(16, 4096 / batch));
+  // Workgroups per pyramid: ~16 (61 keypoints each at 981 per pyramid) but such that the grid is a whole number of
+  // "waves" of resident workgroups (7 per CU: 64 VGPRs, 13.5 KB LDS) — batch 256: 14 chunks = 2 x 1792 workgroups
+  // measured 0.079 ms against 0.085 ms with 16 (2.3 waves: the last one 30 % full).
+  int nch = std::min(64, std::max(16, 4096 / batch));
+  {
+    const long slots = 7L * std::max(1, c->num_cus);
+    long best = nch, bestd = 1L << 40;
+    for (long m = 1; m <= 64; m++) {
+      const long cand = m * slots / batch;
+      if (cand < 4 || cand > 64) continue;
+      const long d = std::labs(cand - nch);
+      if (d < bestd) {
+        bestd = d;
+        best = cand;
+      }
+    }
+    nch = (int)best;
+  }
+  if (c->opt_orb_chunks > 0) nch = c->opt_orb_chunks;
   const size_t per_max = ((size_t)p->max_keypoints + nch - 1) / nch;
   size_t olds = (size_t)pf::OWAVES * 2 * pf::ORB_PATCH_BYTES + sizeof(uint32_t) * (((size_t)F.strips_per_pyr + 1 + 3) & ~(size_t)3) +
                 sizeof(uint32_t) * 2 * per_max;        // keypoints to describe here and their final positions
