@@ -72,8 +72,7 @@ struct FusedLevel {
                      // a level's narrower tiles leave under the residency budget to its queue)
   int tbytes;        // plain layout: bytes reserved for the image tile = max((R+10)*tpitch, the scan
                      // fallbacks' survivor / per-cell buffers — larger only with narrow x-tiles)
-  uint32_t vpr_recip; // ceil(2^32 / (tpitch/16)): row = umulhi(i, vpr_recip) for i < 2^16
-  int st_dr, st_dv;  // staging step of a thread: NT / (tpitch/16) rows and NT % (tpitch/16) vectors
+  uint32_t vpr_recip; // ceil(2^32 / (tpitch/16)): row = umulhi(i, vpr_recip) for a vector index i < 2^16
   // A plan entry is a whole pyramid level, or one X-TILE of a wide level: a column range handled by its own
   // workgroups like a level of its own (w / col0 describe the tile plus a halo of real image columns in place
   // of the border), so that the LDS footprint — and with it the number of resident workgroups — does not grow
@@ -549,43 +548,34 @@ __device__ __forceinline__ void strip_body(const StripArgs A, const FusedLevel L
       const int r_st0 = carry_img ? 10 : 0;         // the first 10 rows were carried over
       if (carry_img && (ablate & 2048)) {           // profiling only: no global loads on carried strips
       } else if (VEC16 && carry_img && pf_have) {   // the new rows were prefetched while the strip above ran
-        const int vpr = tpitch >> 4;
-        int r = (int)__umulhi((uint32_t)tid, L.vpr_recip), v = tid - r * vpr;
-        r += 10;
-        const int dr = L.st_dr, dv = L.st_dv;          // NT / vpr and NT % vpr, from the plan (no division here)
+        // The tile's rows are contiguous in LDS (tpitch = 16 * vectors per row), so the strip's new rows
+        // 10 .. nrows-1 are ONE run of (nrows - 10) * vpr 16-byte vectors: thread t owns vectors t, t + NT, ...
+        // — one base address with immediate offsets, one compare per vector, nothing to carry across strips.
+        const int nvec = (nrows - 10) * (tpitch >> 4);
+        lds_u4 *dstv = (lds_u4 *)(tile0 + 10 * tpitch) + tid;
 #pragma unroll
-        for (int k = 0; k < PF_MAX; k++) {
-          if (r < nrows) *(lds_u4 *)(tile0 + r * tpitch + 16 * v) = pf[k];
-          v += dv;
-          if (v >= vpr) {
-            v -= vpr;
-            r++;
-          }
-          r += dr;
-        }
+        for (int k = 0; k < PF_MAX; k++)
+          if (tid + NT * k < nvec) dstv[NT * k] = pf[k];
       } else if (VEC16) {
         const int vpr = tpitch >> 4;                // 16-byte vectors per row
-        // (row, vector) of this thread's first element, then stepped incrementally: no per-element
-        // division, and the end-of-buffer clipping is only compiled into the (wave-uniform) tail case
-        int r = (int)__umulhi((uint32_t)tid, L.vpr_recip), v = tid - r * vpr;
-        r += r_st0;
-        const int dr = L.st_dr, dv = L.st_dv;          // NT / vpr and NT % vpr, from the plan (no division here)
-        const uint8_t *src0 = im + (ptrdiff_t)y_lo * A.vstep + xbase;
+        // linear vector index i over the rows to stage: LDS offset 16 i (contiguous rows), global offset
+        // 16 i + row * (vstep - tpitch) with row = i / vpr by one multiply-high (i < 2^16)
+        const int nvec = (nrows - r_st0) * vpr;
+        const int gap = A.vstep - tpitch;
+        const uint8_t *src0 = im + (ptrdiff_t)(y_lo + r_st0) * A.vstep + xbase;
+        lds_u4 *dstv = (lds_u4 *)(tile0 + r_st0 * tpitch);
         const bool tail = (ptrdiff_t)(y_lo + nrows - 1) * A.vstep + xbase + tpitch > lim;
         if (!tail) {
-          for (; r < nrows; r += dr) {
-            *(lds_u4 *)(tile0 + r * tpitch + 16 * v) = *(const u32x4 *)(src0 + (uint32_t)(r * A.vstep + 16 * v));   // (a pyramid is < 2 GiB)
-            v += dv;
-            if (v >= vpr) {
-              v -= vpr;
-              r++;
-            }
+          for (int i = tid; i < nvec; i += NT) {
+            const int row = (int)__umulhi((uint32_t)i, L.vpr_recip);
+            dstv[i] = *(const u32x4 *)(src0 + (uint32_t)(16 * i + row * gap));   // (a pyramid is < 2 GiB)
           }
         } else {
-          for (; r < nrows; r += dr) {
+          for (int i = tid; i < nvec; i += NT) {
             // never read past the pyramid buffer (the last tile can overhang the image row: flat
             // addressing like the reference, clipped at the end of the buffer)
-            const ptrdiff_t off = (ptrdiff_t)(y_lo + r) * A.vstep + xbase + 16 * v;
+            const int row = (int)__umulhi((uint32_t)i, L.vpr_recip);
+            const ptrdiff_t off = (ptrdiff_t)(y_lo + r_st0) * A.vstep + xbase + (ptrdiff_t)16 * i + (ptrdiff_t)row * gap;
             u32x4 d;
             if (off + 16 <= lim) {
               d = *(const u32x4 *)(im + off);
@@ -596,12 +586,7 @@ __device__ __forceinline__ void strip_body(const StripArgs A, const FusedLevel L
                 if (off + k < lim) w4[k >> 2] |= (uint32_t)im[off + k] << (8 * (k & 3));
               d = (u32x4){w4[0], w4[1], w4[2], w4[3]};
             }
-            *(lds_u4 *)(tile0 + r * tpitch + 16 * v) = d;
-            v += dv;
-            if (v >= vpr) {
-              v -= vpr;
-              r++;
-            }
+            dstv[i] = d;
           }
         }
       } else {
@@ -624,19 +609,13 @@ __device__ __forceinline__ void strip_body(const StripArgs A, const FusedLevel L
       const int ylo_n = ye - 4, ye_n = min(ye + L.R, Lh - B);
       const int nrows_n = min(ye_n + 6, Lh) - ylo_n;
       if ((ptrdiff_t)(ylo_n + nrows_n - 1) * A.vstep + xbase + tpitch <= lim) {
-        const uint8_t *src_n = im + (ptrdiff_t)ylo_n * A.vstep + xbase;
-        int r = (int)__umulhi((uint32_t)tid, L.vpr_recip), v = tid - r * vpr;
-        r += 10;
-        const int dr = L.st_dr, dv = L.st_dv;          // NT / vpr and NT % vpr, from the plan (no division here)
+        // the next strip's new rows 10 .. nrows_n-1 as one run of vectors (see the store above)
+        const int nvec_n = (nrows_n - 10) * vpr, gap = A.vstep - tpitch;
+        const uint8_t *src_n = im + (ptrdiff_t)(ylo_n + 10) * A.vstep + xbase;
 #pragma unroll
         for (int k = 0; k < PF_MAX; k++) {
-          if (r < nrows_n) pf[k] = *(const u32x4 *)(src_n + (uint32_t)(r * A.vstep + 16 * v));
-          v += dv;
-          if (v >= vpr) {
-            v -= vpr;
-            r++;
-          }
-          r += dr;
+          const int i = tid + NT * k;
+          if (i < nvec_n) pf[k] = *(const u32x4 *)(src_n + (uint32_t)(16 * i + (int)__umulhi((uint32_t)i, L.vpr_recip) * gap));
         }
         pf_issued = true;
       }

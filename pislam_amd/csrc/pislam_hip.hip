@@ -1055,8 +1055,6 @@ bool build_fused_plan(const pislam_ctx *c, const pislam_frontend_params *p, cons
       L.tpitch = (L.tcols + worst_lead + 8 + 15) & ~15;
     }
     L.vpr_recip = (uint32_t)(((1ull << 32) + (L.tpitch / 16) - 1) / (L.tpitch / 16));
-    L.st_dr = pf::NT / (L.tpitch / 16);
-    L.st_dv = pf::NT % (L.tpitch / 16);
     strips += L.nstrips;
     slots += L.nstrips * (R / 2) * L.nbx;
     // scan fallbacks reuse the image tile: row buffers of R/2 x nbx dwords, or per-cell results (<= one
