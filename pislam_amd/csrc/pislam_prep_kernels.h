@@ -187,17 +187,12 @@ __global__ __launch_bounds__(256) void k_bilinear4(const uint8_t *__restrict__ s
     r0[4 * v] = a.x; r0[4 * v + 1] = a.y; r0[4 * v + 2] = a.z; r0[4 * v + 3] = a.w;
     r1[4 * v] = b.x; r1[4 * v + 1] = b.y; r1[4 * v + 2] = b.z; r1[4 * v + 3] = b.w;
   }
-  // Both source rows of a column travel as one packed u16 pair {row0, row1} (v_perm_b32), so the
-  // horizontal filter of the two rows is two v_pk_mad_u16 + one packed shift, and the vertical filter
-  // one v_dot2_u32_u16 (+128 as its accumulator) and a shift.  Every intermediate fits 16 bits exactly
-  // like the reference's u16 arithmetic: p*f0 + p'*f1 + 128 <= 255*256 + 128 < 65536.
-  typedef unsigned short bl_us2 __attribute__((ext_vector_type(2)));
-  auto pair_of = [](const uint32_t *ra, const uint32_t *rb, int i) {       // {ra byte i, rb byte i} zero-extended
-    const uint32_t sel = 0x0c000c00u | (uint32_t)(i & 3) | ((uint32_t)(4 + (i & 3)) << 16);
-    return __builtin_bit_cast(bl_us2, __builtin_amdgcn_perm(rb[i >> 2], ra[i >> 2], sel));
-  };
-  const bl_us2 fy = {(unsigned short)fy0, (unsigned short)fy1};
-  const bl_us2 half = {128, 128};
+  // Horizontal filter: the two taps of an output are adjacent source bytes, so p0*f0 + p1*f1 + 128 is ONE
+  // v_dot4_u32_u8 of the source dword with a constant weight word (f0, f1 at the taps' byte positions, zero
+  // elsewhere; accumulator 128) — the bytes are never unpacked.  Taps that straddle two dwords take one
+  // v_alignbyte first.  Vertical filter: two v_mad_u32_u24.  8 VALU per output (the packed-u16 form took 11;
+  // the kernels are VALU-bound: 124 M outputs per 64-frame 720p build).  Every intermediate is what the
+  // reference's u16 arithmetic holds: p*f0 + p'*f1 + 128 <= 255*256 + 128 < 65536.
   uint32_t outw[M];
 #pragma unroll
   for (int k = 0; k < M; k++) outw[k] = 0;
@@ -206,10 +201,20 @@ __global__ __launch_bounds__(256) void k_bilinear4(const uint8_t *__restrict__ s
 #pragma unroll
     for (int x = 0; x < M; x++) {
       const int sx = b * N + ((M == 7) ? x : x + (x > 3) + (x > 8));
-      const unsigned short fx0 = (M == 7) ? F7[x] : F13[x], fx1 = (M == 7) ? F7[M - 1 - x] : F13[M - 1 - x];
-      const bl_us2 f0 = {fx0, fx0}, f1 = {fx1, fx1};
-      const bl_us2 hv = (pair_of(r0, r1, sx) * f0 + (pair_of(r0, r1, sx + 1) * f1 + half)) >> 8;     // {h0, h1}
-      const uint32_t o = __builtin_amdgcn_udot2(hv, fy, 128u, false) >> 8;
+      const uint32_t fx0 = (M == 7) ? F7[x] : F13[x], fx1 = (M == 7) ? F7[M - 1 - x] : F13[M - 1 - x];
+      uint32_t w0, w1, wt;
+      if ((sx & 3) == 3) {                             // taps in two dwords (the last group's never are: sx + 1 < 4 N)
+        w0 = __builtin_amdgcn_alignbyte(r0[(sx >> 2) + 1], r0[sx >> 2], 3);
+        w1 = __builtin_amdgcn_alignbyte(r1[(sx >> 2) + 1], r1[sx >> 2], 3);
+        wt = fx0 | (fx1 << 8);
+      } else {
+        w0 = r0[sx >> 2];
+        w1 = r1[sx >> 2];
+        wt = (fx0 << (8 * (sx & 3))) | (fx1 << (8 * ((sx & 3) + 1)));
+      }
+      const uint32_t h0 = __builtin_amdgcn_udot4(w0, wt, 128u, false) >> 8;
+      const uint32_t h1 = __builtin_amdgcn_udot4(w1, wt, 128u, false) >> 8;
+      const uint32_t o = (__umul24(h0, (uint32_t)fy0) + __umul24(h1, (uint32_t)fy1) + 128u) >> 8;
       const int oi = b * M + x;
       outw[oi >> 2] |= o << (8 * (oi & 3));
     }
