@@ -1102,7 +1102,8 @@ bool build_fused_plan(const pislam_ctx *c, const pislam_frontend_params *p, cons
 int run_fused(pislam_ctx *c, const pislam_frontend_params *p, const pf::FusedParams &F, size_t lds, size_t lds_alias,
               const uint8_t *pyramids, size_t stride, int batch, uint32_t *kp, uint32_t *desc, uint32_t *counts) {
   // descriptor staging: QS_SHARED slots of `words` dwords per strip (ALIAS strips hold at most QS_SHARED survivors)
-  const size_t sdesc_bytes = sizeof(uint32_t) * (size_t)F.strips_per_pyr * batch * pf::QS_SHARED * (size_t)p->words;
+  // (only strips that describe their own keypoints write there: option "orb_in_strip")
+  const size_t sdesc_bytes = F.orb_in_strip ? sizeof(uint32_t) * (size_t)F.strips_per_pyr * batch * pf::QS_SHARED * (size_t)p->words : 0;
   if (c->w_stage.ensure(sizeof(uint32_t) * (size_t)F.slots_per_pyr * batch) != PISLAM_OK ||
       c->w_stripcnt.ensure(sizeof(uint32_t) * (size_t)F.strips_per_pyr * batch) != PISLAM_OK ||
       c->w_stagedesc.ensure(sdesc_bytes) != PISLAM_OK)
@@ -1292,7 +1293,8 @@ PISLAM_EXPORT int pislam_frontend_reserve(pislam_ctx *c, const pislam_frontend_p
       bool grew_ovf = false;
       if (c->w_stage.ensure(sizeof(uint32_t) * (size_t)F.slots_per_pyr * batch) != PISLAM_OK ||
           c->w_stripcnt.ensure(sizeof(uint32_t) * (size_t)F.strips_per_pyr * batch) != PISLAM_OK ||
-          c->w_stagedesc.ensure(sizeof(uint32_t) * (size_t)F.strips_per_pyr * batch * pf::QS_SHARED * (size_t)p->words) != PISLAM_OK ||
+          (F.orb_in_strip &&
+           c->w_stagedesc.ensure(sizeof(uint32_t) * (size_t)F.strips_per_pyr * batch * pf::QS_SHARED * (size_t)p->words) != PISLAM_OK) ||
           c->w_ovf.ensure(sizeof(uint32_t) * ((size_t)F.strips_per_pyr * batch + 2), &grew_ovf) != PISLAM_OK)
         return fail(c, PISLAM_ERR_NOMEM, "hipMalloc(fused staging)");
       if (grew_ovf) HIPCHK(c, hipMemsetAsync(c->w_ovf.p, 0, 2 * sizeof(uint32_t), c->stream));
