@@ -91,6 +91,7 @@ def main():
     ap.add_argument("--xtile-cols", type=int, default=-1)
     ap.add_argument("--run-len", type=int, default=0)
     ap.add_argument("--alias", type=int, default=-1)
+    ap.add_argument("--tile-cols", type=int, default=0, help="levels with more classified columns are cut into x-tiles (0 = default 704, < 0 never)")
     ap.add_argument("--orb-in-strip", type=int, default=-1, help="1: strips describe their own keypoints; 0 (default): one gather+ORB pass")
     ap.add_argument("--graph", type=int, default=1,
                     help="1 (default): capture the step's launches into a hipGraph (torch.cuda.CUDAGraph) per output set "
@@ -175,6 +176,8 @@ def main():
     ctx.set_option("lds_pad", args.lds_pad)
     if args.alias >= 0:
         ctx.set_option("alias", args.alias)
+    if args.tile_cols:
+        ctx.set_option("tile_cols", args.tile_cols)
     if args.orb_in_strip >= 0:
         ctx.set_option("orb_in_strip", args.orb_in_strip)
     if args.run_len:
@@ -445,6 +448,10 @@ def main():
         print(json.dumps(out))
     if world > 1:
         torch.distributed.barrier()
+        try:
+            ctx.dist_finalize()                          # our RCCL communicator first, while every rank is still alive
+        except Exception:                                # noqa: BLE001
+            pass
         torch.distributed.destroy_process_group()
 
 

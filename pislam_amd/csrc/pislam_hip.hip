@@ -9,6 +9,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -960,7 +961,11 @@ bool build_fused_plan(const pislam_ctx *c, const pislam_frontend_params *p, cons
     for (int l = 0; l < p->nlevels; l++) {
       const int w = lv[l].width, nx = w - 2 * B, ny = lv[l].height - 2 * B;
       int nt = 1;
-      if (nx > 0 && ny > 0 && 16 * cdiv(nx, 16) > tile_max) nt = cdiv(nx, std::max(64, std::min(tile_max, 640)));
+      // tiles of ~448 owned columns: with the 32-column halo a tile row is two full 256-pixel prefilter steps,
+      // and its strips reach the full 28 rows at 5 workgroups per CU (1280x960 batch 256: 0.94 ms with three
+      // 416-column tiles at level 0 against 1.01 ms with two of 624)
+      if (nx > 0 && ny > 0 && 16 * cdiv(nx, 16) > tile_max)
+        nt = std::max(2, tile_max >= 640 ? (nx + 224) / 448 : cdiv(nx, std::max(64, tile_max)));
       const int T = nt > 1 ? (cdiv(nx, nt) + 31) & ~31 : 0;
       nt = nt > 1 ? cdiv(nx, T) : 1;
       const int g0 = (int)entries.size();
@@ -1079,12 +1084,19 @@ bool build_fused_plan(const pislam_ctx *c, const pislam_frontend_params *p, cons
       lds_alias = std::max(lds_alias, (size_t)fixed + (size_t)L.qh * 4);
     }
   }
-  // Runs: a workgroup walks run_len consecutive strips of a level (halo carried in LDS).  Longer runs
-  // save the duplicated halo work but leave fewer workgroups; keep >= ~3 per resident slot
-  // (4 workgroups x CUs), at most 8 strips per run (batch 256 VGA: 8; batch 32: 1).
-  F->run_len = c->opt_run_len > 0 ? c->opt_run_len
-                                  : (int)std::min<long long>(8, std::max<long long>(1, (long long)strips * batch /
-                                                                                      (12LL * std::max(1, c->num_cus))));
+  // Runs: a workgroup walks run_len consecutive strips of a level (halo carried in LDS).  Longer runs save the
+  // duplicated halo work but leave fewer, longer workgroups for the dispatcher to balance over the 5 resident
+  // slots per CU.  Measured (strip kernel, ms): VGA batch 256 (15 strips per slot): 0.236 / 0.231 / 0.233 / 0.243 /
+  // 0.242 / 0.235 / 0.231 / 0.229 / 0.229 / 0.243 for run_len 1 / 2 / 3 / 4 / 5 / 6 / 8 / 10 / 12 / 16 — the carry is
+  // worth ~3 % at best and the curve is dispatch-quantisation noise; 720p batch 64 (10 strips per slot): 0.208 /
+  // 0.207 / 0.216 / 0.227 / 0.238 for 1..5; 1280x960 batch 256 (54 per slot): 1.029 / 1.018 / 1.012 / 1.044 / 1.053 /
+  // 1.010 for 4 / 5 / 6 / 7 / 8..10 / 12, batch 64: 0.278 / 0.307 / 0.376 for 2 / 3 / 8; VGA batch 32, 64: 1 is best.
+  // Rule: ~6.5 workgroups per resident slot, at most 6 strips per run.  (List-scheduling and processor-sharing
+  // simulations of one XCD were tried as a predictor: neither tracks the measured 2-3 % structure.)
+  {
+    const double per_slot = (double)strips * batch / (5.0 * std::max(1, c->num_cus));
+    F->run_len = c->opt_run_len > 0 ? c->opt_run_len : std::max(1, std::min(6, (int)(per_slot / 6.5 + 0.5)));
+  }
   for (int l = 0; l < F->nlevels; l++) {
     F->lv[l].run0 = runs;
     F->lv[l].nruns = cdiv(F->lv[l].nstrips, F->run_len);
