@@ -1,3 +1,5 @@
+#!/bin/bash
+# usage: tools/bench_quick.sh [bench.py args]  — one short bench run, prints ms/step, kp+desc/s, strip-kernel ms and stage times
 # quick A/B: bench vga default (+ optional extra args), prints ms/step and stage times
 python bench.py --steps 50 --warmup 5 --no-cpu-baseline "$@" 2>/dev/null | python -c "
 import json,sys
