@@ -186,7 +186,9 @@ struct OrbLane {
   int half, r;                                      // r = patch row index, dy = r - 15 (r = 31 idle)
   int sl_h[3], sl_park[3], sl_rel[3];
   bool sl_on[3];
-  uint32_t cmask[8];                                // circle mask of this lane's row: byte j of the 32 covers dx = j - 15
+  // circle mask of this lane's row (Orb.h:118-121,163-286), folded into dot-product weights — byte j of the 32
+  // covers dx = j - 15: m01 = 1 where the pixel belongs to the patch, mdx = |dx| there (0 elsewhere)
+  uint32_t m01[8], mdx[8];
 };
 __device__ __forceinline__ OrbLane orb_lane(int lane, int vstep) {
   OrbLane G;
@@ -196,13 +198,17 @@ __device__ __forceinline__ OrbLane orb_lane(int lane, int vstep) {
   const int u = (G.r < 31) ? patch_umax(dy < 0 ? -dy : dy) : -1;
 #pragma unroll
   for (int k = 0; k < 8; k++) {
-    uint32_t m = 0;
+    uint32_t m = 0, w = 0;
 #pragma unroll
     for (int b = 0; b < 4; b++) {
       const int dx = 4 * k + b - 15, adx = dx < 0 ? -dx : dx;
-      if (adx <= u) m |= 0xffu << (8 * b);
+      if (adx <= u) {
+        m |= 1u << (8 * b);
+        w |= (uint32_t)adx << (8 * b);
+      }
     }
-    G.cmask[k] = m;
+    G.m01[k] = m;
+    G.mdx[k] = w;
   }
 #pragma unroll
   for (int j = 0; j < 3; j++) {
@@ -262,21 +268,15 @@ __device__ __forceinline__ void orb_describe(const OrbLane &G, const OrbWin &cur
 #pragma unroll
     for (int k = 0; k < 8; k++) row[k] = __builtin_amdgcn_alignbyte(in[k + 1], in[k], sh & 3u);
   }
-  // moments of this row: sum v and sum |dx| v, left (dx<0) and right (dx>0) separately
+  // moments of this row: sum v and sum |dx| v, left (dx<0) and right (dx>0) separately (Orb.h:123-126).  The
+  // circle mask lives in the dot-product weights (a zero weight ignores the pixel), so the row is never ANDed.
   uint32_t sv = 0, left = 0, right = 0;
 #pragma unroll
-  for (int k = 0; k < 8; k++) {
-    const uint32_t v = row[k] & G.cmask[k];
-    sv = __builtin_amdgcn_udot4(v, 0x01010101u, sv, false);
-  }
-  left = __builtin_amdgcn_udot4(row[0] & G.cmask[0], 0x0c0d0e0fu, left, false);    // dx -15..-12
-  left = __builtin_amdgcn_udot4(row[1] & G.cmask[1], 0x08090a0bu, left, false);    // dx -11..-8
-  left = __builtin_amdgcn_udot4(row[2] & G.cmask[2], 0x04050607u, left, false);    // dx  -7..-4
-  left = __builtin_amdgcn_udot4(row[3] & G.cmask[3], 0x00010203u, left, false);    // dx  -3..0
-  right = __builtin_amdgcn_udot4(row[4] & G.cmask[4], 0x04030201u, right, false);  // dx   1..4
-  right = __builtin_amdgcn_udot4(row[5] & G.cmask[5], 0x08070605u, right, false);  // dx   5..8
-  right = __builtin_amdgcn_udot4(row[6] & G.cmask[6], 0x0c0b0a09u, right, false);  // dx   9..12
-  right = __builtin_amdgcn_udot4(row[7] & G.cmask[7], 0x000f0e0du, right, false);  // dx  13..15 (16 masked)
+  for (int k = 0; k < 8; k++) sv = __builtin_amdgcn_udot4(row[k], G.m01[k], sv, false);
+#pragma unroll
+  for (int k = 0; k < 4; k++) left = __builtin_amdgcn_udot4(row[k], G.mdx[k], left, false);        // dx -15 .. 0
+#pragma unroll
+  for (int k = 4; k < 8; k++) right = __builtin_amdgcn_udot4(row[k], G.mdx[k], right, false);      // dx 1 .. 15 (16 masked)
   const int m10 = half_sum((int)right - (int)left, half);
   const int m01 = half_sum((r - 15) * (int)sv, half);
   const uint32_t rot = angle_bin_with(m10, m01, [&](float f) { return vrecpe_f32_tab(f, rtab); });
@@ -284,18 +284,39 @@ __device__ __forceinline__ void orb_describe(const OrbLane &G, const OrbWin &cur
   const uint32_t *tab = ::g_brief_ofs.v + rot * 256 + r;   // defined by the including TU
   // the patch's byte (dy,dx) sits at (dy+15)*48 + sh + dx+15; sh is the same for every row
   const lds_u8 *bp = patch_l + sh;
-  uint32_t myword = 0;
   uint32_t ent[8];
 #pragma unroll
   for (int round = 0; round < 8; round++) ent[round] = tab[32 * round];   // all 8 table loads in flight
+  uint64_t m[8];
 #pragma unroll
   for (int round = 0; round < 8; round++) {
     const uint32_t e = ent[round];
     const uint32_t a = bp[e & 0xffffu], b = bp[e >> 16];
-    const uint64_t m = __ballot(a < b);                           // Brief.h:52
-    // lane `round` of either half keeps that half's word (rounds >= words are never stored)
-    const uint32_t w = half ? (uint32_t)(m >> 32) : (uint32_t)m;
-    if (r == round) myword = w;
+    m[round] = __ballot(a < b);                                     // Brief.h:52
+  }
+  // lane `round` of either half keeps that half's word: the 16 ballot halves go straight from their SGPRs into
+  // the lanes with v_writelane_b32 (no compare / select per round).  All compares are issued before the first
+  // write; the s_nop covers the "VALU wrote the SGPR a v_writelane reads" distance for the last of them
+  // (tools/probes/writelane.hip: without it the lane can receive the SGPR's previous value; hipcc pads no
+  // hazards inside inline asm).
+  uint32_t myword = 0;
+  {
+    const uint32_t l0 = (uint32_t)m[0], l1 = (uint32_t)m[1], l2 = (uint32_t)m[2], l3 = (uint32_t)m[3], l4 = (uint32_t)m[4],
+                   l5 = (uint32_t)m[5], l6 = (uint32_t)m[6], l7 = (uint32_t)m[7];
+    const uint32_t h0 = (uint32_t)(m[0] >> 32), h1 = (uint32_t)(m[1] >> 32), h2 = (uint32_t)(m[2] >> 32), h3 = (uint32_t)(m[3] >> 32),
+                   h4 = (uint32_t)(m[4] >> 32), h5 = (uint32_t)(m[5] >> 32), h6 = (uint32_t)(m[6] >> 32), h7 = (uint32_t)(m[7] >> 32);
+    asm volatile("s_nop 4\n\t"
+                 "v_writelane_b32 %0, %1, 0\n\tv_writelane_b32 %0, %9, 32\n\t"
+                 "v_writelane_b32 %0, %2, 1\n\tv_writelane_b32 %0, %10, 33\n\t"
+                 "v_writelane_b32 %0, %3, 2\n\tv_writelane_b32 %0, %11, 34\n\t"
+                 "v_writelane_b32 %0, %4, 3\n\tv_writelane_b32 %0, %12, 35\n\t"
+                 "v_writelane_b32 %0, %5, 4\n\tv_writelane_b32 %0, %13, 36\n\t"
+                 "v_writelane_b32 %0, %6, 5\n\tv_writelane_b32 %0, %14, 37\n\t"
+                 "v_writelane_b32 %0, %7, 6\n\tv_writelane_b32 %0, %15, 38\n\t"
+                 "v_writelane_b32 %0, %8, 7\n\tv_writelane_b32 %0, %16, 39"
+                 : "+v"(myword)
+                 : "s"(l0), "s"(l1), "s"(l2), "s"(l3), "s"(l4), "s"(l5), "s"(l6), "s"(l7), "s"(h0), "s"(h1), "s"(h2), "s"(h3),
+                   "s"(h4), "s"(h5), "s"(h6), "s"(h7));
   }
   if (valid && r < words) dst[r] = myword;
 }
