@@ -161,7 +161,12 @@ __device__ __attribute__((noinline)) void harris_overflow(lds_u8 *tile, lds_u8 *
 // ===========================================================================
 constexpr int OWAVES = 4;                           // waves per k_gather_orb workgroup
 constexpr int ORB_PITCH = 48;                       // one 48-byte (3 x 16 B) window per patch row
-constexpr int ORB_PATCH_BYTES = 32 * ORB_PITCH + 16;   // 31 rows (+1 idle) + slack for the byte shift
+// Row r of a patch starts at r * 48 + 4 * (r >> 3) bytes: a pitch of 12 dwords alone would put rows r, r+8, r+16,
+// r+24 on the same banks (12 * 8 = 96 = 3 * 32), a 4-way conflict on every one of the 9 row reads of the moments
+// (lane = row); the skew of one dword per 8 rows spreads them (PMC: 57 % of the kernel's LDS cycles were bank
+// conflicts, the LDS 68 % busy).
+__host__ __device__ constexpr int orb_row_ofs(int r) { return r * ORB_PITCH + 4 * (r >> 3); }
+constexpr int ORB_PATCH_BYTES = 32 * ORB_PITCH + 32;   // 31 rows (+1 idle) + skew + slack for the byte shift
 
 // Sum over each 32-lane half of the wave, result in every lane of that half.  DPP row shifts
 // (zero fill) leave each 16-lane row's sum in its last lane, row_bcast:15 folds row 0 into row 1 and
@@ -218,7 +223,7 @@ __device__ __forceinline__ OrbLane orb_lane(int lane, int vstep) {
     G.sl_h[j] = h;
     G.sl_on[j] = slot < 186;
     G.sl_rel[j] = row * vstep + 16 * chunk;         // byte offset of the chunk relative to the patch origin (y-15, x-15)
-    G.sl_park[j] = h * ORB_PATCH_BYTES + row * ORB_PITCH + 16 * chunk;
+    G.sl_park[j] = h * ORB_PATCH_BYTES + orb_row_ofs(row) + 16 * chunk;
   }
   return G;
 }
@@ -252,11 +257,18 @@ __device__ __forceinline__ void orb_describe(const OrbLane &G, const OrbWin &cur
   const bool valid = pme != 0;
   const int x = decode_x(pme), y = decode_y(pme);
   const uint32_t sh = (uint32_t)(((y - 15) * vstep + (x - 15)) & 15);   // same for every row
+  // (the skewed row starts are only 4-byte aligned: four dword stores per chunk instead of one 16-byte store)
 #pragma unroll
   for (int j = 0; j < 3; j++)
-    if (G.sl_on[j]) *(lds_u4 *)(wave_patches + G.sl_park[j]) = (u32x4){cur.w[j].x, cur.w[j].y, cur.w[j].z, cur.w[j].w};
+    if (G.sl_on[j]) {
+      lds_u32 *d = (lds_u32 *)(wave_patches + G.sl_park[j]);
+      d[0] = cur.w[j].x;
+      d[1] = cur.w[j].y;
+      d[2] = cur.w[j].z;
+      d[3] = cur.w[j].w;
+    }
   lds_u8 *patch_l = wave_patches + half * ORB_PATCH_BYTES;
-  const lds_u8 *prow = patch_l + r * ORB_PITCH;
+  const lds_u8 *prow = patch_l + orb_row_ofs(r);
   // read the row back aligned to the PATCH: 9 aligned dwords + v_alignbyte (byte-unaligned
   // ds_read_b32 works on gfx950 but costs ~47 stall cycles each — SQ_LDS_UNALIGNED_STALL)
   uint32_t row[8];
@@ -282,7 +294,8 @@ __device__ __forceinline__ void orb_describe(const OrbLane &G, const OrbWin &cur
   const uint32_t rot = angle_bin_with(m10, m01, [&](float f) { return vrecpe_f32_tab(f, rtab); });
   // BRIEF: pair k = 32*round + r of this half's keypoint -> bit r of word `round`
   const uint32_t *tab = ::g_brief_ofs.v + rot * 256 + r;   // defined by the including TU
-  // the patch's byte (dy,dx) sits at (dy+15)*48 + sh + dx+15; sh is the same for every row
+  // the patch's byte (dy,dx) sits at orb_row_ofs(dy+15) + sh + dx+15 (the table holds the first and last term); sh is
+  // the same for every row
   const lds_u8 *bp = patch_l + sh;
   uint32_t ent[8];
 #pragma unroll

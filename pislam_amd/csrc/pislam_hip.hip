@@ -22,18 +22,20 @@ __device__ const uint32_t g_brief_tab[30 * 256] = {
 static constexpr uint32_t h_brief_tab_packed[30 * 256] = {
 #include "brief_table.inc"
 };
-// The same table as byte offsets into a 48-byte-pitch LDS patch whose row 15 / column 15 is the
-// keypoint: ofs = (dy+15)*48 + (dx+15); low half = first sample point, high half = second.
+// The same table as byte offsets into the LDS patch of the ORB kernels (48-byte rows, skewed by one dword per 8
+// rows: pf::orb_row_ofs) whose row 15 / column 15 is the keypoint: ofs = row_ofs(dy+15) + (dx+15); low half = first
+// sample point, high half = second.
 struct BriefOfsTab {
   uint32_t v[30 * 256];
 };
+static constexpr int brief_row_ofs(int r) { return r * 48 + 4 * (r >> 3); }   // == pf::orb_row_ofs (checked below)
 static constexpr BriefOfsTab make_brief_ofs() {
   BriefOfsTab t{};
   for (int i = 0; i < 30 * 256; i++) {
     const uint32_t e = h_brief_tab_packed[i];
     const int dx0 = (int8_t)(e & 0xff), dy0 = (int8_t)((e >> 8) & 0xff);
     const int dx1 = (int8_t)((e >> 16) & 0xff), dy1 = (int8_t)(e >> 24);
-    t.v[i] = (uint32_t)((dy0 + 15) * 48 + dx0 + 15) | ((uint32_t)((dy1 + 15) * 48 + dx1 + 15) << 16);
+    t.v[i] = (uint32_t)(brief_row_ofs(dy0 + 15) + dx0 + 15) | ((uint32_t)(brief_row_ofs(dy1 + 15) + dx1 + 15) << 16);
   }
   return t;
 }
@@ -43,6 +45,8 @@ __device__ const BriefOfsTab g_brief_ofs = make_brief_ofs();
 __device__ const pdev::VrecpeTab g_vrecpe_tab = pdev::make_vrecpe_tab();   // used by pf::k_gather_orb
 #include "pislam_stage_kernels.h"
 #include "pislam_fused_kernels.h"
+static_assert(brief_row_ofs(0) == pf::orb_row_ofs(0) && brief_row_ofs(15) == pf::orb_row_ofs(15) &&
+              brief_row_ofs(30) == pf::orb_row_ofs(30), "g_brief_ofs must use the patch layout of the ORB kernels");
 #include "pislam_prep_kernels.h"
 #include "pislam_match_kernels.h"
 
