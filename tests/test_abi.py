@@ -95,3 +95,43 @@ int main() {
 ''')
     r = subprocess.run(["g++", "-std=c++11", "-fsyntax-only", "-I", inc, str(src)], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
+
+
+def test_multi_gpu_binding_of_integration_md_compiles(tmp_path):
+    """The C++ one-process-per-GPU loop INTEGRATION.md section 4 shows (pislam_dist_*: unique id, communicator,
+    shard, fence, batch call, count all-gather, slowest-rank reduction) compiles against include/pislam_hip.h
+    with a plain host compiler, and tools/pislam_demo.cpp (the complete program) builds."""
+    src = tmp_path / "dist_usage.cpp"
+    src.write_text(r'''
+#include "pislam_hip.h"
+int run(int rank, int world, int local_device, void *my_stream, const pislam_frontend_params &p, const pislam_level *lv,
+        const uint8_t *d_pyr, size_t stride, int global_batch, uint32_t *d_kp[2], uint32_t *d_desc[2], uint32_t *d_counts[2],
+        uint32_t *d_all[2], int steps) {
+  uint8_t id[PISLAM_DIST_ID_BYTES] = {0};
+  if (rank == 0 && pislam_dist_get_unique_id(id) != PISLAM_OK) return 1;
+  pislam_ctx *ctx = nullptr;
+  if (pislam_ctx_create(local_device, &ctx) != PISLAM_OK) return 2;
+  pislam_ctx_set_stream(ctx, my_stream);
+  if (pislam_dist_init(ctx, id, rank, world) != PISLAM_OK) return 3;
+  int first = 0, count = 0;
+  pislam_dist_shard(global_batch, rank, world, &first, &count);
+  for (int s = 0; s < steps; s++) {
+    const int o = s & 1;
+    pislam_dist_fence(ctx, 2);
+    pislam_orb_frontend_batch(ctx, &p, lv, d_pyr + (size_t)first * stride, stride, count, d_kp[o], d_desc[o], d_counts[o]);
+    pislam_dist_allgather_counts(ctx, d_counts[o], (size_t)count, d_all[o]);
+  }
+  pislam_dist_synchronize(ctx);
+  double t = 1.0;
+  pislam_dist_allreduce_max(ctx, &t);
+  const int ok = pislam_dist_rank(ctx) == rank && pislam_dist_world(ctx) == world;
+  pislam_dist_finalize(ctx);
+  pislam_ctx_destroy(ctx);
+  return ok ? 0 : 4;
+}
+''')
+    r = subprocess.run(["g++", "-std=c++11", "-fsyntax-only", "-I", os.path.join(ROOT, "include"), str(src)],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run(["make", "-C", os.path.join(ROOT, "tools"), "pislam_demo"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
