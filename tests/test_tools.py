@@ -60,6 +60,20 @@ def test_cpp_tool_dropin_sequence_reproduces_reference_pins(tmp_path, demo_files
     assert "1754 features" in r.stdout and re.search(r"GPU  Time: [0-9.]+ ms  \(fastDetect [0-9.]+, fastScoreHarris", r.stdout)
     kp, desc = read_result(out)
     assert len(kp) == 1754 and sha16(kp) == SURVEY_PINS["kp"] and sha16(desc) == SURVEY_PINS["desc"]
+    # --paint: the demo's out.png equivalent (demo.cpp:103-111): every keypoint marked by black ticks 4-5 px away
+    marked = tmp_path / "marked.pgm"
+    r = subprocess.run([exe, str(src), "--paint", str(marked)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, (r.stdout, r.stderr)
+    raw = open(marked, "rb").read()
+    assert raw.startswith(b"P5\n640 2210\n255\n")
+    m = np.frombuffer(raw[len(b"P5\n640 2210\n255\n"):], np.uint8).reshape(2210, 640)
+    exp = np.fromfile(demo_files[0], np.uint8).reshape(2210, 640).copy()
+    for pt in kp:
+        x, y = (int(pt) >> 12) & 0xfff, int(pt) & 0xfff
+        for d in (-5, -4, 4, 5):
+            exp[y + d, x] = 0
+            exp[y, x + d] = 0
+    assert (m == exp).all()
     r = subprocess.run([exe, str(src), "--buckets", "--out", str(out)], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "1315 features" in r.stdout, (r.stdout, r.stderr)
     assert sha16(read_result(out)[0]) == SURVEY_PINS["kp_bucket43"]

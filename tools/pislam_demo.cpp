@@ -4,9 +4,11 @@
 // and the C ABI include/pislam_hip.h — no libpng (raw or binary PGM in, a flat binary file out), no Python,
 // no torch in the process.
 //
-//   pislam_demo <pyramid.raw|pyramid.pgm> [--buckets] [--out result.bin]
+//   pislam_demo <pyramid.raw|pyramid.pgm> [--buckets] [--out result.bin] [--paint marked.pgm]
 //       the reference's call sequence through the pislam:: templates (host arrays, staged per call), with
-//       the wall time of every stage — the equivalent of demo.cpp's "CPU  Time" line (demo.cpp:113-114)
+//       the wall time of every stage — the equivalent of demo.cpp's "CPU  Time" line (demo.cpp:113-114);
+//       --paint writes the pyramid with every keypoint marked by four dark ticks 4-5 pixels from it, as the
+//       reference demo's out.png does (demo.cpp:103-111,118-130), as a binary PGM
 //   ... --threads T
 //       the same call sequence from T host threads at once (the reference's functions are re-entrant; the
 //       drop-in templates keep one context + stream per thread): every thread must report the same result
@@ -78,6 +80,23 @@ bool load_pyramid(const char *path) {
   return ok;
 }
 
+// the demo's marker (demo.cpp:118-130): black ticks at distance 4 and 5 above, below, left and right
+void paint_point(int x, int y) {
+  const int d[4] = {-5, -4, 4, 5};
+  for (int k = 0; k < 4; k++) {
+    if (y + d[k] >= 0 && y + d[k] < ROWS) img[y + d[k]][x] = 0;
+    if (x + d[k] >= 0 && x + d[k] < IMG_W) img[y][x + d[k]] = 0;
+  }
+}
+bool write_pgm(const char *path) {
+  FILE *o = fopen(path, "wb");
+  if (!o) return false;
+  fprintf(o, "P5\n%d %d\n255\n", IMG_W, ROWS);
+  const bool ok = fwrite(img, 1, sizeof(img), o) == sizeof(img);
+  fclose(o);
+  return ok;
+}
+
 void write_result(const char *path, const std::vector<uint32_t> &kp, const std::vector<uint32_t> &desc) {
   FILE *o = fopen(path, "wb");
   if (!o) return;
@@ -107,7 +126,8 @@ void write_result(const char *path, const std::vector<uint32_t> &kp, const std::
   } while (0)
 
 // the reference's call sequence through the drop-in templates, timed per stage
-int run_dropin(bool buckets, const char *out_path, std::vector<uint32_t> *points_out = nullptr) {
+int run_dropin(bool buckets, const char *out_path, std::vector<uint32_t> *points_out = nullptr,
+               const char *paint_path = nullptr) {
   std::vector<uint32_t> points, descriptors;
   std::vector<uint8_t> out_buf((size_t)ROWS * IMG_W, 0);     // the score map `out`, zero-initialised (Fast.h:42-44)
   uint8_t(*out)[IMG_W] = (uint8_t(*)[IMG_W])out_buf.data();
@@ -153,6 +173,10 @@ int run_dropin(bool buckets, const char *out_path, std::vector<uint32_t> *points
   if (points_out) {
     *points_out = points;
     points_out->insert(points_out->end(), descriptors.begin(), descriptors.end());
+  }
+  if (paint_path) {                                   // after everything that reads the image
+    for (uint32_t pt : points) paint_point((int)pislam::decodeFastX(pt), (int)pislam::decodeFastY(pt));
+    if (!write_pgm(paint_path)) return 16;
   }
   return 0;
 }
@@ -276,17 +300,18 @@ int run_batch(int batch, int steps, bool buckets, const char *out_path, int rank
 
 int main(int argc, char **argv) {
   if (argc < 2) {
-    fprintf(stderr, "Usage: %s pyramid.raw|pyramid.pgm [--buckets] [--out result.bin] [--batch N [--steps K] "
+    fprintf(stderr, "Usage: %s pyramid.raw|pyramid.pgm [--buckets] [--out result.bin] [--paint marked.pgm] [--threads T] [--batch N [--steps K] "
                     "[--world W] [--rccl-single]]\n", argv[0]);
     return 1;
   }
   bool buckets = false, rccl_single = false;
-  const char *out_path = nullptr;
+  const char *out_path = nullptr, *paint_path = nullptr;
   int batch = 0, steps = 10, world = 1, threads = 1;
   for (int i = 2; i < argc; i++) {
     if (!strcmp(argv[i], "--buckets")) buckets = true;
     else if (!strcmp(argv[i], "--rccl-single")) rccl_single = true;
     else if (!strcmp(argv[i], "--out") && i + 1 < argc) out_path = argv[++i];
+    else if (!strcmp(argv[i], "--paint") && i + 1 < argc) paint_path = argv[++i];
     else if (!strcmp(argv[i], "--batch") && i + 1 < argc) batch = atoi(argv[++i]);
     else if (!strcmp(argv[i], "--steps") && i + 1 < argc) steps = atoi(argv[++i]);
     else if (!strcmp(argv[i], "--world") && i + 1 < argc) world = atoi(argv[++i]);
@@ -316,7 +341,7 @@ int main(int argc, char **argv) {
     printf("%d threads agree\n", threads);
     return 0;
   }
-  if (batch <= 0) return run_dropin(buckets, out_path);
+  if (batch <= 0) return run_dropin(buckets, out_path, nullptr, paint_path);
   if (world < 1 || steps < 1) return 1;
   // one process per GPU: fork the ranks BEFORE the first HIP call (a forked HIP runtime is unusable)
   char id_file[256];
