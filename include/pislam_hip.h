@@ -58,7 +58,7 @@ int pislam_ctx_set_stream(pislam_ctx *ctx, void *hip_stream);
  *   "xtile_cols" image x-tiles inside a strip (0 = full width);  "orb_chunks" gather+ORB workgroups per pyramid
  *   "tile_cols"  levels with more classified columns are cut into x-tiles run by separate workgroups (0 = 704, < 0 never)
  *   "orb_in_strip" 1 strips describe their own keypoints right after their NMS, 0 (default) one gather+ORB pass describes all
- *   "wgs_per_cu", "lds_pad", "repeat_strips", "ablate"  profiling only (ablate != 0 gives INVALID results by design)
+ *   "wgs_per_cu", "strip_px", "strip_rows_max", "lds_pad", "repeat_strips", "ablate"  profiling only (ablate != 0 gives INVALID results by design)
  *   "dist_rccl_single" test hook: pislam_dist_init(world = 1) still creates a 1-rank RCCL communicator */
 int pislam_ctx_set_option(pislam_ctx *ctx, const char *key, int value);
 int pislam_ctx_synchronize(pislam_ctx *ctx);

@@ -111,6 +111,8 @@ struct pislam_ctx {
   int opt_xtile_cols = 0;    // fused pipeline: max classified columns per image x-tile (0 = full width)
   int opt_lds_pad = 0;       // profiling only: extra dynamic LDS bytes per strip workgroup
   int opt_wgs_per_cu = 0;    // fused pipeline: if > 0, size strip heights for this many workgroups per CU
+  int opt_strip_px = 16384;  // profiling: pixels per strip the height heuristic aims at
+  int opt_strip_rows_max = 28;   // profiling: upper bound of the heuristic strip height
   int opt_tile_cols = 0;     // fused pipeline: levels with more classified columns are cut into x-tiles (0 = 704, < 0 = never)
   int opt_orb_in_strip = 0;  // fused pipeline: 1 = strips describe their own keypoints (measured slower: DESIGN.md §8), 0 = k_gather_orb describes all
   int opt_dist_rccl_single = 0;   // test hook: pislam_dist_init(world = 1) still creates a (1-rank) RCCL communicator
@@ -447,6 +449,10 @@ PISLAM_EXPORT int pislam_ctx_set_option(pislam_ctx *c, const char *key, int valu
   } else if (!strcmp(key, "wgs_per_cu")) {
     if (value < 0 || value > 8) return fail(c, PISLAM_ERR_INVALID, "wgs_per_cu must be 0..8");
     c->opt_wgs_per_cu = value;
+  } else if (!strcmp(key, "strip_px")) {
+    c->opt_strip_px = std::max(4096, value);
+  } else if (!strcmp(key, "strip_rows_max")) {
+    c->opt_strip_rows_max = std::max(16, std::min(64, value & ~1));
   } else if (!strcmp(key, "tile_cols")) {
     if (value > 0 && value < 64) return fail(c, PISLAM_ERR_INVALID, "tile_cols must be 0 (default), < 0 (never) or >= 64");
     c->opt_tile_cols = value;
@@ -942,7 +948,7 @@ bool build_fused_plan(const pislam_ctx *c, const pislam_frontend_params *p, cons
     const long budget = 160 * 1024 / wgs - (long)(pf::WAVES * pf::QCAP + pf::QH_SHARED) * 4;
     const int rcap = (int)(budget / tpitch_l - 10) & ~1;
     if (wgs != 5 && rcap < 10) return 0;              // (an explicit residency request falls back to the generic rule)
-    return std::max(16, std::min(std::min(28, std::max(16, (16384 / w) & ~1)), rcap));
+    return std::max(16, std::min(std::min(c->opt_strip_rows_max, std::max(16, (c->opt_strip_px / w) & ~1)), rcap));
   };
   // Residency target of the heuristic: 5 workgroups per CU.  (A search over 5 / 4 / 3 per CU with a cost model
   // "pixels * (R + 4) / R / measured throughput at that residency" was tried for the 1280-wide levels of BASELINE
