@@ -463,6 +463,64 @@ def test_full_batch_properties(gpu_ctx, orc, pipeline):
         assert (np.diff(key) > 0).all()
 
 
+def test_full_batch_properties_1280x960_and_720p_build(gpu_ctx, orc):
+    """BASELINE configs[3] / [4] at their bench sizes (batch 256 / 64; x-tiled wide levels, packed shelves,
+    pyramid built on the device): repeated runs bit-identical, results independent of the batch slot, a
+    sample of slots equal to the oracle (orc_pyramid4), keypoints in reference order inside every level."""
+    import torch
+    from pislam_amd import synth
+    from pislam_amd.frontend import OrbFrontend, PyramidBuilder
+    dev = torch.device("cuda:0")
+    # ---- configs[3]: 1280x960 packed layout, batch 256 (8 distinct pyramids) ----
+    levels = synth.packed_level_table(1280, 960)
+    rows = synth.pyramid_rows(levels)
+    base = synth.make_batch(0, 8, w0=1280, h0=960, vstep=1280, levels=levels)
+    batch = 256
+    idx = torch.arange(batch, device=dev) % 8
+    d_pyr = torch.from_numpy(base).to(dev)[idx].contiguous()
+    fe = OrbFrontend(levels, vstep=1280, rows=rows, max_keypoints=8192, ctx=gpu_ctx)
+    kp, desc, counts = fe.alloc_outputs(batch, dev)
+    fe(d_pyr, kp, desc, counts)
+    torch.cuda.synchronize()
+    c1, k1, d1 = (t.cpu().numpy().view(np.uint32).copy() for t in (counts, kp, desc))
+    fe(d_pyr, kp, desc, counts)
+    torch.cuda.synchronize()
+    c2, k2, d2 = (t.cpu().numpy().view(np.uint32) for t in (counts, kp, desc))
+    assert (c1 == c2).all() and (k1 == k2).all() and (d1 == d2).all()
+    for b in range(8, batch):
+        n = min(int(c1[b]), 8192)
+        assert c1[b] == c1[b % 8] and (k1[b, :n] == k1[b % 8, :n]).all() and (d1[b, :n] == d1[b % 8, :n]).all()
+    for b in (0, 5):
+        okp, odesc, _ = orc.pyramid4(base[b], levels)
+        m = min(len(okp), 8192)
+        assert c1[b] == len(okp) and (k1[b, :m] == okp[:m]).all() and (d1[b, :m] == odesc[:m]).all()
+    redone, strips = fe.last_stats()
+    assert strips > 0 and redone == 0
+    # ---- configs[4]: 64 720p frames -> pyramids built on the device -> ORB ----
+    pb = PyramidBuilder(1280, 720, ctx=gpu_ctx)
+    frames = np.stack([synth.make_level0(100 + i, 1280, 720) for i in range(4)])
+    B = 64
+    d_fr = torch.from_numpy(frames).to(dev)[torch.arange(B, device=dev) % 4].contiguous()
+    d_pyr = torch.zeros((B, pb.rows, pb.vstep), dtype=torch.uint8, device=dev)
+    pb(d_fr, d_pyr)
+    snap = d_pyr.clone()
+    pb(d_fr, d_pyr, margins_clean=True)                     # the bench's steady-state refill
+    torch.cuda.synchronize()
+    assert torch.equal(snap, d_pyr)
+    fe = OrbFrontend(pb.levels, vstep=pb.vstep, rows=pb.rows, max_keypoints=8192, ctx=gpu_ctx)
+    kp, desc, counts = fe.alloc_outputs(B, dev)
+    fe(d_pyr, kp, desc, counts)
+    torch.cuda.synchronize()
+    c, k, d = (t.cpu().numpy().view(np.uint32) for t in (counts, kp, desc))
+    host = d_pyr[:4].cpu().numpy()
+    for b in range(4, B):
+        n = int(c[b])
+        assert c[b] == c[b % 4] and (k[b, :n] == k[b % 4, :n]).all() and (d[b, :n] == d[b % 4, :n]).all()
+    for b in range(2):
+        okp, odesc, _ = orc.pyramid4(host[b], pb.levels)
+        assert c[b] == len(okp) and (k[b, :len(okp)] == okp).all() and (d[b, :len(okp)] == odesc).all()
+
+
 def test_packed_1280x960_layout(gpu_ctx, orc):
     """BASELINE configs[3]: 1280x960, vstep 1280, levels 4|5 and 6|7 side by side (12-bit y limit of
     encodeFast, Util.h:27-29): both pipelines equal the oracle run level by level."""
