@@ -91,6 +91,7 @@ def main():
     ap.add_argument("--xtile-cols", type=int, default=-1)
     ap.add_argument("--run-len", type=int, default=0)
     ap.add_argument("--alias", type=int, default=-1)
+    ap.add_argument("--run-order", type=int, default=-1, help="1 (default): a pyramid's runs are launched longest first; 0: entry order")
     ap.add_argument("--strip-px", type=int, default=0, help="profiling: pixels per strip the height heuristic aims at (default 16384)")
     ap.add_argument("--strip-rows-max", type=int, default=0, help="profiling: upper bound of the heuristic strip height (default 28)")
     ap.add_argument("--tile-cols", type=int, default=0, help="levels with more classified columns are cut into x-tiles (0 = default 704, < 0 never)")
@@ -178,6 +179,8 @@ def main():
     ctx.set_option("lds_pad", args.lds_pad)
     if args.alias >= 0:
         ctx.set_option("alias", args.alias)
+    if args.run_order >= 0:
+        ctx.set_option("run_order", args.run_order)
     if args.strip_px:
         ctx.set_option("strip_px", args.strip_px)
     if args.strip_rows_max:

@@ -37,6 +37,7 @@ typedef __attribute__((address_space(3))) uint32_t lds_u32;
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));   // plain clang vector (uint4 is a class)
 typedef __attribute__((address_space(3))) u32x4 lds_u4;
 
+constexpr int MAX_ORDER = 160;              // runs per pyramid the launch-order table holds
 constexpr int MAX_LEVELS = 24;              // plan entries: levels, wide ones cut into x-tiles (see FusedLevel::gn)
 constexpr int WAVES = 4;               // waves per strip workgroup
 constexpr int NT = WAVES * 64;         // threads per strip workgroup
@@ -93,9 +94,13 @@ struct FusedParams {
   int lbs, limit;    // fastExtract logBucketSize (0 = none; fused path: 2..5) and bucketLimit
   int words;         // orbCompute words (descriptor dwords per keypoint)
   int orb_in_strip;  // ALIAS + 16-byte-aligned kernels: strips describe their own keypoints (strip_body phase E)
+  int order_n;       // > 0: the launch order of a pyramid's runs is order[] (longest first)
   int dump_score;    // debug: also write the score tile to the HBM score map
   int ablate;        // profiling only: bit0 stop after staging, bit1 pretest only, bit2 no Harris, bit3 no NMS
   FusedLevel lv[MAX_LEVELS];
+  // Runs of one pyramid in launch order, longest (estimated) first, so that the short ones fill the tail of
+  // the launch (longest-processing-time-first list scheduling); plans with more runs keep entry order.
+  uint32_t order[MAX_ORDER];                       // entry << 16 | run inside the entry (dwords: scalar loads)
 };
 
 // Workgroup barrier that orders LDS traffic only (s_waitcnt lgkmcnt(0); s_barrier).  __syncthreads()
@@ -1088,8 +1093,14 @@ __global__ __launch_bounds__(NT) void k_fused_strips(
   if (pyr >= P.batch) return;
   int run = slot / groups;
   int li = 0;
-  while (li + 1 < P.nlevels && run >= P.lv[li + 1].run0) li++;
-  run -= P.lv[li].run0;
+  if (P.order_n > 0) {
+    const uint32_t o = P.order[run];
+    li = (int)(o >> 16);
+    run = (int)(o & 0xffffu);
+  } else {
+    while (li + 1 < P.nlevels && run >= P.lv[li + 1].run0) li++;
+    run -= P.lv[li].run0;
+  }
   // A workgroup walks a RUN of consecutive strips of one level, top to bottom.  From the second strip
   // on, the 10 halo image rows and the 3 halo score rows it shares with the strip above are carried
   // over inside LDS (strip_body `carry`), so a run behaves like one strip of run_len * R rows at the

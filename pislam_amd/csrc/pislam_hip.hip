@@ -113,6 +113,7 @@ struct pislam_ctx {
   int opt_wgs_per_cu = 0;    // fused pipeline: if > 0, size strip heights for this many workgroups per CU
   int opt_strip_px = 16384;  // profiling: pixels per strip the height heuristic aims at
   int opt_strip_rows_max = 28;   // profiling: upper bound of the heuristic strip height
+  int opt_run_order = 1;     // fused pipeline: launch a pyramid's runs longest first (0: in entry order)
   int opt_tile_cols = 0;     // fused pipeline: levels with more classified columns are cut into x-tiles (0 = 704, < 0 = never)
   int opt_orb_in_strip = 0;  // fused pipeline: 1 = strips describe their own keypoints (measured slower: DESIGN.md §8), 0 = k_gather_orb describes all
   int opt_dist_rccl_single = 0;   // test hook: pislam_dist_init(world = 1) still creates a (1-rank) RCCL communicator
@@ -449,6 +450,8 @@ PISLAM_EXPORT int pislam_ctx_set_option(pislam_ctx *c, const char *key, int valu
   } else if (!strcmp(key, "wgs_per_cu")) {
     if (value < 0 || value > 8) return fail(c, PISLAM_ERR_INVALID, "wgs_per_cu must be 0..8");
     c->opt_wgs_per_cu = value;
+  } else if (!strcmp(key, "run_order")) {
+    c->opt_run_order = value != 0;
   } else if (!strcmp(key, "strip_px")) {
     c->opt_strip_px = std::max(4096, value);
   } else if (!strcmp(key, "strip_rows_max")) {
@@ -1101,16 +1104,45 @@ bool build_fused_plan(const pislam_ctx *c, const pislam_frontend_params *p, cons
   // worth ~3 % at best and the curve is dispatch-quantisation noise; 720p batch 64 (10 strips per slot): 0.208 /
   // 0.207 / 0.216 / 0.227 / 0.238 for 1..5; 1280x960 batch 256 (54 per slot): 1.029 / 1.018 / 1.012 / 1.044 / 1.053 /
   // 1.010 for 4 / 5 / 6 / 7 / 8..10 / 12, batch 64: 0.278 / 0.307 / 0.376 for 2 / 3 / 8; VGA batch 32, 64: 1 is best.
-  // Rule: ~6.5 workgroups per resident slot, at most 6 strips per run.  (List-scheduling and processor-sharing
+  // Rule: ~6.5 workgroups per resident slot, at most 8 strips per run.  (List-scheduling and processor-sharing
   // simulations of one XCD were tried as a predictor: neither tracks the measured 2-3 % structure.)
+  // With the runs of a pyramid launched longest first (order[], below) the curve flattens: VGA batch 256
+  // 0.232 / 0.222 / 0.220 / 0.224 / 0.222 / 0.233 for run_len 1 / 2 / 3 / 4 / 6 / 8; 1280x960 batch 256 0.920 / 0.898 /
+  // 0.899 / 0.889 / 0.889 for 2 / 4 / 6 / 8 / 12; 720p batch 64 0.191 / 0.191 / 0.197 / 0.206 for 1 / 2 / 3 / 4.
   {
     const double per_slot = (double)strips * batch / (5.0 * std::max(1, c->num_cus));
-    F->run_len = c->opt_run_len > 0 ? c->opt_run_len : std::max(1, std::min(6, (int)(per_slot / 6.5 + 0.5)));
+    F->run_len = c->opt_run_len > 0 ? c->opt_run_len : std::max(1, std::min(8, (int)(per_slot / 6.5 + 0.5)));
   }
   for (int l = 0; l < F->nlevels; l++) {
     F->lv[l].run0 = runs;
     F->lv[l].nruns = cdiv(F->lv[l].nstrips, F->run_len);
     runs += F->lv[l].nruns;
+  }
+  // Launch order of a pyramid's runs: estimated cost (pixels + a fixed share per strip), longest first — the
+  // longest-processing-time-first rule of list scheduling: workgroups are dispatched in blockIdx order to the
+  // 5 resident slots per CU, so the short runs of the small levels fill the tail of the launch.  Entry order
+  // (level by level) interleaves short last-runs of big levels with long runs of the next level: VGA batch 256
+  // 0.232 -> 0.222 ms, 1280x960 batch 256 0.927 -> 0.895 ms.
+  F->order_n = 0;
+  if (runs > 0 && runs <= pf::MAX_ORDER && c->opt_run_order) {
+    struct RunCost {
+      double cost;
+      int entry, run;
+    };
+    std::vector<RunCost> rc;
+    for (int l = 0; l < F->nlevels; l++) {
+      const pf::FusedLevel &L = F->lv[l];
+      const int ny = L.h - 2 * p->border;
+      for (int r = 0; r < L.nruns; r++) {
+        double cst = 0;
+        for (int sidx = r * F->run_len; sidx < std::min((r + 1) * F->run_len, L.nstrips); sidx++)
+          cst += 1.6 * L.w * std::min(L.R, ny - sidx * L.R) + 6000.0;
+        rc.push_back({cst, l, r});
+      }
+    }
+    std::stable_sort(rc.begin(), rc.end(), [](const RunCost &a, const RunCost &b) { return a.cost > b.cost; });
+    for (size_t i = 0; i < rc.size(); i++) F->order[i] = ((uint32_t)rc[i].entry << 16) | (uint32_t)rc[i].run;
+    F->order_n = (int)rc.size();
   }
   F->strips_per_pyr = strips;
   F->runs_per_pyr = runs;
