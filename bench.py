@@ -99,6 +99,9 @@ def main():
     ap.add_argument("--graph", type=int, default=1,
                     help="1 (default): capture the step's launches into a hipGraph (torch.cuda.CUDAGraph) per output set "
                          "and replay it — falls back to eager launches if the capture or its check fails; 0: eager")
+    ap.add_argument("--streams", type=int, default=3,
+                    help="independent pipelines (HIP stream + context + outputs + graph); step k runs on pipeline "
+                         "k %% S, so consecutive batches overlap on the GPU (default 3; 1 = strictly one batch at a time)")
     ap.add_argument("--match", action="store_true",
                     help="also match every pyramid's descriptors against its neighbour's inside the step (SURVEY 8f-4)")
     ap.add_argument("--lds-pad", type=int, default=0, help="profiling only: extra LDS per strip workgroup")
@@ -169,136 +172,183 @@ def main():
     B = args.batch
     distinct = args.distinct or (B if args.workload == "vga" else min(B, 16))
     first = rank * B
-    if args.graph:                                     # graph capture needs a non-default stream
-        torch.cuda.set_stream(torch.cuda.Stream(dev))
-    stream = torch.cuda.current_stream(dev)
-    ctx = Context(device=local_rank, stream=stream.cuda_stream)
-    ctx.set_option("pipeline", args.pipeline)
-    ctx.set_option("strip_rows", args.strip_rows)
-    ctx.set_option("orb_chunks", args.orb_chunks)
-    ctx.set_option("lds_pad", args.lds_pad)
-    if args.alias >= 0:
-        ctx.set_option("alias", args.alias)
-    if args.run_order >= 0:
-        ctx.set_option("run_order", args.run_order)
-    if args.strip_px:
-        ctx.set_option("strip_px", args.strip_px)
-    if args.strip_rows_max:
-        ctx.set_option("strip_rows_max", args.strip_rows_max)
-    if args.tile_cols:
-        ctx.set_option("tile_cols", args.tile_cols)
-    if args.orb_in_strip >= 0:
-        ctx.set_option("orb_in_strip", args.orb_in_strip)
-    if args.run_len:
-        ctx.set_option("run_len", args.run_len)
-    if args.xtile_cols >= 0:
-        ctx.set_option("xtile_cols", args.xtile_cols)
-    if args.wgs_per_cu:
-        ctx.set_option("wgs_per_cu", args.wgs_per_cu)
-    ctx.set_option("ablate", args.ablate)
+    S = 1 if args.match else max(1, args.streams)
+    force = args.force_exchange and world == 1
+    # Output sets per pipeline: with one pipeline the consumer of step i's outputs — the all-gather of its counts
+    # on the collective stream — overlaps step i+1 computing into a second set; with several pipelines the
+    # other pipelines' steps do.
+    nsets = 2 if (S == 1 and (world > 1 or force)) else 1
+
+    def make_context(stream):
+        c = Context(device=local_rank, stream=stream.cuda_stream)
+        c.set_option("pipeline", args.pipeline)
+        c.set_option("strip_rows", args.strip_rows)
+        c.set_option("orb_chunks", args.orb_chunks)
+        c.set_option("lds_pad", args.lds_pad)
+        if args.alias >= 0:
+            c.set_option("alias", args.alias)
+        if args.run_order >= 0:
+            c.set_option("run_order", args.run_order)
+        if args.strip_px:
+            c.set_option("strip_px", args.strip_px)
+        if args.strip_rows_max:
+            c.set_option("strip_rows_max", args.strip_rows_max)
+        if args.tile_cols:
+            c.set_option("tile_cols", args.tile_cols)
+        if args.orb_in_strip >= 0:
+            c.set_option("orb_in_strip", args.orb_in_strip)
+        if args.run_len:
+            c.set_option("run_len", args.run_len)
+        if args.xtile_cols >= 0:
+            c.set_option("xtile_cols", args.xtile_cols)
+        if args.wgs_per_cu:
+            c.set_option("wgs_per_cu", args.wgs_per_cu)
+        c.set_option("ablate", args.ablate)
+        return c
+
+    # ---- the resident input (shared by every pipeline; the 720p workload builds its pyramids per pipeline) ----
+    host = d_frames = d_pyr0 = None
     if args.workload == "720p-build":
-        builder = PyramidBuilder(w0, h0, ctx=ctx)
-        levels, vstep = builder.levels, builder.vstep
-        rows = builder.rows
         fr = np.stack([synth.make_level0(first + i, w0, h0) for i in range(min(distinct, B))])
         d_frames = torch.from_numpy(fr).to(dev)
         if distinct < B:
             d_frames = d_frames[torch.arange(B, device=dev) % distinct].contiguous()
-        d_pyr = torch.empty((B, rows, vstep), dtype=torch.uint8, device=dev)
-        builder(d_frames, d_pyr)
-        torch.cuda.synchronize()
-        host = d_pyr[:min(distinct, B)].cpu().numpy()
     else:
         rows = synth.pyramid_rows(levels)
         host = synth.make_batch(first, min(distinct, B), w0=w0, h0=h0, vstep=vstep, levels=levels)
-        d_pyr = torch.from_numpy(host).to(dev)
+        d_pyr0 = torch.from_numpy(host).to(dev)
         if distinct < B:
-            d_pyr = d_pyr[torch.arange(B, device=dev) % distinct].contiguous()
+            d_pyr0 = d_pyr0[torch.arange(B, device=dev) % distinct].contiguous()
 
-    fe = OrbFrontend(levels, vstep=vstep, rows=rows, max_keypoints=args.max_keypoints, ctx=ctx,
-                     log_bucket_size=args.log_bucket_size, bucket_limit=args.bucket_limit)
-    fe.reserve(B)
-    kp, desc, counts = fe.alloc_outputs(B, dev)
+    # ---- S independent pipelines: batch k runs on pipeline k % S — its own HIP stream, context (workspace),
+    # outputs and hipGraph — so that the gather+ORB kernel of one batch (latency / LDS bound) and the tail of its
+    # strip kernel run under the strip kernel of the next batch (VALU bound).  Every batch is still processed
+    # completely (strips -> overflow pass -> gather+ORB, then the count all-gather) inside the timed region.
+    class Pipe:
+        pass
+
+    pipes = []
+    rccl_note = None
+    for i in range(S):
+        P = Pipe()
+        P.stream = torch.cuda.Stream(dev)
+        P.ctx = make_context(P.stream)
+        P.builder = None
+        with torch.cuda.stream(P.stream):
+            if args.workload == "720p-build":
+                P.builder = PyramidBuilder(w0, h0, ctx=P.ctx)
+                levels, vstep, rows = P.builder.levels, P.builder.vstep, P.builder.rows
+                P.d_pyr = torch.empty((B, rows, vstep), dtype=torch.uint8, device=dev)
+                P.builder(d_frames, P.d_pyr)
+                torch.cuda.synchronize()
+                if host is None:
+                    host = P.d_pyr[:min(distinct, B)].cpu().numpy()
+            else:
+                P.d_pyr = d_pyr0
+            P.fe = OrbFrontend(levels, vstep=vstep, rows=rows, max_keypoints=args.max_keypoints, ctx=P.ctx,
+                               log_bucket_size=args.log_bucket_size, bucket_limit=args.bucket_limit)
+            P.fe.reserve(B)
+            P.outs = [P.fe.alloc_outputs(B, dev) for _ in range(nsets)]
+        # The count all-gather goes through the C ABI (pislam_dist_*: RCCL communicator from a unique id,
+        # ncclAllGather on the context's collective stream), one communicator per pipeline context.  Ranks
+        # sharing one GPU (gloo test mode) cannot form an RCCL communicator; if the C-ABI path fails on any
+        # rank, all ranks fall back to torch.distributed's all-gather and the JSON line says so.
+        err = None
+        if world > 1 and args.dist_backend == "gloo":
+            err = "test mode: ranks share a GPU"
+        elif world > 1:
+            err = pdist.init_rccl(P.ctx, rank, world, dev)
+            if err and rank == 0:
+                print(f"[bench] C-ABI RCCL path unavailable, using torch.distributed: {err}", file=sys.stderr)
+        if force:
+            from pislam_amd import capi
+            P.ctx.set_option("dist_rccl_single", 1)
+            P.ctx.dist_init(capi.dist_unique_id(), 0, 1)
+        P.xchg = pdist.CountExchange(world, ctx=P.ctx if ((world > 1 and err is None) or force) else None,
+                                     always_collective=force, sets=nsets)
+        rccl_note = rccl_note or err
+        pipes.append(P)
+    ctx, fe, builder, d_pyr = pipes[0].ctx, pipes[0].fe, pipes[0].builder, pipes[0].d_pyr
+    stream = pipes[0].stream
+    kp, desc, counts = pipes[0].outs[0]
+    xchg = pipes[0].xchg
 
     m_out = None
     if args.match:
         # train side: the neighbouring pyramid's descriptors (static inputs -> made once, outside the step)
         from pislam_amd.frontend import matchHammingBatch
-        fe(d_pyr, kp, desc, counts)
+        with torch.cuda.stream(stream):
+            fe(d_pyr, kp, desc, counts)
         torch.cuda.synchronize()
         t_desc, t_counts = torch.roll(desc, 1, 0).contiguous(), torch.roll(counts, 1, 0).contiguous()
         m_out = [torch.empty((B, args.max_keypoints), dtype=torch.int32, device=dev) for _ in range(3)]
-
-    # Two output sets, alternating per step: the consumer of step i's outputs — here the all-gather of its
-    # counts (pislam_amd.dist.CountExchange, on RCCL's own stream) — overlaps step i+1's kernels.
-    outs = [(kp, desc, counts)] + ([fe.alloc_outputs(B, dev)] if world > 1 else [])
-    # The count all-gather goes through the C ABI (pislam_dist_*: RCCL communicator from a unique id,
-    # ncclAllGather on the context's collective stream).  Ranks sharing one GPU (gloo test mode) cannot form
-    # an RCCL communicator; if the C-ABI path fails on any rank, all ranks fall back to torch.distributed's
-    # all-gather and the JSON line says so.
-    rccl_err = None
-    if world > 1 and args.dist_backend == "gloo":
-        rccl_err = "test mode: ranks share a GPU"
-    elif world > 1:
-        rccl_err = pdist.init_rccl(ctx, rank, world, dev)
-        if rccl_err and rank == 0:
-            print(f"[bench] C-ABI RCCL path unavailable, using torch.distributed: {rccl_err}", file=sys.stderr)
-    force = args.force_exchange and world == 1
-    if force:
-        from pislam_amd import capi
-        ctx.set_option("dist_rccl_single", 1)
-        ctx.dist_init(capi.dist_unique_id(), 0, 1)
-        outs.append(fe.alloc_outputs(B, dev))           # two output sets, as with N > 1
-    xchg = pdist.CountExchange(world, ctx=ctx if ((world > 1 and rccl_err is None) or force) else None, always_collective=force)
     nstep = [0]
 
-    def launches(k_, d_, c_):
-        if builder is not None:
+    def launches(P, k_, d_, c_):
+        if P.builder is not None:
             # steady state of a stream: the same pyramid buffer is refilled every step by the same builder
             # (its first fill, before the timed region, established the zero margins)
-            builder(d_frames, d_pyr, margins_clean=True)
-        fe(d_pyr, k_, d_, c_)
+            P.builder(d_frames, P.d_pyr, margins_clean=True)
+        P.fe(P.d_pyr, k_, d_, c_)
         if m_out is not None:
-            matchHammingBatch(d_, c_, t_desc, t_counts, *m_out, ctx=ctx)
+            matchHammingBatch(d_, c_, t_desc, t_counts, *m_out, ctx=P.ctx)
 
-    graphs = None
+    use_graphs = False
     if args.graph:
         # The batch call allocates nothing and never synchronises once the workspace is reserved, so a step's
         # launches can be replayed from a hipGraph.  Any failure (capture error, replay not reproducing the
         # eager counts) falls back to eager launches: the measurement must never depend on this.
         try:
-            for o in outs:
-                launches(*o)                            # warm-up outside the capture (allocations, module load)
+            for P in pipes:
+                with torch.cuda.stream(P.stream):
+                    for o in P.outs:
+                        launches(P, *o)                 # warm-up outside the capture (allocations, module load)
             torch.cuda.synchronize()
-            want = [o[2].clone() for o in outs]
-            graphs = []
-            for o in outs:
-                g = torch.cuda.CUDAGraph()
-                # thread_local: API calls of other threads (the RCCL watchdog of a multi-rank run) must not
-                # invalidate the capture
-                with torch.cuda.graph(g, stream=stream, capture_error_mode="thread_local"):
-                    launches(*o)
-                graphs.append(g)
-            for o, g, w in zip(outs, graphs, want):
-                o[2].zero_()
-                g.replay()
-                torch.cuda.synchronize()
-                if not torch.equal(o[2], w):
-                    raise RuntimeError("graph replay does not reproduce the eager result")
+            for P in pipes:
+                want = [o[2].clone() for o in P.outs]
+                P.graphs = []
+                for o in P.outs:
+                    g = torch.cuda.CUDAGraph()
+                    # thread_local: API calls of other threads (the RCCL watchdog of a multi-rank run) must not
+                    # invalidate the capture
+                    with torch.cuda.graph(g, stream=P.stream, capture_error_mode="thread_local"):
+                        launches(P, *o)
+                    P.graphs.append(g)
+                for o, g, w in zip(P.outs, P.graphs, want):
+                    o[2].zero_()
+                    torch.cuda.synchronize()
+                    with torch.cuda.stream(P.stream):
+                        g.replay()
+                    torch.cuda.synchronize()
+                    if not torch.equal(o[2], w):
+                        raise RuntimeError("graph replay does not reproduce the eager result")
+            use_graphs = True
         except Exception as e:                          # noqa: BLE001
             print(f"[bench] hipGraph path disabled: {e!r}", file=sys.stderr)
-            graphs = None
             torch.cuda.synchronize()
+    graphs = pipes[0].graphs if use_graphs else None
 
     def step():
-        i = nstep[0] % len(outs)
+        k = nstep[0]
         nstep[0] += 1
-        xchg.before_step()                              # the launch stream waits for the all-gather of step i-2
-        if graphs is not None:
-            graphs[i].replay()
-        else:
-            launches(*outs[i])
-        xchg.start(outs[i][2])
+        P = pipes[k % S]
+        i = (k // S) % nsets
+        with torch.cuda.stream(P.stream):
+            P.xchg.before_step()                        # this pipeline's stream waits for the all-gather that read set i
+            if use_graphs:
+                P.graphs[i].replay()
+            else:
+                launches(P, *P.outs[i])
+            P.xchg.start(P.outs[i][2])
+        return P
+
+    def spin_once():
+        for P in pipes:
+            with torch.cuda.stream(P.stream):
+                if use_graphs:
+                    P.graphs[0].replay()
+                else:
+                    launches(P, *P.outs[0])
 
     # Clock ramp: the GPU idles at a few hundred MHz and needs a fraction of a second of load to reach its
     # sustained clocks — far longer than a handful of 0.4 ms steps.  Spin the same step, untimed, before the W
@@ -307,23 +357,26 @@ def main():
     t_spin = time.perf_counter()
     while time.perf_counter() - t_spin < args.spin_s:
         for _ in range(8):
-            if graphs is not None:
-                graphs[0].replay()
-            else:
-                launches(*outs[0])
+            spin_once()
         torch.cuda.synchronize()
     for _ in range(args.warmup):
         step()
-    xchg.finish()
+    for P in pipes:
+        P.xchg.finish()
     torch.cuda.synchronize()
     if world > 1:
         torch.distributed.barrier()
     torch.cuda.synchronize()
     nstep[0] = 0
     t0 = time.perf_counter()
+    last = None
     for _ in range(args.steps):
-        step()
-    allc = xchg.finish()                                # every step's all-gather has completed
+        last = step()
+    allc = None
+    for P in pipes:                                     # every step's all-gather has completed
+        r = P.xchg.finish()
+        if P is last:
+            allc = r
     torch.cuda.synchronize()
     if world > 1:
         torch.distributed.barrier()
@@ -435,6 +488,10 @@ def main():
                 "parallelism": f"pyramid-shard x{world}, RCCL all-gather of counts" if world > 1 else "single GPU",
                 "pipeline": "fused" if fused else "staged",
                 "launch": "hipGraph replay" if graphs is not None else "eager",
+                "streams": S,
+                "batches_in_flight": f"{S}: step k runs on pipeline k % {S} (own HIP stream, context/workspace, outputs, "
+                                     "graph); each step is one whole batch, all K steps start and finish inside the "
+                                     "timed region" if S > 1 else "1",
                 "strips_redone_by_overflow_pass": f"{deferred} of {nstrips}",
                 "max_keypoints": args.max_keypoints, "pyramids_over_capacity": capped,
                 "count_allgather": xchg.path,
@@ -444,7 +501,8 @@ def main():
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_source,
                 "traffic_whole_step": traffic_step,
-                "kernel": "pf::k_fused_strips (hipEvents on the launch stream around 16 back-to-back launches, / 16)" if fused
+                "kernel": "pf::k_fused_strips (hipEvents on the launch stream around 16 back-to-back launches, / 16, measured after "
+                          "the timed region with the other pipelines idle)" if fused
                           else "whole staged step (all launches)",
                 "algorithmic_bytes_per_launch": b_alg_launch, "launch_ms": launch_ms,
                 "step_gpu_ms": ev_total_ms,
@@ -457,10 +515,11 @@ def main():
         print(json.dumps(out))
     if world > 1:
         torch.distributed.barrier()
-        try:
-            ctx.dist_finalize()                          # our RCCL communicator first, while every rank is still alive
-        except Exception:                                # noqa: BLE001
-            pass
+        for P in pipes:
+            try:
+                P.ctx.dist_finalize()                    # our RCCL communicators first, while every rank is still alive
+            except Exception:                            # noqa: BLE001
+                pass
         torch.distributed.destroy_process_group()
 
 

@@ -122,12 +122,13 @@ class CountExchange:
     `ctx` (a capi.Context on which init_rccl succeeded) selects the C-ABI RCCL path; without it the
     exchange uses torch.distributed (gloo test mode, or the fallback bench.py reports as such)."""
 
-    def __init__(self, world: int, ctx=None, always_collective: bool = False):
+    def __init__(self, world: int, ctx=None, always_collective: bool = False, sets: int = 2):
         self.world = world
+        self.sets = sets                     # output sets the caller alternates between on this context (1 or 2)
         self.ctx = ctx
         self.always = always_collective      # tests: run the collective path on a 1-rank group too
-        self.pending = [None, None]          # torch path: (work, out) per output set
-        self.outs = [None, None]             # C-ABI path: gathered counts per output set
+        self.pending = [None] * sets         # torch path: (work, out) per output set
+        self.outs = [None] * sets            # C-ABI path: gathered counts per output set
         self.last = None
         self.i = 0
 
@@ -139,19 +140,19 @@ class CountExchange:
 
     def before_step(self):
         """Call before enqueueing a step: the step overwrites the counts buffer whose all-gather was started
-        two steps ago, so the launch stream first waits (on the device) for that collective."""
+        `sets` steps ago (on this context), so the launch stream first waits (on the device) for that collective."""
         if self.world == 1 and not self.always:
             return
         if self.ctx is not None:
-            self.ctx.dist_fence(2)
+            self.ctx.dist_fence(self.sets)
             return
-        prev = self.pending[self.i & 1]
+        prev = self.pending[self.i % self.sets]
         if prev is not None:
             prev[0].wait()
-            self.pending[self.i & 1] = None
+            self.pending[self.i % self.sets] = None
 
     def start(self, local_counts: torch.Tensor):
-        slot = self.i & 1
+        slot = self.i % self.sets
         self.i += 1
         if self.world == 1 and not self.always:
             self.last = local_counts

@@ -770,9 +770,10 @@ def test_count_exchange_through_the_c_abi(rccl):
 
 
 def test_bench_step_with_the_c_abi_exchange_on_one_rank():
-    """bench.py's N>1 step structure on this 1-GPU box: two output sets, hipGraph replays on the launch stream,
-    the count all-gather of every step through pislam_dist_* on the collective stream (a 1-rank RCCL
-    communicator), fences for buffer reuse — and the same keypoint totals as the plain run."""
+    """bench.py's N>1 step structure on this 1-GPU box: hipGraph replays on the launch stream(s), the count
+    all-gather of every step through pislam_dist_* on the collective stream (a 1-rank RCCL communicator per
+    pipeline context), fences for buffer reuse — with one pipeline and two output sets, and with 2 / 3
+    pipelines (batches in flight on separate HIP streams) — and the same keypoint totals as the plain run."""
     import json
     import os
     import subprocess
@@ -780,15 +781,19 @@ def test_bench_step_with_the_c_abi_exchange_on_one_rank():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict({k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}, HSA_ENABLE_IPC_MODE_LEGACY="0")
     res = []
-    for extra in ([], ["--force-exchange"]):
+    for extra in (["--streams", "1"], ["--streams", "1", "--force-exchange"], ["--streams", "2", "--force-exchange"],
+                  ["--streams", "3", "--force-exchange"], []):
         out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "7", "--warmup", "2", "--batch", "16",
                               "--no-cpu-baseline", "--spin-s", "0.1"] + extra, capture_output=True, text=True, timeout=300,
                              cwd=root, env=env)
         assert out.returncode == 0, out.stderr[-2000:]
         res.append(json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1]))
-    assert "C ABI" in res[1]["config"]["count_allgather"] and "none" in res[0]["config"]["count_allgather"]
-    assert res[0]["config"]["keypoints_per_pyramid"] == res[1]["config"]["keypoints_per_pyramid"] > 100
-    assert res[1]["config"]["launch"] == res[0]["config"]["launch"]
+    assert "none" in res[0]["config"]["count_allgather"] and "none" in res[4]["config"]["count_allgather"]
+    for r, s in zip(res[1:4], (1, 2, 3)):
+        assert "C ABI" in r["config"]["count_allgather"] and r["config"]["streams"] == s
+        assert r["config"]["keypoints_per_pyramid"] == res[0]["config"]["keypoints_per_pyramid"] > 100
+        assert r["config"]["launch"] == res[0]["config"]["launch"] == "hipGraph replay"
+    assert res[4]["config"]["keypoints_per_pyramid"] == res[0]["config"]["keypoints_per_pyramid"]
 
 
 def test_bench_self_launch_two_ranks_sharing_this_gpu():

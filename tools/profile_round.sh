@@ -10,33 +10,26 @@ cd /tmp && export TMPDIR=/tmp
 python $root/bench.py --steps 20 --warmup 5 > $out/bench_vga.json 2> $out/bench_vga.err
 python $root/bench.py --steps 20 --warmup 5 --workload 1280x960 --batch 256 --cpu-seconds 5 > $out/bench_1280x960.json 2> $out/bench_1280x960.err
 python $root/bench.py --steps 20 --warmup 5 --workload 720p-build --batch 64 --cpu-seconds 5 > $out/bench_720p_build.json 2> $out/bench_720p_build.err
+python $root/bench.py --steps 20 --warmup 5 --streams 1 --no-cpu-baseline > $out/bench_vga_streams1.json 2> /dev/null
 python $root/bench.py --steps 20 --warmup 5 --log-bucket-size 4 --bucket-limit 3 --no-cpu-baseline > $out/bench_vga_buckets43.json 2> /dev/null
 for w in vga 1280x960 720p-build; do
   b=256; [ $w = 720p-build ] && b=64
   rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace_$w -o p -- python $root/bench.py --steps 20 --warmup 5 --no-cpu-baseline --workload $w --batch $b > $out/bench_under_rocprof_$w.json 2>/dev/null
   cp $out/trace_$w/p_kernel_stats.csv $out/kernel_stats_$w.csv
+  # one batch at a time: per-kernel durations without another batch's kernels sharing the GPU (these are the
+  # durations roofline.launch_ms has to agree with)
+  rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace1_$w -o p -- python $root/bench.py --steps 20 --warmup 5 --no-cpu-baseline --streams 1 --workload $w --batch $b > /dev/null 2>&1
+  cp $out/trace1_$w/p_kernel_stats.csv $out/kernel_stats_${w}_streams1.csv
 done
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $root/gpurun_out/${tag}hbm_fetch -o p -- python $root/bench.py --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $root/gpurun_out/${tag}hbm_write -o p -- python $root/bench.py --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
-rocprofv3 --kernel-trace --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_HIT_sum TCC_MISS_sum --output-format csv -d $root/gpurun_out/${tag}hbm_tcc -o p -- python $root/bench.py --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
-rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VMEM_RD SQ_WAIT_INST_ANY --output-format csv -d $out/pmc_sq -o p -- python $root/bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $root/gpurun_out/${tag}hbm_fetch -o p -- python $root/bench.py --steps 3 --warmup 1 --streams 1 --no-cpu-baseline > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $root/gpurun_out/${tag}hbm_write -o p -- python $root/bench.py --steps 3 --warmup 1 --streams 1 --no-cpu-baseline > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_HIT_sum TCC_MISS_sum --output-format csv -d $root/gpurun_out/${tag}hbm_tcc -o p -- python $root/bench.py --steps 3 --warmup 1 --streams 1 --no-cpu-baseline > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VMEM_RD SQ_WAIT_INST_ANY --output-format csv -d $out/pmc_sq -o p -- python $root/bench.py --steps 2 --warmup 1 --streams 1 --no-cpu-baseline > /dev/null 2>&1
 cd $root
 python tools/hbm_traffic.py ${tag}hbm $out/hbm_traffic.json "round 2 kernels"
-python - <<P
-import csv, collections
-for name in ("fetch", "write"):
-    rows = list(csv.DictReader(open("gpurun_out/${tag}hbm_%s/p_counter_collection.csv" % name)))
-    keep = [r for r in rows if "pf::" in r["Kernel_Name"]]
-    w = csv.DictWriter(open("$out/pmc_%s_size.csv" % name, "w"), fieldnames=rows[0].keys()); w.writeheader(); w.writerows(keep)
-rows = list(csv.DictReader(open("$out/pmc_sq/p_counter_collection.csv")))
-keep = [r for r in rows if "pf::" in r["Kernel_Name"]]
-w = csv.DictWriter(open("$out/pmc_sq_counters.csv", "w"), fieldnames=rows[0].keys()); w.writeheader(); w.writerows(keep)
-agg = collections.defaultdict(lambda: collections.defaultdict(float)); n = collections.defaultdict(collections.Counter)
-for r in keep:
-    k = r["Kernel_Name"].split("(")[0].split("::")[-1].split("<")[0]
-    agg[k][r["Counter_Name"]] += float(r["Counter_Value"]); n[k][r["Counter_Name"]] += 1
-for k, d in agg.items():
-    print(k, {c: round(v / n[k][c] / 1e6, 2) for c, v in d.items()})
-P
-rm -rf $out/trace_* $out/pmc_sq
+python tools/pmc_aggregate.py gpurun_out/${tag}hbm_fetch/p_counter_collection.csv $out/pmc_fetch_size.csv
+python tools/pmc_aggregate.py gpurun_out/${tag}hbm_write/p_counter_collection.csv $out/pmc_write_size.csv
+python tools/pmc_aggregate.py $out/pmc_sq/p_counter_collection.csv $out/pmc_sq_counters.csv
+cat $out/pmc_sq_counters.csv | cut -d, -f1-4
+rm -rf $out/trace_* $out/trace1_* $out/pmc_sq
 ls -la $out
