@@ -93,7 +93,7 @@ def main():
     ap.add_argument("--alias", type=int, default=-1)
     ap.add_argument("--run-order", type=int, default=-1, help="1 (default): a pyramid's runs are launched longest first; 0: entry order")
     ap.add_argument("--strip-px", type=int, default=0, help="profiling: pixels per strip the height heuristic aims at (default 16384)")
-    ap.add_argument("--strip-rows-max", type=int, default=0, help="profiling: upper bound of the heuristic strip height (default 28)")
+    ap.add_argument("--strip-rows-max", type=int, default=0, help="profiling: upper bound of the heuristic strip height (default: 56 for large launches, 28 for small ones)")
     ap.add_argument("--tile-cols", type=int, default=0, help="levels with more classified columns are cut into x-tiles (0 = default 704, < 0 never)")
     ap.add_argument("--orb-in-strip", type=int, default=-1, help="1: strips describe their own keypoints; 0 (default): one gather+ORB pass")
     ap.add_argument("--graph", type=int, default=1,

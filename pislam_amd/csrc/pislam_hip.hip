@@ -112,7 +112,7 @@ struct pislam_ctx {
   int opt_lds_pad = 0;       // profiling only: extra dynamic LDS bytes per strip workgroup
   int opt_wgs_per_cu = 0;    // fused pipeline: if > 0, size strip heights for this many workgroups per CU
   int opt_strip_px = 16384;  // profiling: pixels per strip the height heuristic aims at
-  int opt_strip_rows_max = 28;   // profiling: upper bound of the heuristic strip height
+  int opt_strip_rows_max = 0;    // profiling: upper bound of the heuristic strip height (0 = rule in build_fused_plan)
   int opt_run_order = 1;     // fused pipeline: launch a pyramid's runs longest first (0: in entry order)
   int opt_tile_cols = 0;     // fused pipeline: levels with more classified columns are cut into x-tiles (0 = 704, < 0 = never)
   int opt_orb_in_strip = 0;  // fused pipeline: 1 = strips describe their own keypoints (measured slower: DESIGN.md §8), 0 = k_gather_orb describes all
@@ -455,7 +455,7 @@ PISLAM_EXPORT int pislam_ctx_set_option(pislam_ctx *c, const char *key, int valu
   } else if (!strcmp(key, "strip_px")) {
     c->opt_strip_px = std::max(4096, value);
   } else if (!strcmp(key, "strip_rows_max")) {
-    c->opt_strip_rows_max = std::max(16, std::min(64, value & ~1));
+    c->opt_strip_rows_max = value <= 0 ? 0 : std::max(16, std::min(64, value & ~1));
   } else if (!strcmp(key, "tile_cols")) {
     if (value > 0 && value < 64) return fail(c, PISLAM_ERR_INVALID, "tile_cols must be 0 (default), < 0 (never) or >= 64");
     c->opt_tile_cols = value;
@@ -922,8 +922,8 @@ namespace {
 
 // Strip plan of the fused pipeline.  Strip height per level: aim at ~8k pixels per workgroup,
 // even, 16..32 rows (override: option "strip_rows").
-bool build_fused_plan(const pislam_ctx *c, const pislam_frontend_params *p, const pislam_level *lv,
-                      int batch, pf::FusedParams *F, size_t *lds_bytes, size_t *lds_alias_bytes) {
+bool build_fused_plan_rows(const pislam_ctx *c, const pislam_frontend_params *p, const pislam_level *lv,
+                           int batch, int rows_max, pf::FusedParams *F, size_t *lds_bytes, size_t *lds_alias_bytes) {
   if (p->nlevels > pf::MAX_LEVELS) return false;
   memset(F, 0, sizeof(*F));
   F->vstep = p->vstep;
@@ -951,7 +951,7 @@ bool build_fused_plan(const pislam_ctx *c, const pislam_frontend_params *p, cons
     const long budget = 160 * 1024 / wgs - (long)(pf::WAVES * pf::QCAP + pf::QH_SHARED) * 4;
     const int rcap = (int)(budget / tpitch_l - 10) & ~1;
     if (wgs != 5 && rcap < 10) return 0;              // (an explicit residency request falls back to the generic rule)
-    return std::max(16, std::min(std::min(c->opt_strip_rows_max, std::max(16, (c->opt_strip_px / w) & ~1)), rcap));
+    return std::max(16, std::min(std::min(rows_max, std::max(16, (c->opt_strip_px / w) & ~1)), rcap));
   };
   // Residency target of the heuristic: 5 workgroups per CU.  (A search over 5 / 4 / 3 per CU with a cost model
   // "pixels * (R + 4) / R / measured throughput at that residency" was tried for the 1280-wide levels of BASELINE
@@ -1151,6 +1151,30 @@ bool build_fused_plan(const pislam_ctx *c, const pislam_frontend_params *p, cons
   *lds_alias_bytes = lds_alias + (size_t)c->opt_lds_pad;   // profiling: opt_lds_pad lowers the residency artificially
   if ((size_t)p->rows * p->vstep > 0x7fffffffu) return false;   // 32-bit byte offsets inside a pyramid
   return lds <= 150 * 1024;       // (strips == 0: no level holds a classifiable pixel — the caller writes zero counts)
+}
+
+// Cap of the heuristic strip height.  Every strip pays a fixed share (set-up, barriers, the halo carried through
+// LDS, the ragged last wave step of each phase), so the narrow levels want strips as tall as the prefetch
+// registers allow (R * pitch <= 16 KiB) — but only when the launch has plenty of workgroups per resident slot;
+// a small launch is balanced better by more, shorter strips.  Measured, strip kernel alone (ms) for caps 28 / 36 /
+// 44 / 56 / 64: VGA batch 256 (15 strips per slot at cap 28) 0.221 / 0.212 / 0.209 / 0.207 / 0.211; 1280x960 batch
+// 256 (54 per slot) 0.885 / 0.857 / 0.861 / 0.861; 720p batch 64 (10 per slot): whole step 0.337 / 0.346 / 0.346 /
+// 0.344.  Rule: cap 56 from 12 strips per slot on, 28 below.  Option "strip_rows_max" overrides.
+bool build_fused_plan(const pislam_ctx *c, const pislam_frontend_params *p, const pislam_level *lv, int batch,
+                      pf::FusedParams *F, size_t *lds_bytes, size_t *lds_alias_bytes) {
+  if (c->opt_strip_rows_max > 0)
+    return build_fused_plan_rows(c, p, lv, batch, c->opt_strip_rows_max, F, lds_bytes, lds_alias_bytes);
+  if (!build_fused_plan_rows(c, p, lv, batch, 28, F, lds_bytes, lds_alias_bytes)) return false;
+  const double per_slot = (double)F->strips_per_pyr * batch / (5.0 * std::max(1, c->num_cus));
+  if (per_slot < 12.0) return true;
+  pf::FusedParams tall;
+  size_t l0 = 0, l1 = 0;
+  if (build_fused_plan_rows(c, p, lv, batch, 56, &tall, &l0, &l1)) {
+    *F = tall;
+    *lds_bytes = l0;
+    *lds_alias_bytes = l1;
+  }
+  return true;
 }
 
 int run_fused(pislam_ctx *c, const pislam_frontend_params *p, const pf::FusedParams &F, size_t lds, size_t lds_alias,

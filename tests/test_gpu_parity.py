@@ -133,11 +133,12 @@ def test_x_tiles_as_work_items_reproduce_reference_order(gpu_ctx, demo, tile_col
             gpu_ctx.set_option(k, v)
 
 
-@pytest.mark.parametrize("orb_in_strip", [0, 1])
-def test_product_kernels_on_reference_demo_pyramid(gpu_ctx, demo, orb_in_strip):
+@pytest.mark.parametrize("orb_in_strip,rows_max", [(0, 0), (1, 0), (0, 56), (1, 44), (0, 64)])
+def test_product_kernels_on_reference_demo_pyramid(gpu_ctx, demo, orb_in_strip, rows_max):
     """The product instantiations (no debug hooks) with either ORB placement — one gather+ORB pass (default) or
-    every strip describing its own keypoints (strip_body phase E, descriptors staged per strip) — on the
-    reference's demo photo and a dense variant that sends strips through the overflow pass."""
+    every strip describing its own keypoints (strip_body phase E, descriptors staged per strip) — and with the
+    strip-height cap of small launches (28) and of large ones (56: up to 56-row strips on the narrow levels) —
+    on the reference's demo photo and a dense variant that sends strips through the overflow pass."""
     import torch
     from pislam_amd.frontend import OrbFrontend
     img = demo["img"]
@@ -145,6 +146,7 @@ def test_product_kernels_on_reference_demo_pyramid(gpu_ctx, demo, orb_in_strip):
     noisy = (img.astype(np.int32) + np.random.default_rng(1).integers(-40, 41, img.shape)).clip(0, 255).astype(np.uint8)
     pyr = torch.from_numpy(np.stack([img, noisy, img])).to(dev)
     gpu_ctx.set_option("orb_in_strip", orb_in_strip)
+    gpu_ctx.set_option("strip_rows_max", rows_max)
     try:
         for lbs, lim, n, pin in ((0, 5, 1754, "kp"), (4, 3, 1315, "kp_bucket43")):
             fe = OrbFrontend(demo["levels"], vstep=640, rows=2210, max_keypoints=16384, log_bucket_size=lbs,
@@ -167,6 +169,7 @@ def test_product_kernels_on_reference_demo_pyramid(gpu_ctx, demo, orb_in_strip):
             assert strips > 0 and (redone > 0 or lbs != 0 or True)
     finally:
         gpu_ctx.set_option("orb_in_strip", 0)
+        gpu_ctx.set_option("strip_rows_max", 0)
 
 
 @pytest.mark.parametrize("w,h,border,thr", [
