@@ -74,6 +74,8 @@ struct FusedLevel {
   int tbytes;        // plain layout: bytes reserved for the image tile = max((R+10)*tpitch, the scan
                      // fallbacks' survivor / per-cell buffers — larger only with narrow x-tiles)
   uint32_t vpr_recip; // ceil(2^32 / (tpitch/16)): row = umulhi(i, vpr_recip) for a vector index i < 2^16
+  int tail_rows;      // prefilter: rows whose last, partial 256-column step share one wave step (64 / groups in it)
+  uint32_t tail_recip; // ceil(2^32 / groups in the tail step): row of a lane = umulhi(lane, tail_recip)
   // A plan entry is a whole pyramid level, or one X-TILE of a wide level: a column range handled by its own
   // workgroups like a level of its own (w / col0 describe the tile plus a halo of real image columns in place
   // of the border), so that the LDS footprint — and with it the number of resident workgroups — does not grow
@@ -670,8 +672,17 @@ __device__ __forceinline__ void strip_body(const StripArgs A, const FusedLevel L
     // tile's columns and one tail step with the lanes past cxb masked off, so that the full steps need
     // no per-lane bounds test (their compare lands directly in VCC = the ballot).
     const int nfull = (cxb - xs) >> 8, rem = (cxb - xs) & 255;
-    const bool tail_lane = 4 * lane < rem;
-    auto prefilter_step = [&](const lds_u8 *pc, const lds_u8 *pu, const lds_u8 *pd, bool lane_ok, int xrow) {
+    // The tail step of a row uses only rem / 4 lanes (VGA: 24, 61, 39, 21, 6, 57, 46, 37 of 64 for levels 0..7), so
+    // the tails of `tm` = 64 / (rem / 4) consecutive rows (plan: L.tail_rows) share one wave step: lane ->
+    // (row lrow, group lcol) of the step.
+    const int tg = (rem + 3) >> 2;
+    const int tm = L.ntx == 1 ? L.tail_rows : 1;
+    const int lrow = tm > 1 ? (int)__umulhi((uint32_t)lane, L.tail_recip) : 0;
+    const int lcol = lane - lrow * tg;
+    const bool tail_lane = lrow < tm && 4 * lcol < rem;
+    const int tail_ofs = lrow * tpitch + 4 * lcol;
+    const uint32_t tail_key = ((uint32_t)lrow << 16) + (uint32_t)(4 * lcol);
+    auto prefilter_step = [&](const lds_u8 *pc, const lds_u8 *pu, const lds_u8 *pd, bool lane_ok, uint32_t key) {
       // aligned dword reads; lanes past the tile's columns read harmless bytes of the next tile row
       const uint32_t wc = *(const lds_u32 *)pc;
       const uint32_t wl = *(const lds_u32 *)(pc - 4);
@@ -684,7 +695,7 @@ __device__ __forceinline__ void strip_body(const StripArgs A, const FusedLevel L
       const bool g = lane_ok && (min(sv, sh) > (uint32_t)thr);
       const uint64_t m = __ballot(g);
       if (m == 0) return;
-      if (g) qg[ng + ballot_rank(m)] = (uint32_t)(xrow + 4 * lane);   // pack_xy(x0, r)
+      if (g) qg[ng + ballot_rank(m)] = key;                               // pack_xy(x0, r)
       ng += __popcll(m);
       if (ng >= 64) {
         ng -= 64;
@@ -694,18 +705,26 @@ __device__ __forceinline__ void strip_body(const StripArgs A, const FusedLevel L
     // (Unrolling the full steps so that their 256-byte strides become immediate DS offsets instead of three
     //  pointer increments was tried: every copy of the step inlines the pretest / FAST batch code behind it,
     //  4859 -> 6481 instructions for 3 VALU per step.)
-    for (int r = r_lo + wave; r < r_hi; r += WAVES) {
-      const lds_u8 *pc = tile + (r + 3) * tpitch + xs + 4 * lane;
-      const lds_u8 *pu = pc - 3 * tpitch, *pd = pc + 3 * tpitch;
-      int xrow = (int)pack_xy(xs, r);               // wave-uniform: column of lane 0 | row << 16
-      for (int it = 0; it < nfull; it++) {
-        prefilter_step(pc, pu, pd, true, xrow);
-        pc += 256;
-        pu += 256;
-        pd += 256;
-        xrow += 256;
+    if (nfull > 0)
+      for (int r = r_lo + wave; r < r_hi; r += WAVES) {
+        const lds_u8 *pc = tile + (r + 3) * tpitch + xs + 4 * lane;
+        const lds_u8 *pu = pc - 3 * tpitch, *pd = pc + 3 * tpitch;
+        uint32_t key = pack_xy(xs, r) + (uint32_t)(4 * lane);    // column of this lane's group | row << 16
+        for (int it = 0; it < nfull; it++) {
+          prefilter_step(pc, pu, pd, true, key);
+          pc += 256;
+          pu += 256;
+          pd += 256;
+          key += 256;
+        }
       }
-      if (rem) prefilter_step(pc, pu, pd, tail_lane, xrow);
+    if (rem) {
+      const int xt0 = xs + (nfull << 8);
+      for (int r = r_lo + wave * tm; r < r_hi; r += WAVES * tm) {
+        const bool ok = tail_lane && lrow < r_hi - r;
+        const lds_u8 *pc = tile + (r + 3) * tpitch + xt0 + (ok ? tail_ofs : 0);
+        prefilter_step(pc, pc - 3 * tpitch, pc + 3 * tpitch, ok, pack_xy(xt0, r) + tail_key);
+      }
     }
     if (ng > 0 && !(ablate & 16)) pretest_batch(lane < ng, lane < ng ? qg[lane] : pack_xy(xs, r_lo));
     ng = 0;
