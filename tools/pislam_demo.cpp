@@ -12,9 +12,11 @@
 //   ... --threads T
 //       the same call sequence from T host threads at once (the reference's functions are re-entrant; the
 //       drop-in templates keep one context + stream per thread): every thread must report the same result
-//   ... --batch N [--steps K]
+//   ... --batch N [--steps K] [--streams S]
 //       the measured path: N copies of the pyramid resident on the device, pislam_orb_frontend_batch
-//       K times, per-stage hipEvent times (pislam_frontend_last_timing)
+//       K times, per-stage hipEvent times (pislam_frontend_last_timing); S > 1 keeps S batches in flight: step s
+//       runs on pipeline s % S (its own context, HIP stream and outputs), so one batch's gather+ORB kernel runs
+//       under the next batch's strip kernel
 //   ... --batch N --world W [--rccl-single]
 //       one PROCESS per GPU (this program forks W ranks before touching HIP): rank 0 draws the RCCL
 //       unique id (pislam_dist_get_unique_id) and hands it over through a file, every rank runs its shard of
@@ -181,9 +183,16 @@ int run_dropin(bool buckets, const char *out_path, std::vector<uint32_t> *points
   return 0;
 }
 
-// the measured path from C++: device-resident batch, optional shard over `world` processes
+// the measured path from C++: device-resident batch, optional shard over `world` processes, `streams` batches in
+// flight (one context + HIP stream + output set + communicator per pipeline; step s runs on pipeline s % streams)
+struct Pipe {
+  pislam_ctx *ctx = nullptr;
+  hipStream_t stream = nullptr;
+  uint32_t *d_kp = nullptr, *d_desc = nullptr, *d_counts = nullptr, *d_all = nullptr;
+};
+
 int run_batch(int batch, int steps, bool buckets, const char *out_path, int rank, int world, const char *id_file,
-              bool rccl_single) {
+              bool rccl_single, int streams) {
   int ndev = 0;
   HIP_OK(hipGetDeviceCount(&ndev));
   if (ndev < 1) {
@@ -196,39 +205,41 @@ int run_batch(int batch, int steps, bool buckets, const char *out_path, int rank
   }
   const int device = rank % ndev;
   HIP_OK(hipSetDevice(device));
-  pislam_ctx *ctx = nullptr;
-  if (pislam_ctx_create(device, &ctx) != PISLAM_OK) return 11;
-  hipStream_t stream;
-  HIP_OK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
-  PISLAM_OK_(ctx, pislam_ctx_set_stream(ctx, stream));
-
-  // ---- one process per GPU: communicator from a unique id handed over through a file ----
-  uint8_t id[PISLAM_DIST_ID_BYTES];
-  memset(id, 0, sizeof(id));
+  std::vector<Pipe> pipes((size_t)streams);
   const bool need_id = world > 1 || rccl_single;
-  if (need_id) {
-    if (rank == 0) {
-      if (pislam_dist_get_unique_id(id) != PISLAM_OK) {
-        fprintf(stderr, "pislam_dist_get_unique_id failed (RCCL not loadable?)\n");
-        return 13;
+  for (int k = 0; k < streams; k++) {
+    Pipe &p = pipes[(size_t)k];
+    if (pislam_ctx_create(device, &p.ctx) != PISLAM_OK) return 11;
+    HIP_OK(hipStreamCreateWithFlags(&p.stream, hipStreamNonBlocking));
+    PISLAM_OK_(p.ctx, pislam_ctx_set_stream(p.ctx, p.stream));
+    // ---- one process per GPU: communicator from a unique id handed over through a file (one per pipeline) ----
+    uint8_t id[PISLAM_DIST_ID_BYTES];
+    memset(id, 0, sizeof(id));
+    if (need_id) {
+      const std::string path = std::string(id_file) + "." + std::to_string(k);
+      if (rank == 0) {
+        if (pislam_dist_get_unique_id(id) != PISLAM_OK) {
+          fprintf(stderr, "pislam_dist_get_unique_id failed (RCCL not loadable?)\n");
+          return 13;
+        }
+        const std::string tmp = path + ".tmp";
+        FILE *f = fopen(tmp.c_str(), "wb");
+        if (!f || fwrite(id, 1, sizeof(id), f) != sizeof(id)) return 13;
+        fclose(f);
+        rename(tmp.c_str(), path.c_str());               // atomic: readers never see a partial id
+      } else {
+        FILE *f = nullptr;
+        for (int tries = 0; tries < 6000 && !(f = fopen(path.c_str(), "rb")); tries++) usleep(10000);
+        if (!f || fread(id, 1, sizeof(id), f) != sizeof(id)) {
+          fprintf(stderr, "rank %d: no unique id at %s\n", rank, path.c_str());
+          return 13;
+        }
+        fclose(f);
       }
-      const std::string tmp = std::string(id_file) + ".tmp";
-      FILE *f = fopen(tmp.c_str(), "wb");
-      if (!f || fwrite(id, 1, sizeof(id), f) != sizeof(id)) return 13;
-      fclose(f);
-      rename(tmp.c_str(), id_file);                    // atomic: readers never see a partial id
-    } else {
-      FILE *f = nullptr;
-      for (int tries = 0; tries < 6000 && !(f = fopen(id_file, "rb")); tries++) usleep(10000);
-      if (!f || fread(id, 1, sizeof(id), f) != sizeof(id)) {
-        fprintf(stderr, "rank %d: no unique id at %s\n", rank, id_file);
-        return 13;
-      }
-      fclose(f);
+      if (rccl_single) PISLAM_OK_(p.ctx, pislam_ctx_set_option(p.ctx, "dist_rccl_single", 1));
     }
-    if (rccl_single) PISLAM_OK_(ctx, pislam_ctx_set_option(ctx, "dist_rccl_single", 1));
+    PISLAM_OK_(p.ctx, pislam_dist_init(p.ctx, need_id ? id : nullptr, rank, world));
   }
-  PISLAM_OK_(ctx, pislam_dist_init(ctx, need_id ? id : nullptr, rank, world));
 
   // ---- this rank's shard of the world * batch pyramids (all copies of the one input here) ----
   int first = 0, count = 0;
@@ -242,57 +253,72 @@ int run_batch(int batch, int steps, bool buckets, const char *out_path, int rank
   pislam_frontend_params P = {IMG_W, ROWS, NLEVELS, 16, 20, 1 << 15, buckets ? 4 : 0, buckets ? 3 : 5, 8, 4096};
   const size_t pyr_bytes = (size_t)ROWS * IMG_W;
   uint8_t *d_pyr = nullptr;
-  uint32_t *d_kp = nullptr, *d_desc = nullptr, *d_counts = nullptr, *d_all = nullptr;
   HIP_OK(hipMalloc(&d_pyr, pyr_bytes * count));
-  HIP_OK(hipMalloc(&d_kp, sizeof(uint32_t) * (size_t)P.max_keypoints * count));
-  HIP_OK(hipMalloc(&d_desc, sizeof(uint32_t) * (size_t)P.max_keypoints * P.words * count));
-  HIP_OK(hipMalloc(&d_counts, sizeof(uint32_t) * count));
-  HIP_OK(hipMalloc(&d_all, sizeof(uint32_t) * (size_t)count * world));
-  for (int b = 0; b < count; b++) HIP_OK(hipMemcpyAsync(d_pyr + b * pyr_bytes, img, pyr_bytes, hipMemcpyHostToDevice, stream));
-  PISLAM_OK_(ctx, pislam_frontend_reserve(ctx, &P, lv, count));
-  PISLAM_OK_(ctx, pislam_orb_frontend_batch(ctx, &P, lv, d_pyr, pyr_bytes, count, d_kp, d_desc, d_counts));   // warm-up
-  HIP_OK(hipStreamSynchronize(stream));
+  for (int b = 0; b < count; b++) HIP_OK(hipMemcpy(d_pyr + b * pyr_bytes, img, pyr_bytes, hipMemcpyHostToDevice));
+  for (Pipe &p : pipes) {
+    HIP_OK(hipMalloc(&p.d_kp, sizeof(uint32_t) * (size_t)P.max_keypoints * count));
+    HIP_OK(hipMalloc(&p.d_desc, sizeof(uint32_t) * (size_t)P.max_keypoints * P.words * count));
+    HIP_OK(hipMalloc(&p.d_counts, sizeof(uint32_t) * count));
+    HIP_OK(hipMalloc(&p.d_all, sizeof(uint32_t) * (size_t)count * world));
+    PISLAM_OK_(p.ctx, pislam_frontend_reserve(p.ctx, &P, lv, count));
+    PISLAM_OK_(p.ctx, pislam_orb_frontend_batch(p.ctx, &P, lv, d_pyr, pyr_bytes, count, p.d_kp, p.d_desc, p.d_counts));   // warm-up
+    HIP_OK(hipStreamSynchronize(p.stream));
+  }
 
+  pislam_ctx *ctx = pipes[0].ctx;
   double barrier = 0;
   PISLAM_OK_(ctx, pislam_dist_allreduce_max(ctx, &barrier));        // all ranks start together
   const double t0 = now_ms();
   for (int s = 0; s < steps; s++) {
-    PISLAM_OK_(ctx, pislam_dist_fence(ctx, 1));                      // one output set: wait for the previous all-gather
-    PISLAM_OK_(ctx, pislam_orb_frontend_batch(ctx, &P, lv, d_pyr, pyr_bytes, count, d_kp, d_desc, d_counts));
-    PISLAM_OK_(ctx, pislam_dist_allgather_counts(ctx, d_counts, (size_t)count, d_all));
+    Pipe &p = pipes[(size_t)(s % streams)];
+    PISLAM_OK_(p.ctx, pislam_dist_fence(p.ctx, 1));                  // one output set per pipeline: wait for its previous all-gather
+    PISLAM_OK_(p.ctx, pislam_orb_frontend_batch(p.ctx, &P, lv, d_pyr, pyr_bytes, count, p.d_kp, p.d_desc, p.d_counts));
+    PISLAM_OK_(p.ctx, pislam_dist_allgather_counts(p.ctx, p.d_counts, (size_t)count, p.d_all));
   }
-  HIP_OK(hipStreamSynchronize(stream));
-  PISLAM_OK_(ctx, pislam_dist_synchronize(ctx));
+  for (Pipe &p : pipes) {
+    HIP_OK(hipStreamSynchronize(p.stream));
+    PISLAM_OK_(p.ctx, pislam_dist_synchronize(p.ctx));
+  }
   double dt = now_ms() - t0;
   PISLAM_OK_(ctx, pislam_dist_allreduce_max(ctx, &dt));             // the slowest rank
 
   float total_ms = 0, stage_ms[3] = {0, 0, 0};
   PISLAM_OK_(ctx, pislam_frontend_last_timing(ctx, &total_ms, stage_ms));
   std::vector<uint32_t> all((size_t)count * world);
-  HIP_OK(hipMemcpy(all.data(), d_all, all.size() * 4, hipMemcpyDeviceToHost));
+  HIP_OK(hipMemcpy(all.data(), pipes[0].d_all, all.size() * 4, hipMemcpyDeviceToHost));
   unsigned long long total = 0;
   for (uint32_t c : all) total += c < (uint32_t)P.max_keypoints ? c : (uint32_t)P.max_keypoints;
+  int bad = 0;
+  for (size_t k = 1; k < pipes.size() && steps >= streams; k++) {   // every pipeline gathered the same counts
+    std::vector<uint32_t> other(all.size());
+    HIP_OK(hipMemcpy(other.data(), pipes[k].d_all, other.size() * 4, hipMemcpyDeviceToHost));
+    bad += other != all;
+  }
   if (rank == 0) {
-    printf("GPU  Time: %.3f ms per batch of %d x %d pyramids  (device stages of the last call: detect+score+nms %.3f, "
+    printf("GPU  Time: %.3f ms per batch of %d x %d pyramids, %d in flight  (device stages of the last call: detect+score+nms %.3f, "
            "overflow pass %.3f, gather+orb %.3f ms; %d ranks, count all-gather: %s)\n",
-           dt / steps, world, count, stage_ms[0], stage_ms[1], stage_ms[2], world,
+           dt / steps, world, count, streams, stage_ms[0], stage_ms[1], stage_ms[2], world,
            (world > 1 || rccl_single) ? "ncclAllGather via pislam_dist_allgather_counts" : "single GPU");
     printf("%llu features in %d pyramids (%u per pyramid), %.3e features/s\n", total, world * count, all[0],
            (double)total * steps / (dt * 1e-3));
-    if (out_path) {                                      // pyramid 0 of rank 0
+    if (out_path) {                                      // pyramid 0 of rank 0 (of the last pipeline that ran)
+      const Pipe &p = pipes[(size_t)((steps - 1) % streams)];
       const uint32_t n = all[0] < (uint32_t)P.max_keypoints ? all[0] : (uint32_t)P.max_keypoints;
       std::vector<uint32_t> kp(n), desc((size_t)n * P.words);
-      HIP_OK(hipMemcpy(kp.data(), d_kp, n * 4, hipMemcpyDeviceToHost));
-      HIP_OK(hipMemcpy(desc.data(), d_desc, desc.size() * 4, hipMemcpyDeviceToHost));
+      HIP_OK(hipMemcpy(kp.data(), p.d_kp, n * 4, hipMemcpyDeviceToHost));
+      HIP_OK(hipMemcpy(desc.data(), p.d_desc, desc.size() * 4, hipMemcpyDeviceToHost));
       write_result(out_path, kp, desc);
     }
   }
   // every pyramid is the same image here, so every gathered count must be equal — on every rank
-  int bad = 0;
   for (uint32_t c : all) bad += c != all[0];
-  pislam_dist_finalize(ctx);
-  pislam_ctx_destroy(ctx);
-  (void)hipFree(d_pyr); (void)hipFree(d_kp); (void)hipFree(d_desc); (void)hipFree(d_counts); (void)hipFree(d_all);
+  for (Pipe &p : pipes) {
+    pislam_dist_finalize(p.ctx);
+    pislam_ctx_destroy(p.ctx);
+    (void)hipFree(p.d_kp); (void)hipFree(p.d_desc); (void)hipFree(p.d_counts); (void)hipFree(p.d_all);
+    (void)hipStreamDestroy(p.stream);
+  }
+  (void)hipFree(d_pyr);
   return bad ? 14 : 0;
 }
 
@@ -301,12 +327,12 @@ int run_batch(int batch, int steps, bool buckets, const char *out_path, int rank
 int main(int argc, char **argv) {
   if (argc < 2) {
     fprintf(stderr, "Usage: %s pyramid.raw|pyramid.pgm [--buckets] [--out result.bin] [--paint marked.pgm] [--threads T] [--batch N [--steps K] "
-                    "[--world W] [--rccl-single]]\n", argv[0]);
+                    "[--streams S] [--world W] [--rccl-single]]\n", argv[0]);
     return 1;
   }
   bool buckets = false, rccl_single = false;
   const char *out_path = nullptr, *paint_path = nullptr;
-  int batch = 0, steps = 10, world = 1, threads = 1;
+  int batch = 0, steps = 10, world = 1, threads = 1, streams = 1;
   for (int i = 2; i < argc; i++) {
     if (!strcmp(argv[i], "--buckets")) buckets = true;
     else if (!strcmp(argv[i], "--rccl-single")) rccl_single = true;
@@ -316,6 +342,7 @@ int main(int argc, char **argv) {
     else if (!strcmp(argv[i], "--steps") && i + 1 < argc) steps = atoi(argv[++i]);
     else if (!strcmp(argv[i], "--world") && i + 1 < argc) world = atoi(argv[++i]);
     else if (!strcmp(argv[i], "--threads") && i + 1 < argc) threads = atoi(argv[++i]);
+    else if (!strcmp(argv[i], "--streams") && i + 1 < argc) streams = atoi(argv[++i]);
     else {
       fprintf(stderr, "unknown argument %s\n", argv[i]);
       return 1;
@@ -342,21 +369,20 @@ int main(int argc, char **argv) {
     return 0;
   }
   if (batch <= 0) return run_dropin(buckets, out_path, nullptr, paint_path);
-  if (world < 1 || steps < 1) return 1;
+  if (world < 1 || steps < 1 || streams < 1 || streams > 8) return 1;
   // one process per GPU: fork the ranks BEFORE the first HIP call (a forked HIP runtime is unusable)
   char id_file[256];
   snprintf(id_file, sizeof(id_file), "/tmp/pislam_demo_id_%d", (int)getpid());
-  unlink(id_file);
   if (world == 1) {
-    const int rc = run_batch(batch, steps, buckets, out_path, 0, 1, id_file, rccl_single);
-    unlink(id_file);
+    const int rc = run_batch(batch, steps, buckets, out_path, 0, 1, id_file, rccl_single, streams);
+    for (int k = 0; k < streams; k++) unlink((std::string(id_file) + "." + std::to_string(k)).c_str());
     return rc;
   }
   std::vector<pid_t> kids;
   for (int r = 0; r < world; r++) {
     const pid_t pid = fork();
     if (pid < 0) return 20;
-    if (pid == 0) _exit(run_batch(batch, steps, buckets, out_path, r, world, id_file, false));
+    if (pid == 0) _exit(run_batch(batch, steps, buckets, out_path, r, world, id_file, false, streams));
     kids.push_back(pid);
   }
   int rc = 0;
@@ -365,6 +391,6 @@ int main(int argc, char **argv) {
     waitpid(k, &st, 0);
     if (!WIFEXITED(st) || WEXITSTATUS(st) != 0) rc = WIFEXITED(st) ? WEXITSTATUS(st) : 21;
   }
-  unlink(id_file);
+  for (int k = 0; k < streams; k++) unlink((std::string(id_file) + "." + std::to_string(k)).c_str());
   return rc;
 }
