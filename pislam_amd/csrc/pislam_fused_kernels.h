@@ -434,8 +434,8 @@ __device__ __forceinline__ void strip_body(const StripArgs A, const FusedLevel L
   lds_u32 *qf = qg + QCAP_G;                       // FAST candidates
   // Corners are rare (~1 % of the pixels): a private queue per wave would end in a mostly empty
   // 64-lane Harris batch per wave, so corners go to ONE queue per workgroup (LDS atomic append)
-  // and are scored by all waves together once FAST is finished.  The waves' left-over FAST
-  // candidates (< 64 each) are merged the same way.
+  // and are scored by all waves together once FAST is finished.  (The waves' left-over pretest / FAST
+  // candidates, < 64 each, are NOT merged: that would take one more barrier per strip.)
   lds_u32 *shq_h = shq;
   lds_u32 *shq_n = shq_h + QH_SHARED;               // (plain layout only)
   const int qcap = ALIAS ? L.qh : QH_SHARED;         // capacity of the shared corner queue
