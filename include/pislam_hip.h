@@ -279,7 +279,8 @@ int pislam_match_hamming_batch(pislam_ctx *ctx, int words, const uint32_t *query
  * needs to place every rank's keypoints in one global list) — ncclAllGather over
  * RCCL/xGMI, 4 bytes per pyramid.  RCCL is bound at run time (librccl.so.1;
  * override with the environment variable PISLAM_RCCL_LIB); world == 1 never
- * touches it.
+ * touches it.  PISLAM_DIST_TRACE=1 makes pislam_dist_finalize print the host time
+ * spent in each call of an exchange (a diagnostic, stderr).
  *
  *   rank 0:   pislam_dist_get_unique_id(id);  -> hand `id` to every rank (file, socket, MPI, env ...)
  *   all:      pislam_ctx_create(local_device, &ctx);  pislam_dist_init(ctx, id, rank, world);
