@@ -603,9 +603,10 @@ __device__ __forceinline__ void strip_body(const StripArgs A, const FusedLevel L
         // 16 i + row * (vstep - tpitch) with row = i / vpr by one multiply-high (i < 2^16)
         const int nvec = (nrows - r_st0) * vpr;
         const int gap = A.vstep - tpitch;
-        const uint8_t *src0 = im + (ptrdiff_t)(y_lo + r_st0) * A.vstep + xbase;
+        // (32-bit byte offsets: a pyramid is < 2 GiB — checked by the plan — and y_lo, xbase >= 0)
+        const uint8_t *src0 = im + (uint32_t)((y_lo + r_st0) * A.vstep + xbase);
         lds_u4 *dstv = (lds_u4 *)(tile0 + r_st0 * tpitch);
-        const bool tail = (ptrdiff_t)(y_lo + nrows - 1) * A.vstep + xbase + tpitch > lim;
+        const bool tail = (uint32_t)((y_lo + nrows - 1) * A.vstep + xbase + tpitch) > (uint32_t)lim;
         if (!tail) {
           for (int i = tid; i < nvec; i += NT) {
             const int row = (int)__umulhi((uint32_t)i, L.vpr_recip);
@@ -649,10 +650,10 @@ __device__ __forceinline__ void strip_body(const StripArgs A, const FusedLevel L
       const int vpr = tpitch >> 4;
       const int ylo_n = ye - 4, ye_n = min(ye + L.R, Lh - B);
       const int nrows_n = min(ye_n + 6, Lh) - ylo_n;
-      if ((ptrdiff_t)(ylo_n + nrows_n - 1) * A.vstep + xbase + tpitch <= lim) {
+      if ((uint32_t)((ylo_n + nrows_n - 1) * A.vstep + xbase + tpitch) <= (uint32_t)lim) {
         // the next strip's new rows 10 .. nrows_n-1 as one run of vectors (see the store above)
         const int nvec_n = (nrows_n - 10) * vpr, gap = A.vstep - tpitch;
-        const uint8_t *src_n = im + (ptrdiff_t)(ylo_n + 10) * A.vstep + xbase;
+        const uint8_t *src_n = im + (uint32_t)((ylo_n + 10) * A.vstep + xbase);
 #pragma unroll
         for (int k = 0; k < PF_MAX; k++) {
           const int i = tid + NT * k;
