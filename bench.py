@@ -104,6 +104,7 @@ def main():
                          "k %% S, so consecutive batches overlap on the GPU (default 3; 1 = strictly one batch at a time)")
     ap.add_argument("--match", action="store_true",
                     help="also match every pyramid's descriptors against its neighbour's inside the step (SURVEY 8f-4)")
+    ap.add_argument("--match-mfma", type=int, default=-1, help="--match: 1 (default) matrix-core matcher, 0 the VALU popcount kernel")
     ap.add_argument("--lds-pad", type=int, default=0, help="profiling only: extra LDS per strip workgroup")
     ap.add_argument("--log-bucket-size", type=int, default=0, help="fastExtract logBucketSize (README uses 4)")
     ap.add_argument("--bucket-limit", type=int, default=5, help="fastExtract bucketLimit (README uses 3)")
@@ -198,6 +199,8 @@ def main():
             c.set_option("tile_cols", args.tile_cols)
         if args.orb_in_strip >= 0:
             c.set_option("orb_in_strip", args.orb_in_strip)
+        if args.match_mfma >= 0:
+            c.set_option("match_mfma", args.match_mfma)
         if args.run_len:
             c.set_option("run_len", args.run_len)
         if args.xtile_cols >= 0:

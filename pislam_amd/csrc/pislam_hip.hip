@@ -116,6 +116,7 @@ struct pislam_ctx {
   int opt_run_order = 1;     // fused pipeline: launch a pyramid's runs longest first (0: in entry order)
   int opt_tile_cols = 0;     // fused pipeline: levels with more classified columns are cut into x-tiles (0 = 704, < 0 = never)
   int opt_orb_in_strip = 0;  // fused pipeline: 1 = strips describe their own keypoints (measured slower: DESIGN.md §8), 0 = k_gather_orb describes all
+  int opt_match_mfma = 1;         // matcher on the matrix cores (0: the VALU popcount kernel)
   int opt_dist_rccl_single = 0;   // test hook: pislam_dist_init(world = 1) still creates a (1-rank) RCCL communicator
   int last_pipeline = 0;
   size_t score_bytes_valid = 0;   // bytes of w_score known to be in a consistent (zero-border) state
@@ -450,6 +451,8 @@ PISLAM_EXPORT int pislam_ctx_set_option(pislam_ctx *c, const char *key, int valu
   } else if (!strcmp(key, "wgs_per_cu")) {
     if (value < 0 || value > 8) return fail(c, PISLAM_ERR_INVALID, "wgs_per_cu must be 0..8");
     c->opt_wgs_per_cu = value;
+  } else if (!strcmp(key, "match_mfma")) {
+    c->opt_match_mfma = value != 0;
   } else if (!strcmp(key, "run_order")) {
     c->opt_run_order = value != 0;
   } else if (!strcmp(key, "strip_px")) {
@@ -1501,6 +1504,27 @@ namespace {
 int launch_match(pislam_ctx *c, int words, const uint32_t *q, const uint32_t *qc, size_t q_stride, uint32_t nq,
                  const uint32_t *t, const uint32_t *tc, size_t t_stride, uint32_t nt, int batch, uint32_t max_q,
                  int32_t *idx, uint32_t *dist, uint32_t *dist2, size_t out_stride) {
+  if (c->opt_match_mfma) {
+    // matrix-core path (v_mfma_i32_32x32x32_i8): 4 waves x 32 queries per workgroup pass
+    // query blocks per pair in flight: the batch API only knows the capacity (the counts live on the device), and a
+    // workgroup that finds no queries still costs its launch (~30 ns each: 32 blocks per pair at batch 256 took
+    // 0.27 ms against 0.09 ms with 8), so the grid aims at ~8 workgroups per CU and the workgroups loop
+    const int per_pair = batch > 1 ? std::max(1, std::min(cdiv((int)max_q, pm::MF_Q), cdiv(8 * std::max(1, c->num_cus), batch))) : 65535;
+    const dim3 mgrid((unsigned)std::min(cdiv((int)max_q, pm::MF_Q), per_pair), (unsigned)batch);
+#define PISLAM_MATCH_MFMA(W)                                                                                  \
+  hipLaunchKernelGGL(pm::k_match_mfma<W>, mgrid, dim3(64 * pm::MF_WAVES), 0, c->stream, q, qc, q_stride * W, nq, t, tc, \
+                     t_stride * W, nt, (uint32_t)std::min<size_t>(q_stride, 0xffffffffu),                   \
+                     (uint32_t)std::min<size_t>(t_stride, 65535), idx, dist, dist2, out_stride)
+    switch (words) {
+      case 1: PISLAM_MATCH_MFMA(1); break;
+      case 2: PISLAM_MATCH_MFMA(2); break;
+      case 4: PISLAM_MATCH_MFMA(4); break;
+      case 8: PISLAM_MATCH_MFMA(8); break;
+      default: return fail(c, PISLAM_ERR_INVALID, "words must be 1, 2, 4 or 8");
+    }
+#undef PISLAM_MATCH_MFMA
+    return launch_ok(c, "k_match_mfma");
+  }
   const dim3 grid((unsigned)std::min(cdiv((int)max_q, pm::QPW), batch > 1 ? pm::MAX_GRID_X : 65535), (unsigned)batch);
 #define PISLAM_MATCH(W)                                                                                       \
   hipLaunchKernelGGL(pm::k_match<W>, grid, dim3(pm::QPW * pm::SPLIT), 0, c->stream, q, qc, q_stride * W, nq, t, tc, t_stride * W, \

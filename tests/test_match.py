@@ -46,10 +46,19 @@ def test_oracle_matcher_vs_numpy(orc, words, nq, nt):
         assert (g == e).all()
 
 
+@pytest.fixture(params=[1, 0], ids=["mfma", "valu"])
+def match_kernel(request, gpu_ctx):
+    """Both matcher kernels: the matrix-core one (default) and the VALU popcount one."""
+    gpu_ctx.set_option("match_mfma", request.param)
+    yield request.param
+    gpu_ctx.set_option("match_mfma", 1)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("words", [1, 2, 4, 8])
-@pytest.mark.parametrize("nq,nt", [(0, 5), (5, 0), (1, 1), (7, 2), (300, 257), (64, 1000), (1025, 3000)])
-def test_gpu_matcher_vs_oracle(gpu_ctx, orc, words, nq, nt):
+@pytest.mark.parametrize("nq,nt", [(0, 5), (5, 0), (1, 1), (7, 2), (31, 32), (33, 33), (129, 64), (300, 257), (64, 1000),
+                                   (1025, 3000)])
+def test_gpu_matcher_vs_oracle(gpu_ctx, orc, match_kernel, words, nq, nt):
     from pislam_amd import frontend
     rng = np.random.default_rng(words * 1000 + nq * 7 + nt + 1)
     q, t = make_sets(rng, nq, nt, words)
@@ -57,6 +66,26 @@ def test_gpu_matcher_vs_oracle(gpu_ctx, orc, words, nq, nt):
     exp = orc.match_hamming(q.reshape(nq, words), t.reshape(nt, words))
     for g, e in zip(got, exp):
         assert (g == e).all()
+
+
+@pytest.mark.gpu
+def test_gpu_matcher_structured_bits(gpu_ctx, orc, match_kernel):
+    """Descriptors with one bit set / cleared per position (every bit position of every word reaches its own
+    byte lane of the matrix-core fragments), sparse and dense sets, many exact ties."""
+    from pislam_amd import frontend
+    for words in (1, 2, 4, 8):
+        K = 32 * words
+        one = np.zeros((K, words), np.uint32)
+        for k in range(K):
+            one[k, k // 32] = np.uint32(1) << np.uint32(k % 32)
+        sets = [one, ~one, np.concatenate([one, ~one, one[::-1]]), np.zeros((40, words), np.uint32),
+                np.full((70, words), 0xFFFFFFFF, np.uint32)]
+        for q in sets:
+            for t in sets:
+                got = frontend.matchHamming(q, t, ctx=gpu_ctx)
+                exp = orc.match_hamming(q, t)
+                for g, e in zip(got, exp):
+                    assert (g == e).all(), (words, len(q), len(t))
 
 
 @pytest.mark.gpu
@@ -72,7 +101,7 @@ def test_gpu_matcher_rejects_bad_arguments(gpu_ctx):
 
 
 @pytest.mark.gpu
-def test_gpu_batch_matcher_on_frontend_outputs(gpu_ctx, orc):
+def test_gpu_batch_matcher_on_frontend_outputs(gpu_ctx, orc, match_kernel):
     """Consecutive synthetic frames through the front-end, then matched pairwise on the device with the
     front-end's own [batch][max_kp][words] / counts arrays (ragged, one pair with an empty side)."""
     import torch
