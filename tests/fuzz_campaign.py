@@ -42,12 +42,57 @@ def make_wide(seed):
     return levels, vstep, rows, pyr, par, opts
 
 
+def matcher_campaign(args):
+    """pislam_match_hamming on random set sizes / widths / tie structures, matrix-core and VALU kernels, vs the oracle."""
+    from oracle import orc
+    from pislam_amd import frontend
+    from pislam_amd.capi import Context
+    ctx = Context(device=0)
+    bad, t0 = 0, time.time()
+    for seed in range(args.start, args.start + args.seeds):
+        rng = np.random.default_rng(seed)
+        words = int(rng.choice([1, 2, 4, 8]))
+        nq, nt = int(rng.integers(0, 400)), int(rng.integers(0, 400))
+        kind = int(rng.integers(0, 4))
+        if kind == 0:                                   # random bits
+            t = rng.integers(0, 2**32, size=(nt, words), dtype=np.uint64).astype(np.uint32)
+            q = rng.integers(0, 2**32, size=(nq, words), dtype=np.uint64).astype(np.uint32)
+        elif kind == 1:                                 # few distinct descriptors: many exact ties
+            pool = rng.integers(0, 2**32, size=(4, words), dtype=np.uint64).astype(np.uint32)
+            t = pool[rng.integers(0, 4, nt)] if nt else np.zeros((0, words), np.uint32)
+            q = pool[rng.integers(0, 4, nq)] if nq else np.zeros((0, words), np.uint32)
+        elif kind == 2:                                 # sparse / dense bit patterns
+            t = (rng.integers(0, 2**32, size=(nt, words), dtype=np.uint64) & rng.integers(0, 2**32, size=(nt, words), dtype=np.uint64)).astype(np.uint32)
+            q = (rng.integers(0, 2**32, size=(nq, words), dtype=np.uint64) | rng.integers(0, 2**32, size=(nq, words), dtype=np.uint64)).astype(np.uint32)
+        else:                                           # queries = noisy copies of train descriptors
+            t = rng.integers(0, 2**32, size=(nt, words), dtype=np.uint64).astype(np.uint32)
+            if nt:
+                q = t[rng.integers(0, nt, nq)] ^ (np.uint32(1) << rng.integers(0, 32, size=(nq, words)).astype(np.uint32))
+            else:
+                q = np.zeros((nq, words), np.uint32)
+        q, t = np.ascontiguousarray(q).reshape(nq, words), np.ascontiguousarray(t).reshape(nt, words)
+        exp = orc.match_hamming(q, t)
+        for mf in (1, 0):
+            ctx.set_option("match_mfma", mf)
+            got = frontend.matchHamming(q, t, ctx=ctx)
+            if not all((g == e).all() for g, e in zip(got, exp)):
+                bad += 1
+                print("MISMATCH", seed, "mfma" if mf else "valu", words, nq, nt, kind, flush=True)
+        if (seed - args.start) % 1000 == 999:
+            print(f"[{seed - args.start + 1} cases, {bad} bad, {time.time() - t0:.0f} s]", flush=True)
+    print(f"{args.seeds} matcher cases from seed {args.start}: {bad} mismatches, {time.time() - t0:.0f} s")
+    return 1 if bad else 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seeds", type=int, default=500)
     ap.add_argument("--start", type=int, default=100000)
     ap.add_argument("--wide", action="store_true")
+    ap.add_argument("--matcher", action="store_true", help="random descriptor sets through both matcher kernels instead")
     args = ap.parse_args()
+    if args.matcher:
+        return matcher_campaign(args)
     import torch
     from oracle import orc
     from pislam_amd.capi import Context
