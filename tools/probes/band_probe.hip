@@ -1,5 +1,5 @@
 // band_probe.hip — exploration for DESIGN.md section 8 ("waves that roll down a column band"): the classification
-// phases of the ORB front-end (SAD prefilter -> exact compass pretest -> FAST-9) with ONE WAVE per work item, a
+// phases of the ORB front-end (SAD prefilter -> exact compass pretest -> FAST-9 -> Harris score) with ONE WAVE per work item, a
 // rolling window of image rows in the wave's private LDS and FIFO candidate queues that stay alive over the whole
 // segment — no workgroup barriers, partly filled batches only when a queue entry is about to lose its image rows
 // and at the end of a segment.  Counts the FAST corners per item and checks pyramid 0 against a textbook FAST-9 on
@@ -21,15 +21,18 @@ typedef __attribute__((address_space(3))) u32x4 lds_u4;
 typedef unsigned short us2 __attribute__((ext_vector_type(2)));
 
 constexpr int P = 160;                 // LDS row pitch: 16 halo + 128 owned + 16 halo columns
-constexpr int NR = 32, NSLOT = NR + 6; // ring of 32 image rows, rows with slot < 6 duplicated behind the ring
-constexpr int QG = 128, QF = 256;      // FIFO capacities (dwords)
-constexpr int LDS_BYTES = NSLOT * P + 4 * (QG + QF);
+constexpr int NR = 32, NDUP = 7, NSLOT = NR + NDUP;   // ring of 32 image rows; rows with slot < 7 are duplicated behind
+                                                     // the ring so that rows c-3 .. c+4 are contiguous for every centre row
+constexpr int QG = 128, QF = 256, QC = 128;   // FIFO capacities (dwords): groups, FAST candidates, corners
+constexpr int LDS_BYTES = NSLOT * P + 4 * (QG + QF + QC);
+constexpr int HTHR = 1 << 15;
 constexpr int VSTEP = 640, ROWS = 2210, THR = 20, B = 16;
 
 struct Item {
   int row0, h;       // level position / height
   int cx0, cx1;      // owned classified columns (level-relative), cx1 - cx0 <= 128, multiple of 4
   int y0, y1;        // classified rows (level-relative)
+  int xscore;        // w - B: corners at / beyond it keep 0xff (Fast.h:172)
 };
 
 __device__ __forceinline__ us2 as_us2(uint32_t v) { return __builtin_bit_cast(us2, v); }
@@ -46,11 +49,13 @@ __device__ __forceinline__ void pretest_pk(uint32_t c, uint32_t u, uint32_t d, u
 __device__ __forceinline__ void lds_wait() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
 __global__ __launch_bounds__(64) void k_bands(const Item *__restrict__ items, const uint8_t *__restrict__ pyramids,
-                                              uint32_t *__restrict__ out_count, uint32_t *__restrict__ out_sum, int nitems) {
+                                              uint32_t *__restrict__ out_count, uint32_t *__restrict__ out_sum, int nitems,
+                                              uint8_t *__restrict__ score_map) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   lds_u8 *ring = (lds_u8 *)smem;
   lds_u32 *qg = (lds_u32 *)(smem + NSLOT * P);
   lds_u32 *qf = qg + QG;
+  lds_u32 *qc = qf + QF;
   const Item it = items[blockIdx.x];
   const int lane = threadIdx.x;
   const uint8_t *im = pyramids + (size_t)blockIdx.y * ROWS * VSTEP + (size_t)it.row0 * VSTEP;
@@ -69,7 +74,7 @@ __global__ __launch_bounds__(64) void k_bands(const Item *__restrict__ items, co
   auto park = [&](int yy, int col, u32x4 d) {        // image row yy -> its ring slot (and the duplicate)
     const int s = yy & (NR - 1);
     *(lds_u4 *)(ring + s * P + 16 * col) = d;
-    if (s < 6) *(lds_u4 *)(ring + (s + NR) * P + 16 * col) = d;
+    if (s < NDUP) *(lds_u4 *)(ring + (s + NR) * P + 16 * col) = d;
   };
   auto rowptr = [&](int y) -> const lds_u8 * {       // row y with rows y-3 .. y+3 contiguous around it
     int c = y & (NR - 1);
@@ -77,18 +82,41 @@ __global__ __launch_bounds__(64) void k_bands(const Item *__restrict__ items, co
     return ring + c * P - xs0;
   };
   uint32_t ncorner = 0, csum = 0;
-  uint32_t head_g = 0, tail_g = 0, head_f = 0, tail_f = 0;   // wave-uniform FIFO cursors (free running)
+  uint32_t head_g = 0, tail_g = 0, head_f = 0, tail_f = 0, head_c = 0, tail_c = 0;   // wave-uniform FIFO cursors (free running)
+  int old_c = 0;
+  uint32_t nscored = 0;
   int old_f = 0;   // a lower bound of the rows of the pending FAST candidates (a pretest batch pushes its four pixel
                    // columns one after the other, so the candidate FIFO is not ordered by row)
   const uint32_t t2 = (uint32_t)THR * 0x00010001u;
 
+  // Harris for 64 corners (pdev::harris_score_mm on the 8 x 8 window rows y-3 .. y+4); Fast.h:172: only x < w - B
+  auto harris_batch = [&](bool valid, uint32_t e) {
+    const int x = e & 0xffff, y = e >> 16;
+    uint8_t sc = 0;
+    if (valid) sc = x < it.xscore ? pdev::harris_score_mm((const pdev::lds_byte *)(rowptr(y) - 3 * P + x - 3), P, HTHR) : (uint8_t)0xff;
+    nscored += (uint32_t)__popcll(__ballot(sc != 0));
+    if (sc != 0) csum += (e + sc) * 2654435761u;
+    if (score_map && blockIdx.y == 0 && valid) score_map[(size_t)(it.row0 + y) * VSTEP + x] = sc ? sc : (uint8_t)1;   // 1 = corner below the threshold
+  };
+  auto pop_corners = [&](bool all) {
+    while (tail_c - head_c >= 64u || (all && tail_c != head_c)) {
+      const uint32_t n = min(64u, tail_c - head_c);
+      lds_wait();
+      harris_batch((uint32_t)lane < n, qc[(head_c + min((uint32_t)lane, n - 1)) & (QC - 1)]);
+      head_c += n;
+    }
+  };
   auto fast_batch = [&](bool valid, uint32_t e) {
     bool corner = false;
     const int x = e & 0xffff, y = e >> 16;
     if (valid) corner = pdev::fast9_mm(rowptr(y) + x, P, THR);
     const uint64_t m = __ballot(corner);
+    if (m == 0) return;
     ncorner += (uint32_t)__popcll(m);
-    if (corner) csum += e * 2654435761u;
+    if (tail_c == head_c) old_c = old_f;               // (a lower bound: the batch's candidates are no older)
+    if (corner) qc[(tail_c + pdev::ballot_rank(m)) & (QC - 1)] = e;
+    tail_c += (uint32_t)__popcll(m);
+    pop_corners(false);
   };
   auto pop_fast = [&](bool all) {
     while (tail_f - head_f >= 64u || (all && tail_f != head_f)) {
@@ -149,29 +177,30 @@ __global__ __launch_bounds__(64) void k_bands(const Item *__restrict__ items, co
     return (int)(__builtin_amdgcn_readfirstlane((int)q[head & mask]) >> 16);
   };
 
-  // prologue: rows y0-3 .. y0+2
-  for (int v = lane; v < 60; v += 64) {
+  // prologue: rows y0-3 .. y0+3
+  for (int v = lane; v < 70; v += 64) {
     const int r = v / 10, c = v - 10 * r;
     park(it.y0 - 3 + r, c, *(const u32x4 *)gaddr(it.y0 - 3 + r, c));
   }
   u32x4 pf[2];
 #pragma unroll
   for (int k = 0; k < 2; k++)
-    if (son[k]) pf[k] = *(const u32x4 *)gaddr(min(it.y0 + 3 + srow[k], it.h - 1), scol[k]);
+    if (son[k]) pf[k] = *(const u32x4 *)gaddr(min(it.y0 + 4 + srow[k], it.h - 1), scol[k]);
   const int g = lane & 31, rr = lane >> 5;
   const int x = it.cx0 + 4 * g;
   const bool colok = x < it.cx1;
   for (int yc = it.y0; yc < it.y1; yc += 8) {
     // entries whose rows the next 8 staged rows would overwrite are classified now (rare in textured areas)
-    if (tail_g != head_g && oldest_row(qg, head_g, QG - 1) < yc - 18) pop_groups(true);
-    if (tail_f != head_f && old_f < yc - 18) pop_fast(true);
-    // rows yc+3 .. yc+10 -> ring; the next chunk's rows -> registers
+    if (tail_g != head_g && oldest_row(qg, head_g, QG - 1) < yc - 17) pop_groups(true);
+    if (tail_f != head_f && old_f < yc - 17) pop_fast(true);
+    if (tail_c != head_c && old_c < yc - 17) pop_corners(true);
+    // rows yc+4 .. yc+11 -> ring; the next chunk's rows -> registers
 #pragma unroll
     for (int k = 0; k < 2; k++)
-      if (son[k]) park(yc + 3 + srow[k], scol[k], pf[k]);
+      if (son[k]) park(yc + 4 + srow[k], scol[k], pf[k]);
 #pragma unroll
     for (int k = 0; k < 2; k++)
-      if (son[k]) pf[k] = *(const u32x4 *)gaddr(min(yc + 11 + srow[k], it.h - 1), scol[k]);
+      if (son[k]) pf[k] = *(const u32x4 *)gaddr(min(yc + 12 + srow[k], it.h - 1), scol[k]);
     lds_wait();
 #pragma unroll 1
     for (int i = 0; i < 4; i++) {
@@ -196,12 +225,23 @@ __global__ __launch_bounds__(64) void k_bands(const Item *__restrict__ items, co
   }
   pop_groups(true);
   pop_fast(true);
+  pop_corners(true);
   // reduce the checksum over the wave
   for (int o = 32; o > 0; o >>= 1) csum += (uint32_t)__shfl_xor((int)csum, o, 64);
   if (lane == 0) {
-    out_count[(size_t)blockIdx.y * nitems + blockIdx.x] = ncorner;
+    out_count[(size_t)blockIdx.y * nitems + blockIdx.x] = ncorner + (nscored << 16);
     out_sum[(size_t)blockIdx.y * nitems + blockIdx.x] = csum;
   }
+}
+
+// straightforward reference on the GPU from the same validated primitives: one thread per pixel of pyramid 0
+__global__ void k_reference(const uint8_t *__restrict__ pyr, uint8_t *__restrict__ score_map, int row0, int w, int h, int xend) {
+  const int x = B + blockIdx.x * blockDim.x + threadIdx.x, y = B + blockIdx.y;
+  if (x >= xend || y >= h - B) return;
+  const uint8_t *c = pyr + (size_t)(row0 + y) * VSTEP + x;
+  if (!pdev::fast9(c, VSTEP, THR)) return;
+  const uint8_t sc = x < w - B ? pdev::harris_score(c, VSTEP, HTHR) : (uint8_t)0xff;
+  score_map[(size_t)(row0 + y) * VSTEP + x] = sc ? sc : (uint8_t)1;
 }
 
 // ---- host ------------------------------------------------------------------------------------------------------
@@ -234,7 +274,7 @@ int main(int argc, char **argv) {
     const int nx = LW[l] - 2 * B, xend = B + 16 * ((nx + 15) / 16);
     const int ny = LH[l] - 2 * B, nseg = (ny + seg - 1) / seg, sh = (((ny + nseg - 1) / nseg) + 7) & ~7;
     for (int cx0 = B; cx0 < xend; cx0 += 128)
-      for (int y0 = B; y0 < LH[l] - B; y0 += sh) items.push_back({row0, LH[l], cx0, std::min(cx0 + 128, xend), y0, std::min(y0 + sh, LH[l] - B)});
+      for (int y0 = B; y0 < LH[l] - B; y0 += sh) items.push_back({row0, LH[l], cx0, std::min(cx0 + 128, xend), y0, std::min(y0 + sh, LH[l] - B), LW[l] - B});
     row0 += LH[l];
   }
   const size_t pyr = (size_t)ROWS * VSTEP;
@@ -252,17 +292,41 @@ int main(int argc, char **argv) {
   hipMemcpy(d_items, items.data(), items.size() * sizeof(Item), hipMemcpyHostToDevice);
   const dim3 grid((unsigned)items.size(), (unsigned)batch);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-  for (int i = 0; i < 200; i++) hipLaunchKernelGGL(k_bands, grid, dim3(64), LDS_BYTES, 0, d_items, d_pyr, d_cnt, d_sum, (int)items.size());
+  for (int i = 0; i < 200; i++) hipLaunchKernelGGL(k_bands, grid, dim3(64), LDS_BYTES, 0, d_items, d_pyr, d_cnt, d_sum, (int)items.size(), (uint8_t *)nullptr);
   hipDeviceSynchronize();
   hipEventRecord(e0);
   const int reps = 50;
-  for (int i = 0; i < reps; i++) hipLaunchKernelGGL(k_bands, grid, dim3(64), LDS_BYTES, 0, d_items, d_pyr, d_cnt, d_sum, (int)items.size());
+  for (int i = 0; i < reps; i++) hipLaunchKernelGGL(k_bands, grid, dim3(64), LDS_BYTES, 0, d_items, d_pyr, d_cnt, d_sum, (int)items.size(), (uint8_t *)nullptr);
   hipEventRecord(e1); hipEventSynchronize(e1);
   float ms; hipEventElapsedTime(&ms, e0, e1);
+  // score maps of pyramid 0: band kernel vs the per-pixel reference kernel
+  uint8_t *d_map, *d_ref;
+  hipMalloc(&d_map, pyr); hipMalloc(&d_ref, pyr); hipMemset(d_map, 0, pyr); hipMemset(d_ref, 0, pyr);
+  hipLaunchKernelGGL(k_bands, dim3((unsigned)items.size(), 1), dim3(64), LDS_BYTES, 0, d_items, d_pyr, d_cnt, d_sum, (int)items.size(), d_map);
+  {
+    int r0 = 0;
+    for (int l = 0; l < 8; l++) {
+      const int nx = LW[l] - 2 * B, xend = B + 16 * ((nx + 15) / 16);
+      hipLaunchKernelGGL(k_reference, dim3((xend - B + 63) / 64, LH[l] - 2 * B), dim3(64), 0, 0, d_pyr, d_ref, r0, LW[l], LH[l], xend);
+      r0 += LH[l];
+    }
+  }
+  hipDeviceSynchronize();
+  std::vector<uint8_t> hmap(pyr), href(pyr);
+  hipMemcpy(hmap.data(), d_map, pyr, hipMemcpyDeviceToHost);
+  hipMemcpy(href.data(), d_ref, pyr, hipMemcpyDeviceToHost);
+  size_t map_diff = 0, map_nz = 0;
+  for (size_t i = 0; i < pyr; i++) {
+    map_diff += hmap[i] != href[i];
+    map_nz += href[i] > 1;
+  }
+  hipLaunchKernelGGL(k_bands, grid, dim3(64), LDS_BYTES, 0, d_items, d_pyr, d_cnt, d_sum, (int)items.size(), (uint8_t *)nullptr);
+  hipDeviceSynchronize();
   std::vector<uint32_t> cnt(items.size() * batch);
   hipMemcpy(cnt.data(), d_cnt, cnt.size() * 4, hipMemcpyDeviceToHost);
   unsigned long long total = 0;
-  for (uint32_t c : cnt) total += c;
+  unsigned long long scored = 0;
+  for (uint32_t &c : cnt) { scored += c >> 16; c &= 0xffff; total += c; }
   // CPU check on pyramid 0
   size_t bad = 0; unsigned long long ref_total = 0;
   for (size_t i = 0; i < items.size(); i++) {
@@ -277,7 +341,9 @@ int main(int argc, char **argv) {
     }
   }
   printf("band probe: %zu items per pyramid (segments of <= %d rows), LDS %d B per wave, %.4f ms per launch of %d pyramids, "
-         "%llu FAST corners (%.0f per pyramid); pyramid 0 vs CPU: %zu of %zu items differ (cpu total %llu)\n",
-         items.size(), seg, LDS_BYTES, ms / reps, batch, total, (double)total / batch, bad, items.size(), ref_total);
-  return bad ? 4 : 0;
+         "%llu FAST corners (%.0f per pyramid), %.0f non-zero Harris scores per pyramid; pyramid 0: %zu of %zu items differ from "
+         "the CPU FAST-9 (cpu total %llu), score map vs the per-pixel reference kernel: %zu bytes differ (%zu scores)\n",
+         items.size(), seg, LDS_BYTES, ms / reps, batch, total, (double)total / batch, (double)scored / batch, bad, items.size(), ref_total,
+         map_diff, map_nz);
+  return bad || map_diff ? 4 : 0;
 }
