@@ -83,15 +83,12 @@ __global__ __launch_bounds__(64) void k_bands(const Item *__restrict__ items, co
   };
   uint32_t ncorner = 0, csum = 0;
   uint32_t head_g = 0, tail_g = 0, head_f = 0, tail_f = 0, head_c = 0, tail_c = 0;   // wave-uniform FIFO cursors (free running)
-  int old_c = 0;
-  uint32_t nscored = 0;
-  int old_f = 0;   // a lower bound of the rows of the pending FAST candidates (a pretest batch pushes its four pixel
-                   // columns one after the other, so the candidate FIFO is not ordered by row)
+  uint32_t nscored = 0, nbatch_h = 0, nbatch_f = 0, nbatch_p = 0;
   const uint32_t t2 = (uint32_t)THR * 0x00010001u;
 
   // Harris for 64 corners (pdev::harris_score_mm on the 8 x 8 window rows y-3 .. y+4); Fast.h:172: only x < w - B
   auto harris_batch = [&](bool valid, uint32_t e) {
-    const int x = e & 0xffff, y = e >> 16;
+    const int x = e & 0xfff, y = (e >> 12) & 0xfff;
     uint8_t sc = 0;
     if (valid) sc = x < it.xscore ? pdev::harris_score_mm((const pdev::lds_byte *)(rowptr(y) - 3 * P + x - 3), P, HTHR) : (uint8_t)0xff;
     nscored += (uint32_t)__popcll(__ballot(sc != 0));
@@ -102,18 +99,18 @@ __global__ __launch_bounds__(64) void k_bands(const Item *__restrict__ items, co
     while (tail_c - head_c >= 64u || (all && tail_c != head_c)) {
       const uint32_t n = min(64u, tail_c - head_c);
       lds_wait();
+      nbatch_h++;
       harris_batch((uint32_t)lane < n, qc[(head_c + min((uint32_t)lane, n - 1)) & (QC - 1)]);
       head_c += n;
     }
   };
   auto fast_batch = [&](bool valid, uint32_t e) {
     bool corner = false;
-    const int x = e & 0xffff, y = e >> 16;
+    const int x = e & 0xfff, y = (e >> 12) & 0xfff;
     if (valid) corner = pdev::fast9_mm(rowptr(y) + x, P, THR);
     const uint64_t m = __ballot(corner);
     if (m == 0) return;
     ncorner += (uint32_t)__popcll(m);
-    if (tail_c == head_c) old_c = old_f;               // (a lower bound: the batch's candidates are no older)
     if (corner) qc[(tail_c + pdev::ballot_rank(m)) & (QC - 1)] = e;
     tail_c += (uint32_t)__popcll(m);
     pop_corners(false);
@@ -122,13 +119,16 @@ __global__ __launch_bounds__(64) void k_bands(const Item *__restrict__ items, co
     while (tail_f - head_f >= 64u || (all && tail_f != head_f)) {
       const uint32_t n = min(64u, tail_f - head_f);
       lds_wait();
+      nbatch_f++;
       fast_batch((uint32_t)lane < n, qf[(head_f + min((uint32_t)lane, n - 1)) & (QF - 1)]);
       head_f += n;
     }
   };
-  auto pretest_batch = [&](bool valid, uint32_t key) {
-    const int x0 = key & 0xffff, y = key >> 16;
-    if (tail_f == head_f) old_f = __builtin_amdgcn_readfirstlane(y);   // lane 0 holds the batch's oldest group
+  auto pretest_batch = [&](bool valid, uint32_t key) {   // key: x | row << 12 of a 4-pixel group
+    const int x0 = key & 0xfff, y = (key >> 12) & 0xfff;
+    // candidates carry (their row - the first row of this batch) in bits 24..31: the FIFOs downstream are ordered by
+    // pretest batch, not by row, and "row - delta" of a FIFO's head entry is a lower bound of all its pending rows
+    key |= (uint32_t)(y - __builtin_amdgcn_readfirstlane(y)) << 24;
     const lds_u8 *trow = rowptr(y);
     const uint32_t wc = *(const lds_u32 *)(trow + x0);
     const uint32_t wl = *(const lds_u32 *)(trow + x0 - 4);
@@ -168,13 +168,15 @@ __global__ __launch_bounds__(64) void k_bands(const Item *__restrict__ items, co
     while (tail_g - head_g >= 64u || (all && tail_g != head_g)) {
       const uint32_t n = min(64u, tail_g - head_g);
       lds_wait();
+      nbatch_p++;
       pretest_batch((uint32_t)lane < n, qg[(head_g + min((uint32_t)lane, n - 1)) & (QG - 1)]);
       head_g += n;
     }
   };
-  auto oldest_row = [&](lds_u32 *q, uint32_t head, int mask) -> int {
+  auto oldest_row = [&](lds_u32 *q, uint32_t head, int mask) -> int {   // lower bound of the pending rows of a FIFO
     lds_wait();
-    return (int)(__builtin_amdgcn_readfirstlane((int)q[head & mask]) >> 16);
+    const uint32_t e = (uint32_t)__builtin_amdgcn_readfirstlane((int)q[head & mask]);
+    return (int)((e >> 12) & 0xfff) - (int)(e >> 24);
   };
 
   // prologue: rows y0-3 .. y0+3
@@ -192,8 +194,8 @@ __global__ __launch_bounds__(64) void k_bands(const Item *__restrict__ items, co
   for (int yc = it.y0; yc < it.y1; yc += 8) {
     // entries whose rows the next 8 staged rows would overwrite are classified now (rare in textured areas)
     if (tail_g != head_g && oldest_row(qg, head_g, QG - 1) < yc - 17) pop_groups(true);
-    if (tail_f != head_f && old_f < yc - 17) pop_fast(true);
-    if (tail_c != head_c && old_c < yc - 17) pop_corners(true);
+    if (tail_f != head_f && oldest_row(qf, head_f, QF - 1) < yc - 17) pop_fast(true);
+    if (tail_c != head_c && oldest_row(qc, head_c, QC - 1) < yc - 17) pop_corners(true);
     // rows yc+4 .. yc+11 -> ring; the next chunk's rows -> registers
 #pragma unroll
     for (int k = 0; k < 2; k++)
@@ -217,7 +219,7 @@ __global__ __launch_bounds__(64) void k_bands(const Item *__restrict__ items, co
       const bool pass = colok && y < it.y1 && min(sv, sh) > (uint32_t)THR;
       const uint64_t m = __ballot(pass);
       if (m == 0) continue;
-      if (pass) qg[(tail_g + pdev::ballot_rank(m)) & (QG - 1)] = (uint32_t)x | ((uint32_t)y << 16);
+      if (pass) qg[(tail_g + pdev::ballot_rank(m)) & (QG - 1)] = (uint32_t)x | ((uint32_t)y << 12);
       tail_g += (uint32_t)__popcll(m);
       pop_groups(false);
     }
@@ -230,7 +232,7 @@ __global__ __launch_bounds__(64) void k_bands(const Item *__restrict__ items, co
   for (int o = 32; o > 0; o >>= 1) csum += (uint32_t)__shfl_xor((int)csum, o, 64);
   if (lane == 0) {
     out_count[(size_t)blockIdx.y * nitems + blockIdx.x] = ncorner + (nscored << 16);
-    out_sum[(size_t)blockIdx.y * nitems + blockIdx.x] = csum;
+    out_sum[(size_t)blockIdx.y * nitems + blockIdx.x] = nbatch_h | (nbatch_f << 10) | (nbatch_p << 21);   // (batch counts)
   }
 }
 
@@ -325,6 +327,11 @@ int main(int argc, char **argv) {
   std::vector<uint32_t> cnt(items.size() * batch);
   hipMemcpy(cnt.data(), d_cnt, cnt.size() * 4, hipMemcpyDeviceToHost);
   unsigned long long total = 0;
+  std::vector<uint32_t> bsum(items.size() * batch);
+  hipMemcpy(bsum.data(), d_sum, bsum.size() * 4, hipMemcpyDeviceToHost);
+  unsigned long long nh = 0, nf = 0, np = 0;
+  for (uint32_t v : bsum) { nh += v & 1023; nf += (v >> 10) & 2047; np += v >> 21; }
+  printf("batches per launch: pretest %llu, FAST %llu, Harris %llu\n", np, nf, nh);
   unsigned long long scored = 0;
   for (uint32_t &c : cnt) { scored += c >> 16; c &= 0xffff; total += c; }
   // CPU check on pyramid 0
