@@ -1301,10 +1301,15 @@ int run_fused(pislam_ctx *c, const pislam_frontend_params *p, const pf::FusedPar
     return launch_ok(c, "k_orb<batch>");
   }
   // gather + orbCompute in one launch: (chunks, batch) workgroups
-  // Workgroups per pyramid: ~16 (61 keypoints each at 981 per pyramid) but such that the grid is a whole number of
-  // "waves" of resident workgroups (7 per CU: 64 VGPRs, 13.5 KB LDS) — batch 256: 14 chunks = 2 x 1792 workgroups
+  // Workgroups per pyramid: one per ~70 k classified pixels (keypoint counts are not known to the host; ~70-100
+  // keypoints per workgroup measured best: VGA, 981 keypoints: 14 = 21 chunks > 7, 28; 1280x960, 4389 keypoints: 42-49
+  // chunks 0.36 ms against 0.41 ms with 14), at least 16 for small batches, and such that the grid is a whole number
+  // of "waves" of resident workgroups (7 per CU: 64 VGPRs, 13.5 KB LDS) — batch 256: 14 chunks = 2 x 1792 workgroups
   // measured 0.079 ms against 0.085 ms with 16 (2.3 waves: the last one 30 % full).
-  int nch = std::min(64, std::max(16, 4096 / batch));
+  long px = 0;
+  for (int l = 0; l < F.nlevels; l++) px += (long)(F.lv[l].ex1 - F.lv[l].ex0) * F.lv[l].nstrips * F.lv[l].R;
+  const int by_px = (int)(px / 70000);
+  int nch = std::min(64, batch >= 128 ? std::max(8, by_px) : std::max(by_px, std::max(16, 4096 / batch)));
   {
     const long slots = 7L * std::max(1, c->num_cus);
     long best = nch, bestd = 1L << 40;
