@@ -7,30 +7,64 @@
 A "step" is one pass of the whole hot path (fastDetect -> fastScoreHarris -> fastExtract ->
 orbCompute on every level of every pyramid) over one device-resident batch of 256 synthetic
 pyramids per GPU (BASELINE.json configs[1]); for N>1 each rank owns its own 256 pyramids (weak
-scaling) and the step ends with the RCCL all-gather of the per-pyramid keypoint counts.
+scaling, configs[2]) and the step ends with the RCCL all-gather of the per-pyramid keypoint counts.
 Prints ONE JSON line on rank 0.
+
+Process structure for N > 1 (the run must not be lost to a hang): every torchrun rank is a SUPERVISOR that
+never touches the GPU.  The supervisors (a gloo group of their own) start one WORKER child per rank with a
+rendezvous port of its own, wait for it under a timeout, agree on the outcome, and on a failure or a hang kill
+the workers and retry one rung further down a ladder of safer configurations (eager launches instead of
+hipGraph replay -> one stream -> torch.distributed's all-gather instead of the C-ABI communicator -> counts
+gathered on the host through gloo); the JSON line lists what was dropped (`config.dist_fallbacks`).  A
+wall-clock cap ends the whole run with rc != 0 and a message if nothing works.
 """
 import argparse
 import json
 import os
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-import numpy as np
-import torch
-
 HBM_PEAK_GBPS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+METRIC = "ORB keypoints+descriptors/sec, 640x480 8-level pyramid"
+PROFILE_TAG = "r03"             # profiles/<tag>_counters_<workload>.json holds the PMC passes bench lines quote
+
+
+# ---------------------------------------------------------------------------------------------------------
+# host facts
+# ---------------------------------------------------------------------------------------------------------
+def effective_cores():
+    """CPUs this process can really use: the affinity mask, narrowed by a cgroup CPU quota (cpu.max, v2; or
+    cfs_quota_us / cfs_period_us, v1).  Returns (visible, effective, how)."""
+    vis = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    eff, how = float(vis), "sched_getaffinity"
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            lim = float(q) / float(p)
+            if lim < eff:
+                eff, how = lim, f"cgroup cpu.max {q}/{p}"
+    except Exception:                                   # noqa: BLE001
+        try:
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0 and q / p < eff:
+                eff, how = q / p, f"cgroup cfs quota {int(q)}/{int(p)}"
+        except Exception:                               # noqa: BLE001
+            pass
+    return vis, eff, how
 
 
 def cpu_baseline(pyr_host, levels, budget_s=10.0, mt_s=3.0):
     """The oracle (bit-exact plain-C restatement of the reference path, oracle/pislam_oracle.c) timed
     on ONE host thread — the reference itself is single-threaded — on a bounded sample of the same
-    workload; then the same port on EVERY visible host thread (pthreads inside liborc, one pyramid per
+    workload; then the same port on every visible host thread (pthreads inside liborc, one pyramid per
     thread at a time, timed in C) for >= mt_s seconds.  levels: (w, h, row0[, col0])."""
+    import numpy as np
     from oracle import orc
     orc.lib()
     CPU_CAP = 16384                                       # output capacity per pyramid (keeps allocation out of the timing)
@@ -43,21 +77,27 @@ def cpu_baseline(pyr_host, levels, budget_s=10.0, mt_s=3.0):
         if time.perf_counter() - t0 > budget_s:
             break
     dt = time.perf_counter() - t0
+    vis, eff, how = effective_cores()
     out = {"value": n_kp / dt, "unit": "kp+desc/s", "cores": 1, "kind": "port",
            "sample": f"{n_pyr} pyramids of the batch ({n_kp} keypoints) in {dt:.2f} s, 1 thread, "
-                     f"oracle/pislam_oracle.c -O3 on {os.cpu_count()} visible host cores"}
+                     f"oracle/pislam_oracle.c -O3; host: {vis} CPUs visible, {eff:.1f} usable ({how})"}
     # reported beside the single-thread figure, which stays `value`
     try:
-        nthr = max(1, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
+        nthr = max(1, vis)
         tot, done, dt2 = orc.pyramid_mt(np.ascontiguousarray(pyr_host), levels, nthr, mt_s, cap=CPU_CAP)
-        out["all_threads"] = {"value": tot / dt2, "cores": nthr,
-                              "sample": f"{done} pyramids ({tot} keypoints) in {dt2:.2f} s, {nthr} pthreads (orc_pyramid_mt)"}
+        out["all_threads"] = {"value": tot / dt2, "threads": nthr, "cores_visible": vis, "cores_effective": round(eff, 2),
+                              "cores_effective_source": how,
+                              "sample": f"{done} pyramids ({tot} keypoints) in {dt2:.2f} s, {nthr} pthreads (orc_pyramid_mt) "
+                                        f"on {eff:.1f} usable CPUs"}
     except Exception as e:                                   # never let the extra leg break the bench line
         out["all_threads"] = {"error": repr(e)}
     return out
 
 
-def main():
+# ---------------------------------------------------------------------------------------------------------
+# arguments
+# ---------------------------------------------------------------------------------------------------------
+def build_parser():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
@@ -73,22 +113,23 @@ def main():
                     help="testing only (N=1): run the per-step count all-gather anyway, through a 1-rank RCCL communicator "
                          "created by the C ABI (pislam_dist_*), so that the N>1 data path is exercised on a 1-GPU box")
     ap.add_argument("--selftest-spawn", action="store_true",
-                    help="testing only: exercise launch + rendezvous + count exchange with fake counts on the CPU "
-                         "(no GPU work, value is null)")
+                    help="testing only: exercise launch + supervision + rendezvous + count exchange with fake counts on "
+                         "the CPU (no GPU work, value is null)")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="budget of the 1-thread cpu_baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dist-backend", default=None,
                     help="override the torch.distributed backend (default nccl = RCCL); 'gloo' lets the N>1 code "
                          "path be exercised with several ranks sharing one GPU (testing only)")
+    ap.add_argument("--exchange", default="cabi", choices=["cabi", "torch"],
+                    help="N>1 count all-gather: the C ABI's communicator (pislam_dist_*, default) or torch.distributed's")
     ap.add_argument("--workload", default="vga", choices=["vga", "1280x960", "720p-build"],
-                    help="vga = BASELINE configs[1] (default, the headline); 1280x960 = configs[3] (packed layout, "
-                         "vstep 1280); 720p-build = configs[4] (gaussian5x5 + bilinear pyramid build on the GPU inside "
-                         "the timed step)")
+                    help="vga = BASELINE configs[1] (default, the headline; configs[2] when N>1); 1280x960 = configs[3] "
+                         "(packed layout, vstep 1280); 720p-build = configs[4] (gaussian5x5 + bilinear pyramid build on "
+                         "the GPU inside the timed step)")
     ap.add_argument("--pipeline", type=int, default=0, help="0 auto (fused), 1 staged, 2 fused")
     ap.add_argument("--strip-rows", type=int, default=0)
     ap.add_argument("--orb-chunks", type=int, default=0)
     ap.add_argument("--wgs-per-cu", type=int, default=0)
-    ap.add_argument("--xtile-cols", type=int, default=-1)
     ap.add_argument("--run-len", type=int, default=0)
     ap.add_argument("--alias", type=int, default=-1)
     ap.add_argument("--run-order", type=int, default=-1, help="1 (default): a pyramid's runs are launched longest first; 0: entry order")
@@ -99,9 +140,14 @@ def main():
     ap.add_argument("--graph", type=int, default=1,
                     help="1 (default): capture the step's launches into a hipGraph (torch.cuda.CUDAGraph) per output set "
                          "and replay it — falls back to eager launches if the capture or its check fails; 0: eager")
-    ap.add_argument("--streams", type=int, default=3,
-                    help="independent pipelines (HIP stream + context + outputs + graph); step k runs on pipeline "
-                         "k %% S, so consecutive batches overlap on the GPU (default 3; 1 = strictly one batch at a time)")
+    ap.add_argument("--streams", type=int, default=0,
+                    help="caller-side pipelines (HIP stream + context + outputs + graph); step k runs on pipeline k %% S, so "
+                         "consecutive batches overlap on the GPU.  0 = default (3); 1 = strictly one batch call at a time")
+    ap.add_argument("--opt", action="append", default=[], metavar="KEY=VALUE",
+                    help="any library option (pislam_ctx_set_option), e.g. --opt sub_batches=2; repeatable")
+    ap.add_argument("--margins-clean", type=int, default=1,
+                    help="720p-build: 1 (default) the per-step rebuild vouches for the zero margins its own first fill left "
+                         "(PISLAM_BUILD_MARGINS_CLEAN: the steady state of a stream refilling one buffer); 0 re-zeroes them every step")
     ap.add_argument("--match", action="store_true",
                     help="also match every pyramid's descriptors against its neighbour's inside the step (SURVEY 8f-4)")
     ap.add_argument("--match-mfma", type=int, default=-1, help="--match: 1 (default) matrix-core matcher, 0 the VALU popcount kernel")
@@ -109,32 +155,255 @@ def main():
     ap.add_argument("--log-bucket-size", type=int, default=0, help="fastExtract logBucketSize (README uses 4)")
     ap.add_argument("--bucket-limit", type=int, default=5, help="fastExtract bucketLimit (README uses 3)")
     ap.add_argument("--ablate", type=int, default=0, help="profiling only (results invalid): fused-kernel phase mask")
-    args = ap.parse_args()
-    if not args.max_keypoints:
-        args.max_keypoints = 4096 if args.workload == "vga" else 8192
+    # ---- supervision of the N>1 run ----
+    ap.add_argument("--wall-cap", type=float, default=900.0,
+                    help="wall-clock cap in seconds for the whole run incl. every fallback attempt (rc != 0 beyond it)")
+    ap.add_argument("--attempt-timeout", type=float, default=300.0, help="N>1: hard timeout of one worker attempt")
+    ap.add_argument("--selfcheck-timeout", type=float, default=60.0,
+                    help="N>1 worker: hard timeout of the start-up self-check (2 untimed steps per pipeline incl. the exchange)")
+    ap.add_argument("--worker", action="store_true", help=argparse.SUPPRESS)            # a supervisor's child
+    ap.add_argument("--attempt", type=int, default=0, help=argparse.SUPPRESS)
+    ap.add_argument("--dropped", default="[]", help=argparse.SUPPRESS)                  # JSON list: what earlier attempts dropped
+    return ap
 
+
+# ---------------------------------------------------------------------------------------------------------
+# N > 1: supervisors
+# ---------------------------------------------------------------------------------------------------------
+# The ladder: (what this rung DROPS relative to the previous one, argument overrides — cumulative)
+LADDER = [
+    (None, {}),
+    ("hipGraph replay -> eager launches", {"graph": 0}),
+    ("batches in flight on several streams -> one stream, one batch call at a time", {"streams": 1}),
+    ("C-ABI RCCL communicator (pislam_dist_*) -> torch.distributed all-gather", {"exchange": "torch"}),
+    ("RCCL -> counts all-gathered on the host through gloo (no GPU collective)", {"dist_backend": "gloo"}),
+]
+
+
+def _inject(stage: str, attempt: int, rank: int):
+    """Test hook: PISLAM_BENCH_INJECT="<attempt>:<stage>:<mode>[:<rank>],..." with stage in {start, selfcheck, run} and
+    mode in {hang, fail, exit}: lets the CPU tests break a chosen attempt at a chosen stage and watch the ladder."""
+    spec = os.environ.get("PISLAM_BENCH_INJECT", "")
+    for item in filter(None, spec.split(",")):
+        f = item.split(":")
+        if int(f[0]) != attempt or f[1] != stage or (len(f) > 3 and int(f[3]) != rank):
+            continue
+        if f[2] == "hang":
+            time.sleep(10 ** 6)
+        if f[2] == "exit":
+            os._exit(7)
+        raise RuntimeError(f"injected failure at attempt {attempt}, stage {stage}")
+
+
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def supervisor_main(args, argv):
+    """One per torchrun rank.  CPU only: starts the rank's worker, enforces timeouts, walks the ladder."""
+    import datetime
+    import signal
+    import subprocess
+    import tempfile
+    import torch
+    import torch.distributed as dist
+
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    deadline = time.monotonic() + args.wall_cap
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    dist.init_process_group(backend="gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=120))
+    child = {"p": None}
+
+    def kill_child():
+        p = child["p"]
+        if p is not None and p.poll() is None:
+            try:
+                os.killpg(p.pid, signal.SIGKILL)
+            except Exception:                           # noqa: BLE001
+                pass
+            try:
+                p.wait(timeout=10)
+            except Exception:                           # noqa: BLE001
+                pass
+
+    def on_term(signum, frame):                         # torchrun tearing the job down: take the worker with us
+        kill_child()
+        os._exit(128 + signum)
+
+    signal.signal(signal.SIGTERM, on_term)
+    signal.signal(signal.SIGINT, on_term)
+
+    def agree_max(v: int) -> int:
+        t = torch.tensor([v], dtype=torch.int64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return int(t.item())
+
+    cfg = {"graph": args.graph, "streams": args.streams, "exchange": args.exchange, "dist_backend": args.dist_backend}
+    dropped, tried, attempt, history = [], set(), 0, []
+    rc_final, line = 3, None
+    tmpdir = tempfile.mkdtemp(prefix="pislam_bench_")
+    for label, over in LADDER:
+        new = dict(cfg, **over)
+        if label is not None and new == cfg:            # this rung drops nothing the configuration still has
+            continue
+        cfg = new
+        if label is not None:
+            dropped.append(label)
+        key = json.dumps(cfg, sort_keys=True)
+        if key in tried:
+            continue
+        tried.add(key)
+        if agree_max(1 if deadline - time.monotonic() < 30 else 0):
+            history.append("wall-clock cap reached before the next attempt")
+            break
+        # a rendezvous port of its own for this attempt's workers (rank 0 draws it)
+        port = torch.tensor([_free_port() if rank == 0 else 0], dtype=torch.int64)
+        dist.broadcast(port, src=0)
+        wargs = list(argv) + ["--worker", "--attempt", str(attempt), "--dropped", json.dumps(dropped), "--graph", str(cfg["graph"]),
+                              "--streams", str(cfg["streams"]), "--exchange", cfg["exchange"]]
+        if cfg["dist_backend"]:
+            wargs += ["--dist-backend", cfg["dist_backend"]]
+        # (the workers rendezvous among themselves on the fresh port: rank 0 hosts the store — torchrun's
+        #  TORCHELASTIC_USE_AGENT_STORE would make it look for the agent's store there instead)
+        env = {k: v for k, v in os.environ.items() if not k.startswith("TORCHELASTIC_")}
+        env.update(MASTER_PORT=str(int(port.item())), MASTER_ADDR="127.0.0.1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        out_path = os.path.join(tmpdir, f"attempt{attempt}_rank{rank}.out")
+        timeout = max(10.0, min(args.attempt_timeout, deadline - time.monotonic() - 15))
+        with open(out_path, "w") as fout:
+            p = subprocess.Popen([sys.executable, os.path.abspath(__file__)] + wargs, env=env, stdout=fout,
+                                 stderr=None, start_new_session=True, cwd=os.getcwd())
+            child["p"] = p
+            t0 = time.monotonic()
+            while True:
+                rc = p.poll()
+                if rc is not None:
+                    status = "ok" if rc == 0 else f"worker exit code {rc}"
+                    break
+                if time.monotonic() - t0 > timeout:
+                    status = f"worker still running after {timeout:.0f} s: killed"
+                    kill_child()
+                    break
+                time.sleep(0.1)
+        bad = agree_max(0 if status == "ok" else 1)
+        if not bad:
+            if rank == 0:
+                lines = [ln for ln in open(out_path).read().splitlines() if ln.startswith("{")]
+                line = lines[-1] if lines else None
+            if not agree_max(0 if (rank != 0 or line) else 1):
+                rc_final = 0
+                break
+            status = "rank 0's worker printed no JSON line"
+        kill_child()                                    # every rank's worker of a failed attempt goes away
+        history.append(f"attempt {attempt} ({'as configured' if not dropped else 'after dropping: ' + dropped[-1]}): "
+                       f"rank {rank}: {status}")
+        if rank == 0:
+            print(f"[bench supervisor] {history[-1]}{'; a rank failed' if bad else ''} -> next rung", file=sys.stderr, flush=True)
+        attempt += 1
+    if rank == 0:
+        if rc_final == 0:
+            print(line, flush=True)
+        else:
+            print(f"[bench supervisor] no configuration completed (wall cap {args.wall_cap:.0f} s): " + " | ".join(history),
+                  file=sys.stderr, flush=True)
+    try:
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception:                                   # noqa: BLE001
+        pass
+    return rc_final
+
+
+# ---------------------------------------------------------------------------------------------------------
+# the worker (the whole bench for N = 1)
+# ---------------------------------------------------------------------------------------------------------
+class Watchdog:
+    """Hard timeout for a phase that can hang inside a C call (a wedged collective, a stuck stream sync): Python
+    signal handlers do not run there, a daemon thread does.  On expiry: message, stack dump, os._exit(rc)."""
+
+    def __init__(self, seconds: float, what: str, rc: int = 4):
+        self.t = threading.Timer(seconds, self._fire)
+        self.t.daemon = True
+        self.what, self.rc, self.seconds = what, rc, seconds
+
+    def _fire(self):
+        import faulthandler
+        print(f"[bench worker rank {os.environ.get('RANK', '0')}] {self.what} did not finish within {self.seconds:.0f} s: aborting",
+              file=sys.stderr, flush=True)
+        try:
+            faulthandler.dump_traceback(file=sys.stderr)
+        except Exception:                               # noqa: BLE001
+            pass
+        os._exit(self.rc)
+
+    def __enter__(self):
+        self.t.start()
+        return self
+
+    def __exit__(self, *exc):
+        self.t.cancel()
+        return False
+
+
+def load_counters(workload: str, batch: int, buckets: bool):
+    """PMC passes cannot run inside this process: HBM bytes and instruction counts per step come from the
+    committed profile of this workload (tools/profile_round.sh -> profiles/<tag>_counters_<workload>.json) and are
+    used ONLY when that profile was taken on exactly these kernel sources and this shape."""
+    from pislam_amd import build as pbuild
+    path = os.path.join(ROOT, "profiles", f"{PROFILE_TAG}_counters_{workload}.json")
+    rel = os.path.relpath(path, ROOT)
+    if buckets or not os.path.exists(path):
+        return None, f"null: no PMC profile for this workload / configuration ({rel})"
+    try:
+        tj = json.load(open(path))
+    except Exception as e:                              # noqa: BLE001
+        return None, f"null: {e!r}"
+    if tj.get("source_hash") != pbuild.source_hash():
+        return None, f"null: {rel} was measured on kernel sources {tj.get('source_hash')}, this run uses {pbuild.source_hash()}"
+    if tj.get("batch") != batch:
+        return None, f"null: {rel} was measured at batch {tj.get('batch')}"
+    return tj, f"{rel} (rocprofv3 --pmc passes on kernel sources {tj['source_hash']}: {tj.get('command', '')}; not measured in this run)"
+
+
+def worker_main(args):
+    import numpy as np
+    import torch
     from pislam_amd import dist as pdist
 
-    if args.gpus < 1:
-        raise SystemExit("--gpus must be >= 1")
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        # Plain `python bench.py --gpus N`: start the N ranks ourselves (one process per GPU under
-        # torch.distributed.run on 127.0.0.1); rank 0 prints the JSON line.
-        shared_ok = args.dist_backend == "gloo" or args.selftest_spawn     # test modes: ranks may share a GPU / need none
-        if not shared_ok and torch.cuda.device_count() < args.gpus:
-            raise SystemExit(f"bench.py --gpus {args.gpus}: only {torch.cuda.device_count()} GPU(s) visible "
-                             "(one process per GPU; there is no CPU fallback)")
-        raise SystemExit(pdist.self_launch([os.path.abspath(__file__)] + sys.argv[1:], args.gpus))
-
-    rank, local_rank, world = pdist.init(backend="gloo" if args.selftest_spawn else args.dist_backend)
+    selftest = args.selftest_spawn
+    dropped = json.loads(args.dropped)
+    _inject("start", args.attempt, int(os.environ.get("RANK", "0")))
+    rank, local_rank, world = pdist.init(backend="gloo" if selftest else args.dist_backend)
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus} "
                          "(or run `python bench.py --gpus N` without a torchrun environment)")
-    if args.selftest_spawn:
-        # launch / rendezvous / exchange plumbing only (CPU, gloo): every rank contributes fake counts
+
+    def agree_any(flag: bool, dev=None) -> bool:
+        """True on every rank if `flag` is true on any rank (control plane)."""
+        if world == 1:
+            return flag
+        import torch.distributed as dist
+        t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=dev if dist.get_backend() == "nccl" else None)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return bool(int(t.item()))
+
+    if selftest:
+        # launch / supervision / rendezvous / exchange plumbing only (CPU, gloo): every rank contributes fake counts
         B = 4
         fake = torch.arange(B, dtype=torch.int32) + 100 * rank
         xchg = pdist.CountExchange(world)
+        with Watchdog(args.selfcheck_timeout, "start-up self-check"):
+            _inject("selfcheck", args.attempt, rank)
+            for _ in range(2):
+                xchg.before_step()
+                xchg.start(fake)
+            xchg.finish()
+        _inject("run", args.attempt, rank)
         xchg.before_step()
         xchg.start(fake)
         allc = xchg.finish()
@@ -142,25 +411,26 @@ def main():
         if world > 1:
             torch.distributed.barrier()
         if rank == 0:
-            print(json.dumps({"metric": "ORB keypoints+descriptors/sec, 640x480 8-level pyramid", "value": None,
-                              "unit": "kp+desc/s", "n_gpus": world, "selftest": "spawn", "exchange_ok": ok,
-                              "count_allgather": xchg.path}))
+            print(json.dumps({"metric": METRIC, "value": None, "unit": "kp+desc/s", "n_gpus": world, "selftest": "spawn",
+                              "exchange_ok": ok, "count_allgather": xchg.path,
+                              "config": {"dist_fallbacks": dropped, "rccl_ranks": None, "attempt": args.attempt,
+                                         "graph": args.graph, "streams": args.streams, "exchange": args.exchange,
+                                         "dist_backend": args.dist_backend}}), flush=True)
         if world > 1:
             torch.distributed.destroy_process_group()
-        return
+        return 0
 
     from pislam_amd import synth
     from pislam_amd.frontend import OrbFrontend
     from pislam_amd.capi import Context
 
-    if args.dist_backend == "gloo":
-        local_rank = local_rank % max(1, torch.cuda.device_count())   # ranks may share a GPU in this test mode
+    gloo_mode = args.dist_backend == "gloo"
+    if gloo_mode:
+        local_rank = local_rank % max(1, torch.cuda.device_count())   # ranks may share a GPU in this mode
     assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU fallback)"
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 
-    builder = None
-    d_frames = None
     if args.workload == "vga":
         levels = synth.level_table()                       # demo.cpp:38-47 table, 2210 stacked rows
         vstep, w0, h0 = 640, 640, 480
@@ -173,13 +443,17 @@ def main():
     B = args.batch
     distinct = args.distinct or (B if args.workload == "vga" else min(B, 16))
     first = rank * B
-    S = 1 if args.match else max(1, args.streams)
+    S = 1 if args.match else (args.streams if args.streams > 0 else 3)
     force = args.force_exchange and world == 1
     # Output sets per pipeline: two whenever counts are exchanged, so that a pipeline's next step (into the other
     # set) does not wait for the all-gather of its previous one — the collective's latency (event hand-over to the
-    # collective stream + a latency-bound RCCL kernel, ~50 us) would otherwise be added to every pipeline cycle
-    # (measured on a 1-rank communicator, 3 pipelines: 0.275 ms per step with one set).
+    # collective stream + a latency-bound RCCL kernel, ~50 us) would otherwise be added to every pipeline cycle.
     nsets = 2 if (world > 1 or force) else 1
+    fallbacks = list(dropped)                              # what the supervisors' ladder dropped + what this worker drops
+    extra_opts = []
+    for kv in args.opt:
+        k, _, v = kv.partition("=")
+        extra_opts.append((k.strip(), int(v)))
 
     def make_context(stream):
         c = Context(device=local_rank, stream=stream.cuda_stream)
@@ -187,26 +461,15 @@ def main():
         c.set_option("strip_rows", args.strip_rows)
         c.set_option("orb_chunks", args.orb_chunks)
         c.set_option("lds_pad", args.lds_pad)
-        if args.alias >= 0:
-            c.set_option("alias", args.alias)
-        if args.run_order >= 0:
-            c.set_option("run_order", args.run_order)
-        if args.strip_px:
-            c.set_option("strip_px", args.strip_px)
-        if args.strip_rows_max:
-            c.set_option("strip_rows_max", args.strip_rows_max)
-        if args.tile_cols:
-            c.set_option("tile_cols", args.tile_cols)
-        if args.orb_in_strip >= 0:
-            c.set_option("orb_in_strip", args.orb_in_strip)
-        if args.match_mfma >= 0:
-            c.set_option("match_mfma", args.match_mfma)
-        if args.run_len:
-            c.set_option("run_len", args.run_len)
-        if args.xtile_cols >= 0:
-            c.set_option("xtile_cols", args.xtile_cols)
-        if args.wgs_per_cu:
-            c.set_option("wgs_per_cu", args.wgs_per_cu)
+        for key, val, on in (("alias", args.alias, args.alias >= 0), ("run_order", args.run_order, args.run_order >= 0),
+                             ("strip_px", args.strip_px, args.strip_px), ("strip_rows_max", args.strip_rows_max, args.strip_rows_max),
+                             ("tile_cols", args.tile_cols, args.tile_cols), ("orb_in_strip", args.orb_in_strip, args.orb_in_strip >= 0),
+                             ("match_mfma", args.match_mfma, args.match_mfma >= 0), ("run_len", args.run_len, args.run_len),
+                             ("wgs_per_cu", args.wgs_per_cu, args.wgs_per_cu)):
+            if on:
+                c.set_option(key, val)
+        for k, v in extra_opts:
+            c.set_option(k, v)
         c.set_option("ablate", args.ablate)
         return c
 
@@ -225,19 +488,19 @@ def main():
             d_pyr0 = d_pyr0[torch.arange(B, device=dev) % distinct].contiguous()
 
     # ---- S independent pipelines: batch k runs on pipeline k % S — its own HIP stream, context (workspace),
-    # outputs and hipGraph — so that the gather+ORB kernel of one batch (latency / LDS bound) and the tail of its
-    # strip kernel run under the strip kernel of the next batch (VALU bound).  Every batch is still processed
-    # completely (strips -> overflow pass -> gather+ORB, then the count all-gather) inside the timed region.
+    # outputs and hipGraph — so that the tail of one batch call runs under the head of the next.  Every batch is
+    # still processed completely (strips -> overflow pass -> gather+ORB, then the count all-gather) inside the
+    # timed region.
     class Pipe:
         pass
 
     pipes = []
-    rccl_note = None
     for i in range(S):
         P = Pipe()
         P.stream = torch.cuda.Stream(dev)
         P.ctx = make_context(P.stream)
         P.builder = None
+        P.graphs = None
         with torch.cuda.stream(P.stream):
             if args.workload == "720p-build":
                 P.builder = PyramidBuilder(w0, h0, ctx=P.ctx)
@@ -253,29 +516,37 @@ def main():
                                log_bucket_size=args.log_bucket_size, bucket_limit=args.bucket_limit)
             P.fe.reserve(B)
             P.outs = [P.fe.alloc_outputs(B, dev) for _ in range(nsets)]
-        # The count all-gather goes through the C ABI (pislam_dist_*: RCCL communicator from a unique id,
-        # ncclAllGather on the context's collective stream), one communicator per pipeline context.  Ranks
-        # sharing one GPU (gloo test mode) cannot form an RCCL communicator; if the C-ABI path fails on any
-        # rank, all ranks fall back to torch.distributed's all-gather and the JSON line says so.
-        err = None
-        if world > 1 and args.dist_backend == "gloo":
-            err = "test mode: ranks share a GPU"
-        elif world > 1:
-            err = pdist.init_rccl(P.ctx, rank, world, dev)
-            if err and rank == 0:
-                print(f"[bench] C-ABI RCCL path unavailable, using torch.distributed: {err}", file=sys.stderr)
-        if force:
-            from pislam_amd import capi
-            P.ctx.set_option("dist_rccl_single", 1)
-            P.ctx.dist_init(capi.dist_unique_id(), 0, 1)
-        P.xchg = pdist.CountExchange(world, ctx=P.ctx if ((world > 1 and err is None) or force) else None,
-                                     always_collective=force, sets=nsets)
-        rccl_note = rccl_note or err
         pipes.append(P)
     ctx, fe, builder, d_pyr = pipes[0].ctx, pipes[0].fe, pipes[0].builder, pipes[0].d_pyr
     stream = pipes[0].stream
     kp, desc, counts = pipes[0].outs[0]
+
+    # ---- the count all-gather: ONE communicator and ONE collective stream per process, shared by all pipelines
+    # (pislam_amd.dist.ExchangeHub over the C ABI's pislam_dist_*).  Ranks sharing one GPU (gloo test mode) cannot
+    # form an RCCL communicator; if the C-ABI path fails on any rank, all ranks fall back to torch.distributed's
+    # all-gather and the JSON line says so.
+    hub = None
+    if world > 1 and not gloo_mode and args.exchange == "cabi":
+        err = pdist.init_rccl(ctx, rank, world, dev)
+        if err:
+            fallbacks.append(f"C-ABI RCCL communicator unavailable ({err}) -> torch.distributed all-gather")
+            if rank == 0:
+                print(f"[bench] C-ABI RCCL path unavailable, using torch.distributed: {err}", file=sys.stderr)
+        else:
+            hub = pdist.ExchangeHub(ctx)
+    if force:
+        from pislam_amd import capi
+        ctx.set_option("dist_rccl_single", 1)
+        ctx.dist_init(capi.dist_unique_id(), 0, 1)
+        hub = pdist.ExchangeHub(ctx)
+    for P in pipes:
+        P.xchg = pdist.CountExchange(world, hub=hub, always_collective=force, sets=nsets, stream=P.stream.cuda_stream)
     xchg = pipes[0].xchg
+    rccl_ranks = None
+    if hub is not None:
+        rccl_ranks = ctx.dist_comm_count()                 # what RCCL itself says (ncclCommCount)
+    elif world > 1 and not gloo_mode:
+        rccl_ranks = torch.distributed.get_world_size()    # torch's RCCL process group
 
     m_out = None
     if args.match:
@@ -292,7 +563,7 @@ def main():
         if P.builder is not None:
             # steady state of a stream: the same pyramid buffer is refilled every step by the same builder
             # (its first fill, before the timed region, established the zero margins)
-            P.builder(d_frames, P.d_pyr, margins_clean=True)
+            P.builder(d_frames, P.d_pyr, margins_clean=bool(args.margins_clean))
         P.fe(P.d_pyr, k_, d_, c_)
         if m_out is not None:
             matchHammingBatch(d_, c_, t_desc, t_counts, *m_out, ctx=P.ctx)
@@ -302,6 +573,7 @@ def main():
         # The batch call allocates nothing and never synchronises once the workspace is reserved, so a step's
         # launches can be replayed from a hipGraph.  Any failure (capture error, replay not reproducing the
         # eager counts) falls back to eager launches: the measurement must never depend on this.
+        graph_err = None
         try:
             for P in pipes:
                 with torch.cuda.stream(P.stream):
@@ -326,11 +598,16 @@ def main():
                     torch.cuda.synchronize()
                     if not torch.equal(o[2], w):
                         raise RuntimeError("graph replay does not reproduce the eager result")
-            use_graphs = True
         except Exception as e:                          # noqa: BLE001
-            print(f"[bench] hipGraph path disabled: {e!r}", file=sys.stderr)
+            graph_err = repr(e)
+            print(f"[bench rank {rank}] hipGraph path disabled: {graph_err}", file=sys.stderr)
             torch.cuda.synchronize()
-    graphs = pipes[0].graphs if use_graphs else None
+        # every rank takes the same path (a rank replaying graphs beside ranks launching eagerly would be a
+        # different measurement per rank)
+        if agree_any(graph_err is not None, dev):
+            fallbacks.append("hipGraph capture failed on a rank -> eager launches" + (f" ({graph_err})" if graph_err else ""))
+        else:
+            use_graphs = True
 
     def step():
         k = nstep[0]
@@ -346,6 +623,14 @@ def main():
             P.xchg.start(P.outs[i][2])
         return P
 
+    def finish_all(last=None):
+        r = None
+        for P in pipes:                                 # every step's all-gather has completed
+            v = P.xchg.finish()
+            if P is last:
+                r = v
+        return r
+
     def spin_once():
         for P in pipes:
             with torch.cuda.stream(P.stream):
@@ -354,10 +639,29 @@ def main():
                 else:
                     launches(P, *P.outs[0])
 
+    # ---- start-up self-check (N > 1): two untimed steps per pipeline INCLUDING the exchange, under a hard timeout
+    # — a collective that cannot complete must end this worker (the supervisors then walk the ladder), not the
+    # driver's one shot at the 8-GPU run.
+    if world > 1 or force:
+        with Watchdog(args.selfcheck_timeout, "start-up self-check (2 steps per pipeline + count all-gather)"):
+            _inject("selfcheck", args.attempt, rank)
+            n_chk = 2 * S
+            for _ in range(n_chk):
+                step()
+            Pl = pipes[(n_chk - 1) % S]
+            chk = finish_all(Pl)
+            torch.cuda.synchronize()
+            mine = Pl.outs[((n_chk - 1) // S) % nsets][2]
+            bad = not torch.equal(chk[rank * B:(rank + 1) * B].cpu(), mine.cpu())
+            if agree_any(bad, dev):
+                raise SystemExit("start-up self-check: the gathered counts do not hold this rank's counts")
+        nstep[0] = 0
+
     # Clock ramp: the GPU idles at a few hundred MHz and needs a fraction of a second of load to reach its
     # sustained clocks — far longer than a handful of 0.4 ms steps.  Spin the same step, untimed, before the W
     # warm-up steps so that W and K measure the steady state whatever their values.
     # (No collective in here: the loop is time-based, so ranks run different iteration counts.)
+    _inject("run", args.attempt, rank)
     t_spin = time.perf_counter()
     while time.perf_counter() - t_spin < args.spin_s:
         for _ in range(8):
@@ -365,8 +669,7 @@ def main():
         torch.cuda.synchronize()
     for _ in range(args.warmup):
         step()
-    for P in pipes:
-        P.xchg.finish()
+    finish_all()
     torch.cuda.synchronize()
     if world > 1:
         torch.distributed.barrier()
@@ -376,30 +679,59 @@ def main():
     last = None
     for _ in range(args.steps):
         last = step()
-    allc = None
-    for P in pipes:                                     # every step's all-gather has completed
-        r = P.xchg.finish()
-        if P is last:
-            allc = r
+    allc = finish_all(last)
     torch.cuda.synchronize()
     if world > 1:
         torch.distributed.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    clock_ghz = None
+    try:
+        for _ in range(4):
+            spin_once()                                  # (the probe wave shares the GPU with the steps' kernels)
+        side = Context(device=local_rank)
+        side.set_option("own_stream", 2)
+        clock_ghz = side.shader_clock_ghz(200)
+        side.close()
+        torch.cuda.synchronize()
+    except Exception:                                    # noqa: BLE001
+        pass
+    dt_rank = dt
+    dts = [dt]
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev if torch.distributed.get_backend() == "nccl" else None)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        dt = float(t.item())
+        import torch.distributed as dist
+        on_gpu = dist.get_backend() == "nccl"
+        t = torch.tensor([dt], dtype=torch.float64, device=dev if on_gpu else None)
+        allt = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(allt, t)
+        dts = [float(x.item()) for x in allt]
+        dt = max(dts)                                    # the contract: MAX over ranks
 
-    # device time of the library's launches for the last step (hipEvents on the launch stream)
-    ev_total_ms, ev_stage_ms = fe.last_timing()
-    # a few more event-timed steps for an average kernel-side duration
+    # ---- one batch call at a time (the figure a caller without any stream choreography gets) ----
     ev = []
-    for _ in range(min(5, args.steps)):
-        fe(d_pyr, kp, desc, counts)
+    for _ in range(min(8, max(3, args.steps))):
+        with torch.cuda.stream(stream):
+            launches(pipes[0], kp, desc, counts)
         ev.append(fe.last_timing())
     ev_total_ms = float(np.mean([e[0] for e in ev]))
     ev_stage_ms = [float(np.mean([e[1][i] for e in ev])) for i in range(3)]
+    one_ms = None
+    try:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        REPS = 20
+        with torch.cuda.stream(stream):
+            for i in range(REPS + 3):
+                if i == 3:
+                    e0.record(stream)
+                if use_graphs:
+                    pipes[0].graphs[0].replay()
+                else:
+                    launches(pipes[0], *pipes[0].outs[0])
+            e1.record(stream)
+        torch.cuda.synchronize()
+        one_ms = e0.elapsed_time(e1) / REPS
+    except Exception:                                    # noqa: BLE001
+        pass
     # dominant kernel alone: REP back-to-back launches inside one hipEvent bracket (a single eager launch is
     # bracketed together with ~10 us of command-processor latency)
     strip_ms = None
@@ -414,6 +746,24 @@ def main():
             strip_ms = float(np.mean(rr))
         finally:
             ctx.set_option("repeat_strips", 1)
+    build_info = None
+    if builder is not None:
+        # what PISLAM_BUILD_MARGINS_CLEAN leaves out of the step: the margin pass of a build into a dirty buffer
+        try:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            tm = []
+            for clean in (True, False):
+                with torch.cuda.stream(stream):
+                    e0.record(stream)
+                    for _ in range(10):
+                        builder(d_frames, d_pyr, margins_clean=clean)
+                    e1.record(stream)
+                torch.cuda.synchronize()
+                tm.append(e0.elapsed_time(e1) / 10)
+            build_info = {"build_ms_margins_clean": tm[0], "build_ms_with_margin_pass": tm[1],
+                          "timed_step_uses": "margins_clean" if args.margins_clean else "margin pass every step"}
+        except Exception:                                # noqa: BLE001
+            pass
 
     match_info = None
     if m_out is not None:
@@ -440,42 +790,43 @@ def main():
     value = total_kp_step * args.steps / dt
 
     if rank == 0:
-        valid_px = sum(t[0] * t[1] for t in levels)
-        if builder is not None:            # config 5: + source frame read + pyramid write
-            valid_px += w0 * h0 + sum(t[0] * t[1] for t in levels)
-        # algorithmic bytes: every valid pixel once + 36 B per keypoint + 4 B count
-        b_alg_launch = B * (valid_px + 4) + 36 * local_kp
         fused = args.pipeline != 1
+        valid_px = sum(t[0] * t[1] for t in levels)
+        # algorithmic bytes of the DOMINANT KERNEL's launch: every valid pixel once + 36 B per
+        # keypoint + 4 B count — the strip kernel reads no frame and writes no pyramid, so the 720p-build
+        # workload's extra traffic (frame read + pyramid write) is priced with the whole step, never here
+        b_alg_launch = B * (valid_px + 4) + 36 * local_kp
+        b_alg_step = b_alg_launch + (B * (w0 * h0 + valid_px) if builder is not None else 0)
         # dominant kernel: k_fused_strips (one launch per step covers the whole batch); for the staged
         # pipeline there is no single dominant launch, so the whole step is priced instead
         launch_ms = (strip_ms if strip_ms else ev_stage_ms[0]) if fused else ev_total_ms
         achieved = b_alg_launch / (launch_ms * 1e-3) / 1e9
-        # HBM bytes per launch come from separate rocprofv3 --pmc passes (tools/pmc_hbm.sh), which cannot run
-        # inside this process: the number is read from the committed profile and reported ONLY when that
-        # profile was taken on exactly these kernel sources and this workload; `traffic_source` says where it
-        # is from (or why it is null).
-        from pislam_amd import build as pbuild
-        traffic, traffic_step, traffic_source = None, None, None
-        tpath = os.path.join(ROOT, "profiles", "r02_hbm_traffic.json")
-        if fused and B == 256 and args.workload == "vga" and not args.log_bucket_size and os.path.exists(tpath):
-            try:
-                tj = json.load(open(tpath))
-                if tj.get("source_hash") == pbuild.source_hash():
-                    traffic = tj["kernels"]["k_fused_strips"]["hbm_bytes_per_launch"]
-                    traffic_step = sum(k["hbm_bytes_per_launch"] for k in tj["kernels"].values() if "hbm_bytes_per_launch" in k)
-                    traffic_source = f"profiles/r02_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes on kernel sources {tj['source_hash']}; not measured in this run)"
-                else:
-                    traffic_source = (f"null: profiles/r02_hbm_traffic.json was measured on kernel sources {tj.get('source_hash')}, "
-                                      f"this run uses {pbuild.source_hash()}")
-            except Exception as e:                          # noqa: BLE001
-                traffic_source = f"null: {e!r}"
-        else:
-            traffic_source = "null: no PMC profile for this workload / configuration"
+        step_ms = dt / args.steps * 1e3
+        prof, prof_source = load_counters(args.workload, B, bool(args.log_bucket_size)) if fused else (None, "null: staged pipeline")
+        traffic = traffic_step = valu = None
+        if prof:
+            ks = prof["kernels"]
+            dom = ks.get("k_fused_strips", {})
+            traffic = dom.get("hbm_bytes_per_launch")
+            traffic_step = sum(k.get("hbm_bytes_per_launch", 0) * k.get("launches_per_step", 1) for k in ks.values()) or None
+            if dom.get("SQ_INSTS_VALU") and clock_ghz:
+                nsimd = 4 * 256
+                insts = dom["SQ_INSTS_VALU"]
+                valu = {"insts": insts, "salu_insts": dom.get("SQ_INSTS_SALU"),
+                        "issue_frac": insts * 4.0 / (nsimd * clock_ghz * 1e9 * launch_ms * 1e-3),
+                        "clock_ghz": clock_ghz,
+                        "note": "wave64 VALU instructions of one strip-kernel launch x 4 cycles / (1024 SIMDs x shader clock x "
+                                "launch_ms): the share of the integer issue slots in use — the binding resource of this kernel; "
+                                "clock measured in this run (s_memtime vs s_memrealtime under the steps' load)",
+                        "source": prof_source}
+        cfg_idx = {"vga": 2 if world > 1 else 1, "1280x960": 3, "720p-build": 4}[args.workload]
         out = {
-            "metric": "ORB keypoints+descriptors/sec, 640x480 8-level pyramid",
+            "metric": METRIC,
             "value": value, "unit": "kp+desc/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+            "warmup": args.warmup, "ms_per_step": step_ms, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "one_batch_ms": one_ms,
+            "one_batch_value": (local_kp / (one_ms * 1e-3)) if one_ms else None,
             "config": {
                 "workload": {"vga": f"batch={B} synthetic 640x480 pyramids per GPU, 8 levels x1.2 stacked (vstep=640, "
                                     "2210 rows)",
@@ -483,32 +834,50 @@ def main():
                                          "(vstep=1280, 3768 rows, levels 4|5 and 6|7 side by side)",
                              "720p-build": f"batch={B} synthetic 1280x720 frames per GPU; gaussian5x5 + "
                                            "13/16,7/8,13/16,13/16,7/8,13/16,13/16 bilinear pyramid built on the GPU inside "
-                                           f"the step (vstep={vstep}, {rows} rows)"}[args.workload] +
+                                           f"the step (vstep={vstep}, {rows} rows"
+                                           + (", the rebuild vouches for the zero margins of its own first fill: "
+                                              "PISLAM_BUILD_MARGINS_CLEAN — margin pass cost in config.pyramid_build"
+                                              if args.margins_clean else ", margins re-zeroed every step") + ")"}[args.workload] +
                             ", border=16, FAST threshold=20, Harris threshold=1<<15, " + ("no buckets" if not args.log_bucket_size else f"buckets <{args.log_bucket_size},{args.bucket_limit}>") + ", "
-                            "256-bit descriptors (BASELINE.json configs[1])",
+                            f"256-bit descriptors (BASELINE.json configs[{cfg_idx}]" + (f": {world} GPUs" if world > 1 else "") + ")",
+                "baseline_config_index": cfg_idx,
                 "batch_per_gpu": B, "global_batch": B * world, "distinct_pyramids_per_gpu": min(distinct, B),
                 "keypoints_per_pyramid": total_kp_step / (B * world),
                 "pyramids_per_s": B * world * args.steps / dt,
-                "parallelism": f"pyramid-shard x{world}, RCCL all-gather of counts" if world > 1 else "single GPU",
+                "parallelism": f"pyramid-shard x{world}, all-gather of counts" if world > 1 else "single GPU",
                 "pipeline": "fused" if fused else "staged",
-                "launch": "hipGraph replay" if graphs is not None else "eager",
+                "launch": "hipGraph replay" if use_graphs else "eager",
                 "streams": S,
-                "batches_in_flight": f"{S}: step k runs on pipeline k % {S} (own HIP stream, context/workspace, outputs, "
-                                     "graph); each step is one whole batch, all K steps start and finish inside the "
-                                     "timed region" if S > 1 else "1",
+                "batches_in_flight": (f"{S}: step k runs on pipeline k % {S} (own HIP stream, context/workspace, outputs, "
+                                      "graph); each step is one whole batch, all K steps start and finish inside the "
+                                      "timed region; one_batch_ms = one call at a time, no caller-side overlap" if S > 1 else "1"),
                 "strips_redone_by_overflow_pass": f"{deferred} of {nstrips}",
                 "max_keypoints": args.max_keypoints, "pyramids_over_capacity": capped,
                 "count_allgather": xchg.path,
+                "rccl_ranks": rccl_ranks,
+                "communicators_per_rank": 1 if (hub is not None or (world > 1 and not gloo_mode)) else 0,
+                "dist_fallbacks": fallbacks,
+                "library_options": dict(extra_opts),
+                "ms_per_step_ranks": {"min": min(dts) / args.steps * 1e3, "max": max(dts) / args.steps * 1e3,
+                                      "rank0": dt_rank / args.steps * 1e3},
+                **({"pyramid_build": build_info} if build_info else {}),
                 **({"match_inside_step": match_info} if match_info else {}),
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_source,
+                "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": prof_source,
                 "traffic_whole_step": traffic_step,
                 "kernel": "pf::k_fused_strips (hipEvents on the launch stream around 16 back-to-back launches, / 16, measured after "
                           "the timed region with the other pipelines idle)" if fused
                           else "whole staged step (all launches)",
                 "algorithmic_bytes_per_launch": b_alg_launch, "launch_ms": launch_ms,
+                "whole_step": {"algorithmic_bytes": b_alg_step, "ms": step_ms,
+                               "achieved": b_alg_step / (step_ms * 1e-3) / 1e9,
+                               "frac": b_alg_step / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                               "note": "per GPU, every kernel of a step over ms_per_step" +
+                                       (" (bytes incl. frame read + pyramid write of the build)" if builder is not None else "")},
+                "valu": valu,
+                "shader_clock_ghz": clock_ghz,
                 "step_gpu_ms": ev_total_ms,
                 "stage_ms": {"detect+score+nms": ev_stage_ms[0], "overflow pass" if fused else "extract": ev_stage_ms[1],
                              "gather+orb" if fused else "orb": ev_stage_ms[2]},
@@ -516,16 +885,47 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(host, levels, budget_s=args.cpu_seconds)
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if world > 1:
         torch.distributed.barrier()
-        for P in pipes:
-            try:
-                P.ctx.dist_finalize()                    # our RCCL communicators first, while every rank is still alive
-            except Exception:                            # noqa: BLE001
-                pass
+        try:
+            ctx.dist_finalize()                          # our RCCL communicator first, while every rank is still alive
+        except Exception:                                # noqa: BLE001
+            pass
         torch.distributed.destroy_process_group()
+    return 0
+
+
+def main():
+    ap = build_parser()
+    args = ap.parse_args()
+    if not args.max_keypoints:
+        args.max_keypoints = 4096 if args.workload == "vga" else 8192
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    argv = sys.argv[1:]
+    if args.worker:
+        with Watchdog(max(30.0, args.attempt_timeout + 30), "the worker", rc=5):
+            return worker_main(args)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # Plain `python bench.py --gpus N`: start the N ranks ourselves (one process per GPU under
+        # torch.distributed.run on 127.0.0.1); rank 0 prints the JSON line.
+        import torch
+        from pislam_amd import dist as pdist
+        shared_ok = args.dist_backend == "gloo" or args.selftest_spawn     # test modes: ranks may share a GPU / need none
+        if not shared_ok and torch.cuda.device_count() < args.gpus:
+            raise SystemExit(f"bench.py --gpus {args.gpus}: only {torch.cuda.device_count()} GPU(s) visible "
+                             "(one process per GPU; there is no CPU fallback)")
+        return pdist.self_launch([os.path.abspath(__file__)] + argv, args.gpus)
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus} "
+                         "(or run `python bench.py --gpus N` without a torchrun environment)")
+    if world > 1:
+        return supervisor_main(args, argv)
+    with Watchdog(args.wall_cap, "bench.py", rc=5):
+        return worker_main(args)
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main() or 0)

@@ -38,7 +38,10 @@ extern "C" {
 #define PISLAM_ERR_NOMEM (-3)   /* device allocation failed */
 #define PISLAM_ERR_DIST (-4)    /* RCCL unavailable or a collective failed */
 
-#define PISLAM_ABI_VERSION 1
+/* 2: pislam_pyramid_build_batch takes a PISLAM_BUILD_* bitmask (ABI 1: `blur`, any non-zero value) and refuses
+ *    unknown bits; pislam_dist_comm_count; option "own_stream" 1 creates a stream with DEFAULT flags (ordered
+ *    with the legacy null stream), 2 a non-blocking one; options "sub_batches" / "sub_mb". */
+#define PISLAM_ABI_VERSION 2
 
 typedef struct pislam_ctx pislam_ctx;
 
@@ -50,7 +53,13 @@ int pislam_ctx_destroy(pislam_ctx *ctx);
 /* hip_stream is a hipStream_t passed as void*; NULL = null stream. */
 int pislam_ctx_set_stream(pislam_ctx *ctx, void *hip_stream);
 /* Tuning / test hooks; results never depend on them.  Keys:
- *   "own_stream" 1: issue on a non-blocking stream created (and destroyed) by the context instead of the null stream
+ *   "own_stream" issue on a stream created (and destroyed) by the context instead of the null stream: 1 = default flags
+ *                (still ordered with work on the legacy null stream, like the null stream itself), 2 = hipStreamNonBlocking
+ *                (device-pointer inputs must then be complete, or ordered by the caller, before a call); 0 = back to the null stream
+ *   "sub_batches" fused batch path: 1 (default) one launch group; n <= 16: the batch is cut into n sub-batches whose overflow
+ *                pass + gather/ORB kernels run on a context-owned second stream under the next sub-batch's strip kernel
+ *                (fork / join by events inside the call; results and stream semantics unchanged, hipGraph-capturable;
+ *                measured slower than one launch group on MI355X — DESIGN.md); 0: by size ("sub_mb" MiB per sub-batch, 128)
  *   "pipeline"   0 auto, 1 staged (one launch group per reference call, HBM score map), 2 fused strips
  *   "dump_score" fused pipeline also materialises the score map (pislam_frontend_get_score_map)
  *   "strip_rows" fused strip height (0 = heuristic);  "run_len" strips per workgroup run (0 = by batch)
@@ -194,6 +203,8 @@ int pislam_pyramid_layout(int width, int height, int nlevels, const int32_t *ste
 #define PISLAM_BUILD_BLUR 1          /* level 0 = gaussian5x5 of the frame (else the frame itself)              */
 #define PISLAM_BUILD_MARGINS_CLEAN 2 /* the margins are already zero: this function filled `pyramids` before with */
                                      /* the same layout and nothing else wrote to it since — skip re-zeroing them */
+#define PISLAM_BUILD_CHECK_MARGINS 4 /* debug, with MARGINS_CLEAN: verify that promise (synchronises; non-zero    */
+                                     /* margin bytes -> PISLAM_ERR_INVALID).  Other bits are refused.             */
 int pislam_pyramid_build_batch(pislam_ctx *ctx, int nlevels, const int32_t *steps, const pislam_level *levels,
                                const uint8_t *frames, int frame_vstep, size_t frame_stride, int batch,
                                uint8_t *pyramids, int vstep, int rows, size_t pyramid_stride, int flags);
@@ -240,6 +251,11 @@ int pislam_frontend_last_timing(pislam_ctx *ctx, float *total_ms, float stage_ms
  * Results are identical either way; a large ratio means the input is denser
  * than the fast path is sized for.  Synchronises the context stream. */
 int pislam_frontend_last_stats(pislam_ctx *ctx, uint32_t stats[2]);
+
+/* Measurement aid: the shader clock in GHz while the device is doing whatever else it is doing — one wave on the
+ * context stream compares the shader cycle counter (s_memtime) with the constant 100 MHz counter
+ * (s_memrealtime) over ~`micros` microseconds.  Synchronises.  bench.py prices the VALU issue rate with it. */
+int pislam_debug_shader_clock(pislam_ctx *ctx, int micros, double *ghz);
 
 /* ---- descriptor matching ---------------------------- */
 
@@ -304,6 +320,9 @@ int pislam_dist_get_unique_id(uint8_t id[PISLAM_DIST_ID_BYTES]);
 int pislam_dist_init(pislam_ctx *ctx, const uint8_t id[PISLAM_DIST_ID_BYTES], int rank, int world);
 int pislam_dist_rank(const pislam_ctx *ctx);
 int pislam_dist_world(const pislam_ctx *ctx);
+/* Ranks in the context's communicator as RCCL itself reports them (ncclCommCount) — not the `world` the caller
+ * passed in: 0 without a communicator (single GPU / not initialised), negative on error. */
+int pislam_dist_comm_count(pislam_ctx *ctx);
 
 /* all_counts[r*n + i] = rank r's local_counts[i] (DEVICE pointers, n equal on
  * every rank — pad ragged shards to the largest).  Enqueued on the context's
@@ -315,10 +334,20 @@ int pislam_dist_allgather_counts(pislam_ctx *ctx, const uint32_t *local_counts, 
                                  uint32_t *all_counts);
 
 /* Makes the context stream wait (on the device, not the host) for the
- * collective issued `back` calls ago (1 = the most recent, up to 4): call it
- * before work that overwrites that collective's buffers.  With two alternating
- * output sets, pislam_dist_fence(ctx, 2) before each batch call is enough. */
+ * collective issued `back` calls ago (1 = the most recent): call it before
+ * work that overwrites that collective's buffers.  With two alternating output
+ * sets, pislam_dist_fence(ctx, 2) before each batch call is enough.  (The
+ * completion events of the last 16 collectives are kept; an older one is
+ * covered by waiting for the oldest kept — the collective stream is in order.) */
 int pislam_dist_fence(pislam_ctx *ctx, int back);
+
+/* The same two calls for a process that runs SEVERAL contexts / streams (batches in flight on separate
+ * pipelines) over ONE communicator: the all-gather is ordered after `producer_stream` (a hipStream_t as void*)
+ * instead of the context stream, the fence makes `consumer_stream` wait.  All collectives of the process then
+ * go through one communicator and one collective stream, in host issue order — identical on every rank. */
+int pislam_dist_allgather_counts_on(pislam_ctx *ctx, void *producer_stream, const uint32_t *local_counts, size_t n,
+                                    uint32_t *all_counts);
+int pislam_dist_fence_on(pislam_ctx *ctx, int back, void *consumer_stream);
 
 /* Blocks the host until every collective issued on this context has completed. */
 int pislam_dist_synchronize(pislam_ctx *ctx);

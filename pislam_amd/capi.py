@@ -14,7 +14,7 @@ import numpy as np
 from . import build as _build
 
 PISLAM_OK = 0
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 _vp, _i, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t
 
@@ -70,8 +70,12 @@ SYMBOLS = {
     "pislam_dist_init": (_i, [_vp, ctypes.c_char_p, _i, _i]),
     "pislam_dist_rank": (_i, [_vp]),
     "pislam_dist_world": (_i, [_vp]),
+    "pislam_dist_comm_count": (_i, [_vp]),
     "pislam_dist_allgather_counts": (_i, [_vp, _vp, _sz, _vp]),
     "pislam_dist_fence": (_i, [_vp, _i]),
+    "pislam_dist_allgather_counts_on": (_i, [_vp, _vp, _vp, _sz, _vp]),
+    "pislam_dist_fence_on": (_i, [_vp, _i, _vp]),
+    "pislam_debug_shader_clock": (_i, [_vp, _i, ctypes.POINTER(ctypes.c_double)]),
     "pislam_dist_synchronize": (_i, [_vp]),
     "pislam_dist_allreduce_max": (_i, [_vp, ctypes.POINTER(ctypes.c_double)]),
     "pislam_dist_finalize": (_i, [_vp]),
@@ -192,13 +196,29 @@ class Context:
     def dist_init(self, unique_id: bytes | None, rank: int, world: int):
         self.check(self.lib.pislam_dist_init(self.h, unique_id, rank, world), "pislam_dist_init")
 
-    def dist_allgather_counts(self, local_counts, all_counts):
-        """Device tensors: all_counts[r*n + i] = rank r's local_counts[i]; asynchronous (collective stream)."""
-        self.check(self.lib.pislam_dist_allgather_counts(self.h, ptr(local_counts), local_counts.numel(),
-                                                         ptr(all_counts)), "pislam_dist_allgather_counts")
+    def dist_allgather_counts(self, local_counts, all_counts, stream: int | None = None):
+        """Device tensors: all_counts[r*n + i] = rank r's local_counts[i]; asynchronous (collective stream),
+        ordered after the context stream — or after `stream` (a raw hipStream_t: another pipeline's)."""
+        if stream is None:
+            self.check(self.lib.pislam_dist_allgather_counts(self.h, ptr(local_counts), local_counts.numel(),
+                                                             ptr(all_counts)), "pislam_dist_allgather_counts")
+        else:
+            self.check(self.lib.pislam_dist_allgather_counts_on(self.h, _vp(stream), ptr(local_counts),
+                                                                local_counts.numel(), ptr(all_counts)),
+                       "pislam_dist_allgather_counts_on")
 
-    def dist_fence(self, back: int = 1):
-        self.check(self.lib.pislam_dist_fence(self.h, back), "pislam_dist_fence")
+    def dist_fence(self, back: int = 1, stream: int | None = None):
+        """The context stream — or `stream` (a raw hipStream_t) — waits on the device for the collective issued
+        `back` exchanges ago."""
+        if stream is None:
+            self.check(self.lib.pislam_dist_fence(self.h, back), "pislam_dist_fence")
+        else:
+            self.check(self.lib.pislam_dist_fence_on(self.h, back, _vp(stream)), "pislam_dist_fence_on")
+
+    def shader_clock_ghz(self, micros: int = 200) -> float:
+        v = ctypes.c_double(0)
+        self.check(self.lib.pislam_debug_shader_clock(self.h, micros, ctypes.byref(v)), "pislam_debug_shader_clock")
+        return float(v.value)
 
     def dist_synchronize(self):
         self.check(self.lib.pislam_dist_synchronize(self.h), "pislam_dist_synchronize")
@@ -207,6 +227,13 @@ class Context:
         v = ctypes.c_double(value)
         self.check(self.lib.pislam_dist_allreduce_max(self.h, ctypes.byref(v)), "pislam_dist_allreduce_max")
         return float(v.value)
+
+    def dist_comm_count(self) -> int:
+        """Ranks RCCL itself reports for this context's communicator (ncclCommCount); 0 without one."""
+        n = self.lib.pislam_dist_comm_count(self.h)
+        if n < 0:
+            self.check(n, "pislam_dist_comm_count")
+        return n
 
     def dist_finalize(self):
         self.check(self.lib.pislam_dist_finalize(self.h), "pislam_dist_finalize")

@@ -126,6 +126,17 @@ struct pislam_ctx {
   size_t last_stride = 0;
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
   bool timing_valid = false;
+  // Sub-batch pipelining of the fused batch path (run_fused): the strip kernels of the sub-batches run back to
+  // back on the context stream, the overflow pass + gather/ORB kernel of sub-batch i on `aux_stream` under the
+  // strip kernel of sub-batch i+1 (fork / join with events: one call, one context, capturable in a hipGraph).
+  static constexpr int MAX_SUB = 16;
+  int opt_sub_batches = 1;             // 1 = one launch group (default), n = n sub-batches, 0 = by bytes per sub-batch
+  int opt_sub_mb = 0;                  // auto rule: target MiB of pyramids per sub-batch (0 = default)
+  hipStream_t aux_stream = nullptr;    // created on first use (non-blocking)
+  hipEvent_t ev_sub[MAX_SUB] = {};     // strips of sub-batch i done (context stream -> aux stream)
+  hipEvent_t ev_join = nullptr;        // aux stream -> context stream at the end of the call
+  int ovf_nsub = 0;                    // layout of w_ovf the last call / reserve established: lists, dwords per list
+  size_t ovf_stride = 0;
 };
 
 namespace {
@@ -399,6 +410,13 @@ PISLAM_EXPORT int pislam_ctx_destroy(pislam_ctx *c) {
     b->release();
   for (auto &e : c->ev)
     if (e) (void)hipEventDestroy(e);
+  if (c->aux_stream) {
+    (void)hipStreamSynchronize(c->aux_stream);
+    (void)hipStreamDestroy(c->aux_stream);
+  }
+  for (auto &e : c->ev_sub)
+    if (e) (void)hipEventDestroy(e);
+  if (c->ev_join) (void)hipEventDestroy(c->ev_join);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   delete c;
   return PISLAM_OK;
@@ -411,10 +429,19 @@ PISLAM_EXPORT int pislam_ctx_set_stream(pislam_ctx *c, void *s) {
 }
 
 namespace {
-int use_own_stream(pislam_ctx *c, bool on) {
+// mode 1: a stream with default flags — it still synchronises with the legacy null stream, so device-pointer
+// inputs produced on the null stream stay ordered before the call, as they were when the context issued on
+// the null stream itself; mode 2: hipStreamNonBlocking (the caller orders its producers explicitly).
+int use_own_stream(pislam_ctx *c, int mode) {
   HIPCHK(c, hipSetDevice(c->device));
-  if (on) {
-    if (!c->own_stream) HIPCHK(c, hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
+  if (mode) {
+    if (c->own_stream) {
+      HIPCHK(c, hipStreamSynchronize(c->own_stream));
+      if (c->stream == c->own_stream) c->stream = nullptr;
+      HIPCHK(c, hipStreamDestroy(c->own_stream));
+      c->own_stream = nullptr;
+    }
+    HIPCHK(c, hipStreamCreateWithFlags(&c->own_stream, mode == 2 ? hipStreamNonBlocking : hipStreamDefault));
     c->stream = c->own_stream;
   } else if (c->own_stream) {
     HIPCHK(c, hipStreamSynchronize(c->own_stream));
@@ -432,7 +459,8 @@ PISLAM_EXPORT int pislam_ctx_set_option(pislam_ctx *c, const char *key, int valu
     if (value < 0 || value > 2) return fail(c, PISLAM_ERR_INVALID, "pipeline must be 0 (auto), 1 (staged) or 2 (fused)");
     c->opt_pipeline = value;
   } else if (!strcmp(key, "own_stream")) {
-    return use_own_stream(c, value != 0);
+    if (value < 0 || value > 2) return fail(c, PISLAM_ERR_INVALID, "own_stream must be 0, 1 (default flags) or 2 (non-blocking)");
+    return use_own_stream(c, value);
   } else if (!strcmp(key, "dump_score")) {
     c->opt_dump_score = value != 0;
   } else if (!strcmp(key, "xtile_cols")) {
@@ -469,6 +497,11 @@ PISLAM_EXPORT int pislam_ctx_set_option(pislam_ctx *c, const char *key, int valu
   } else if (!strcmp(key, "orb_chunks")) {
     if (value < 0 || value > 1024) return fail(c, PISLAM_ERR_INVALID, "orb_chunks must be 0..1024");
     c->opt_orb_chunks = value;
+  } else if (!strcmp(key, "sub_batches")) {
+    if (value < 0 || value > pislam_ctx::MAX_SUB) return fail(c, PISLAM_ERR_INVALID, "sub_batches must be 0 (auto) .. 16");
+    c->opt_sub_batches = value;
+  } else if (!strcmp(key, "sub_mb")) {
+    c->opt_sub_mb = std::max(0, value);
   } else if (!strcmp(key, "ablate")) {
     c->opt_ablate = value;
   } else if (!strcmp(key, "strip_rows")) {
@@ -818,6 +851,9 @@ PISLAM_EXPORT int pislam_pyramid_build_batch(pislam_ctx *c, int nlevels, const i
                                              int rows, size_t pyramid_stride, int flags) {
   const bool blur = (flags & PISLAM_BUILD_BLUR) != 0;
   if (!c) return PISLAM_ERR_INVALID;
+  // (ABI 1 took `blur` = any non-zero value here: unknown bits are refused, not silently read as flags)
+  if (flags & ~(PISLAM_BUILD_BLUR | PISLAM_BUILD_MARGINS_CLEAN | PISLAM_BUILD_CHECK_MARGINS))
+    return fail(c, PISLAM_ERR_INVALID, "unknown PISLAM_BUILD_* flag bits");
   if (!levels || !frames || !pyramids || batch <= 0 || nlevels < 1 || nlevels > 16 || (nlevels > 1 && !steps))
     return fail(c, PISLAM_ERR_INVALID, "bad argument");
   if (!is_device_ptr(frames) || !is_device_ptr(pyramids))
@@ -845,7 +881,8 @@ PISLAM_EXPORT int pislam_pyramid_build_batch(pislam_ctx *c, int nlevels, const i
   // (PISLAM_BUILD_MARGINS_CLEAN: a buffer this function filled before with the same layout and nobody wrote
   // to since; the margin pass costs ~20 us per 64 720p frames).  Bytes beyond the margins are nobody's input
   // and are left untouched (zero-initialise the buffer once if they must be defined).
-  if (!(flags & PISLAM_BUILD_MARGINS_CLEAN)) {
+  const bool clean = (flags & PISLAM_BUILD_MARGINS_CLEAN) != 0, check = (flags & PISLAM_BUILD_CHECK_MARGINS) != 0;
+  if (!clean || check) {
     pp::ZeroPlan Z;
     memset(&Z, 0, sizeof(Z));
     Z.nlevels = nlevels;
@@ -862,8 +899,22 @@ PISLAM_EXPORT int pislam_pyramid_build_batch(pislam_ctx *c, int nlevels, const i
         Z.wh[l] = (levels[l - 1].height + N - 1) / N * M;
       }
     }
-    hipLaunchKernelGGL(pp::k_zero_margins, dim3(2 * nlevels, batch), dim3(256), 0, c->stream, Z, pyramids, pyramid_stride);
-    PCHK(launch_ok(c, "k_zero_margins"));
+    if (clean) {
+      // debug: verify the caller's promise instead of trusting it (synchronises; a dirty margin is an error)
+      if (c->w_total.ensure(sizeof(uint32_t)) != PISLAM_OK) return fail(c, PISLAM_ERR_NOMEM, "hipMalloc");
+      HIPCHK(c, hipMemsetAsync(c->w_total.p, 0, sizeof(uint32_t), c->stream));
+      hipLaunchKernelGGL(pp::k_zero_margins<true>, dim3(2 * nlevels, batch), dim3(256), 0, c->stream, Z, pyramids,
+                         pyramid_stride, c->w_total.as<unsigned int>());
+      PCHK(launch_ok(c, "k_zero_margins<check>"));
+      uint32_t nz = 0;
+      HIPCHK(c, hipMemcpyAsync(&nz, c->w_total.p, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+      PCHK(sync(c));
+      if (nz) return fail(c, PISLAM_ERR_INVALID, "PISLAM_BUILD_MARGINS_CLEAN was passed but the margins hold non-zero bytes");
+    } else {
+      hipLaunchKernelGGL(pp::k_zero_margins<false>, dim3(2 * nlevels, batch), dim3(256), 0, c->stream, Z, pyramids,
+                         pyramid_stride, (unsigned int *)nullptr);
+      PCHK(launch_ok(c, "k_zero_margins"));
+    }
   }
   const int w0 = levels[0].width, h0 = levels[0].height;
   if (blur) {
@@ -1186,72 +1237,179 @@ bool build_fused_plan(const pislam_ctx *c, const pislam_frontend_params *p, cons
   return true;
 }
 
-int run_fused(pislam_ctx *c, const pislam_frontend_params *p, const pf::FusedParams &F, size_t lds, size_t lds_alias,
-              const uint8_t *pyramids, size_t stride, int batch, uint32_t *kp, uint32_t *desc, uint32_t *counts) {
+// Sub-batches of a fused batch call (option "sub_batches", default 1 = one launch group): the strip kernels of the
+// sub-batches run back to back on the context stream, overflow pass + gather/ORB of sub-batch i on the context's
+// second stream under the strip kernel of sub-batch i+1 (fork / join by events inside the call).  MEASURED AND
+// NOT THE DEFAULT (MI355X, VGA batch 256, one call at a time): 0.286 ms with one launch group, 0.326 / 0.360 / 0.367
+// / 0.466 ms with 2 / 3 / 4 / 6 sub-batches — a strip launch of 128 pyramids takes 0.121 ms, not half of 0.206: every
+// launch ends in its own tail of partly filled CUs and the serialised launches add ~18 us each, more than the
+// overlap wins back (1280x960: 1.23 -> 1.36 ms with 4).  What does pay is whole batches in flight on separate
+// contexts (bench.py --streams, tools/pislam_demo --streams: 0.252 ms).  `0` = the MiB-per-sub-batch rule below.
+int choose_sub_batches(const pislam_ctx *c, const pislam_frontend_params *p, int batch) {
+  if (c->opt_dump_score || c->opt_ablate || c->opt_pipeline == 1) return 1;
+  int n = c->opt_sub_batches;
+  if (n == 0) {
+    const double mb = (double)p->rows * p->vstep * batch / (1024.0 * 1024.0);
+    const double target = c->opt_sub_mb > 0 ? c->opt_sub_mb : 128.0;
+    n = (int)(mb / target + 0.5);
+    n = std::min(n, batch / 16);
+  }
+  return std::max(1, std::min(std::min(n, batch), (int)pislam_ctx::MAX_SUB));
+}
+inline int sub_max(int batch, int nsub) { return batch / nsub + (batch % nsub ? 1 : 0); }
+
+// Overflow lists: one per sub-batch ([0] count, [1] count of the previous step, [2..] entries), `stride` dwords
+// apart.  A new layout (or a new allocation) starts from an all-zero buffer: a stale entry must never be read
+// as a list header.
+int prepare_ovf(pislam_ctx *c, int nsub, size_t stride) {
+  bool grew = false;
+  if (c->w_ovf.ensure(sizeof(uint32_t) * stride * nsub, &grew) != PISLAM_OK)
+    return fail(c, PISLAM_ERR_NOMEM, "hipMalloc(overflow list)");
+  if (grew || c->ovf_nsub != nsub || c->ovf_stride != stride) {
+    HIPCHK(c, hipMemsetAsync(c->w_ovf.p, 0, c->w_ovf.cap, c->stream));
+    c->ovf_nsub = nsub;
+    c->ovf_stride = stride;
+  }
+  return PISLAM_OK;
+}
+
+int ensure_aux(pislam_ctx *c, int nsub) {
+  if (!c->aux_stream) HIPCHK(c, hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking));
+  if (!c->ev_join) HIPCHK(c, hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+  for (int i = 0; i < nsub; i++)
+    if (!c->ev_sub[i]) HIPCHK(c, hipEventCreateWithFlags(&c->ev_sub[i], hipEventDisableTiming));
+  return PISLAM_OK;
+}
+
+// `Fplan`: the strip plan, built for the largest sub-batch (sub_max pyramids).
+int run_fused(pislam_ctx *c, const pislam_frontend_params *p, const pf::FusedParams &Fplan, size_t lds, size_t lds_alias,
+              const uint8_t *pyramids, size_t stride, int batch, int nsub, uint32_t *kp, uint32_t *desc, uint32_t *counts) {
+  const int S = Fplan.strips_per_pyr;
+  const int submax = sub_max(batch, nsub);
   // descriptor staging: QS_SHARED slots of `words` dwords per strip (ALIAS strips hold at most QS_SHARED survivors)
   // (only strips that describe their own keypoints write there: option "orb_in_strip")
-  const size_t sdesc_bytes = F.orb_in_strip ? sizeof(uint32_t) * (size_t)F.strips_per_pyr * batch * pf::QS_SHARED * (size_t)p->words : 0;
-  if (c->w_stage.ensure(sizeof(uint32_t) * (size_t)F.slots_per_pyr * batch) != PISLAM_OK ||
-      c->w_stripcnt.ensure(sizeof(uint32_t) * (size_t)F.strips_per_pyr * batch) != PISLAM_OK ||
-      c->w_stagedesc.ensure(sdesc_bytes) != PISLAM_OK)
+  const size_t sdesc_per_pyr = Fplan.orb_in_strip ? (size_t)S * pf::QS_SHARED * (size_t)p->words : 0;
+  if (c->w_stage.ensure(sizeof(uint32_t) * (size_t)Fplan.slots_per_pyr * batch) != PISLAM_OK ||
+      c->w_stripcnt.ensure(sizeof(uint32_t) * (size_t)S * batch) != PISLAM_OK ||
+      c->w_stagedesc.ensure(sizeof(uint32_t) * sdesc_per_pyr * batch) != PISLAM_OK)
     return fail(c, PISLAM_ERR_NOMEM, "hipMalloc(fused staging)");
   // 16-byte loads need 16-byte aligned rows
   bool vec = ((uintptr_t)pyramids % 16 == 0) && (stride % 16 == 0) && (p->vstep % 16 == 0);
-  for (int l = 0; l < F.nlevels; l++) vec = vec && (F.lv[l].col0 % 16 == 0);
-  const int groups = cdiv(batch, 8);
-  uint8_t *dump = F.dump_score ? c->w_score.as<uint8_t>() : nullptr;
+  for (int l = 0; l < Fplan.nlevels; l++) vec = vec && (Fplan.lv[l].col0 % 16 == 0);
+  uint8_t *dump = Fplan.dump_score ? c->w_score.as<uint8_t>() : nullptr;
   const size_t dump_stride = (size_t)p->rows * p->vstep;
   // ALIAS layout (score tile laid over the dead image rows, 26 KB instead of 39 KB of LDS per workgroup
   // at VGA): the default.  Its overflow list (strips with overflowing queues) is drained by
   // k_fused_overflow right after; the gather kernel empties the list for the next step.
-  const bool alias = c->opt_alias && batch <= 65535 && F.strips_per_pyr <= 65535;
-  uint32_t *ovf = nullptr;
+  const bool alias = c->opt_alias && submax <= 65535 && S <= 65535;
+  const size_t ovf_stride = 2 + (size_t)S * submax;
   if (alias) {
-    bool grew = false;
-    if (c->w_ovf.ensure(sizeof(uint32_t) * ((size_t)F.strips_per_pyr * batch + 2), &grew) != PISLAM_OK)
-      return fail(c, PISLAM_ERR_NOMEM, "hipMalloc(overflow list)");
-    ovf = c->w_ovf.as<uint32_t>();
-    if (grew) HIPCHK(c, hipMemsetAsync(ovf, 0, 2 * sizeof(uint32_t), c->stream));
-    c->last_strips = (uint32_t)F.strips_per_pyr * (uint32_t)batch;
+    PCHK(prepare_ovf(c, nsub, ovf_stride));
+    c->last_strips = (uint32_t)S * (uint32_t)batch;
   }
-  {
-    // HOOKS instantiations: score-map dump (debug / parity hook) and the profiling ablations
-    const bool hooks = F.dump_score || F.ablate;
-    using KernT = void (*)(const pf::FusedParams, const uint8_t *, size_t, uint32_t *, uint32_t *, uint8_t *, size_t,
-                           unsigned long long *, uint32_t *, uint32_t *);
-    static const KernT kerns[8] = {
-        pf::k_fused_strips<false, false, false>, pf::k_fused_strips<false, false, true>,
-        pf::k_fused_strips<false, true, false>,  pf::k_fused_strips<false, true, true>,
-        pf::k_fused_strips<true, false, false>,  pf::k_fused_strips<true, false, true>,
-        pf::k_fused_strips<true, true, false>,   pf::k_fused_strips<true, true, true>};
-    // strips describing their own keypoints (option "orb_in_strip"): separate instantiations of the aligned ALIAS kernels
-    static const KernT kerns_orb[2] = {pf::k_fused_strips<true, false, true, true>, pf::k_fused_strips<true, true, true, true>};
-    const KernT kern = (F.orb_in_strip && vec && alias) ? kerns_orb[hooks ? 1 : 0]
-                                                        : kerns[(vec ? 4 : 0) | (hooks ? 2 : 0) | (alias ? 1 : 0)];
-    const size_t klds = alias ? lds_alias : lds;
-    if (klds > 150 * 1024) return fail(c, PISLAM_ERR_INVALID, "level too wide for the strip kernel's LDS tiles");
-    if (klds > 64 * 1024)
-      HIPCHK(c, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)klds));
-    const dim3 grid((unsigned)(groups * F.runs_per_pyr * 8));
+  if (nsub > 1) PCHK(ensure_aux(c, nsub));
+  // HOOKS instantiations: score-map dump (debug / parity hook) and the profiling ablations
+  const bool hooks = Fplan.dump_score || Fplan.ablate;
+  using KernT = void (*)(const pf::FusedParams, const uint8_t *, size_t, uint32_t *, uint32_t *, uint8_t *, size_t,
+                         unsigned long long *, uint32_t *, uint32_t *);
+  static const KernT kerns[8] = {
+      pf::k_fused_strips<false, false, false>, pf::k_fused_strips<false, false, true>,
+      pf::k_fused_strips<false, true, false>,  pf::k_fused_strips<false, true, true>,
+      pf::k_fused_strips<true, false, false>,  pf::k_fused_strips<true, false, true>,
+      pf::k_fused_strips<true, true, false>,   pf::k_fused_strips<true, true, true>};
+  // strips describing their own keypoints (option "orb_in_strip"): separate instantiations of the aligned ALIAS kernels
+  static const KernT kerns_orb[2] = {pf::k_fused_strips<true, false, true, true>, pf::k_fused_strips<true, true, true, true>};
+  const KernT kern = (Fplan.orb_in_strip && vec && alias) ? kerns_orb[hooks ? 1 : 0]
+                                                          : kerns[(vec ? 4 : 0) | (hooks ? 2 : 0) | (alias ? 1 : 0)];
+  const size_t klds = alias ? lds_alias : lds;
+  if (klds > 150 * 1024) return fail(c, PISLAM_ERR_INVALID, "level too wide for the strip kernel's LDS tiles");
+  if (klds > 64 * 1024)
+    HIPCHK(c, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)klds));
+  using OvfT = void (*)(const pf::FusedParams, const uint8_t *, size_t, uint32_t *, uint32_t *, uint8_t *, size_t,
+                        const uint32_t *);
+  static const OvfT okerns[4] = {pf::k_fused_overflow<false, false>, pf::k_fused_overflow<false, true>,
+                                 pf::k_fused_overflow<true, false>, pf::k_fused_overflow<true, true>};
+  const OvfT okern = okerns[(vec ? 2 : 0) | (hooks ? 1 : 0)];
+  if (alias && lds > 64 * 1024)
+    HIPCHK(c, hipFuncSetAttribute((const void *)okern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  // k_gather_orb's 48-byte row windows assume a row-independent byte shift (vstep % 16 == 0) and
+  // 32-bit byte offsets inside a pyramid; other layouts take the generic gather + per-keypoint ORB kernels.
+  const bool generic_orb = p->vstep % 16 != 0 || (size_t)p->rows * p->vstep > 0x7fffffffu;
+  // gather + orbCompute in one launch: (chunks, pyramids) workgroups
+  // Workgroups per pyramid: one per ~70 k classified pixels (keypoint counts are not known to the host; ~70-100
+  // keypoints per workgroup measured best: VGA, 981 keypoints: 14 = 21 chunks > 7, 28; 1280x960, 4389 keypoints: 42-49
+  // chunks 0.36 ms against 0.41 ms with 14), at least 16 for small batches, and such that the grid is a whole number
+  // of "waves" of resident workgroups (7 per CU: 64 VGPRs, 13.5 KB LDS) — batch 256: 14 chunks = 2 x 1792 workgroups
+  // measured 0.079 ms against 0.085 ms with 16 (2.3 waves: the last one 30 % full).
+  int nch = 0;
+  size_t per_max = 0, olds = 0;
+  if (!generic_orb) {
+    long px = 0;
+    for (int l = 0; l < Fplan.nlevels; l++) px += (long)(Fplan.lv[l].ex1 - Fplan.lv[l].ex0) * Fplan.lv[l].nstrips * Fplan.lv[l].R;
+    const int by_px = (int)(px / 70000);
+    nch = std::min(64, submax >= 128 ? std::max(8, by_px) : std::max(by_px, std::max(16, 4096 / submax)));
+    if (nsub == 1) {
+      const long slots = 7L * std::max(1, c->num_cus);
+      long best = nch, bestd = 1L << 40;
+      for (long m = 1; m <= 64; m++) {
+        const long cand = m * slots / submax;
+        if (cand < 4 || cand > 64) continue;
+        const long d = std::labs(cand - nch);
+        if (d < bestd) {
+          bestd = d;
+          best = cand;
+        }
+      }
+      nch = (int)best;
+    } else {
+      // pipelined sub-batches: the kernel shares the GPU with the next sub-batch's strip kernel, whole "waves" of
+      // resident workgroups mean nothing there — one workgroup per ~70 k pixels
+      nch = std::min(64, std::max(8, by_px));
+    }
+    if (c->opt_orb_chunks > 0) nch = c->opt_orb_chunks;
+    per_max = ((size_t)p->max_keypoints + nch - 1) / nch;
+    olds = (size_t)pf::OWAVES * 2 * pf::ORB_PATCH_BYTES + sizeof(uint32_t) * (((size_t)S + 1 + 3) & ~(size_t)3) +
+           sizeof(uint32_t) * 2 * per_max;        // keypoints to describe here and their final positions
+    if (olds > 150 * 1024) return fail(c, PISLAM_ERR_INVALID, "max_keypoints too large for the fused ORB kernel");
+    if (olds > 64 * 1024)
+      HIPCHK(c, hipFuncSetAttribute((const void *)pf::k_gather_orb, hipFuncAttributeMaxDynamicSharedMemorySize, (int)olds));
+  }
+
+  const int base = batch / nsub, rem = batch % nsub;
+  hipStream_t M = c->stream, X = nsub > 1 ? c->aux_stream : c->stream;
+  for (int sub = 0; sub < nsub; sub++) {
+    const int first = sub * base + std::min(sub, rem), n = base + (sub < rem ? 1 : 0);
+    pf::FusedParams F = Fplan;
+    F.batch = n;
+    const uint8_t *s_pyr = pyramids + (size_t)first * stride;
+    uint32_t *s_stage = c->w_stage.as<uint32_t>() + (size_t)first * F.slots_per_pyr;
+    uint32_t *s_cnt = c->w_stripcnt.as<uint32_t>() + (size_t)first * S;
+    uint32_t *s_sdesc = c->w_stagedesc.as<uint32_t>() + (size_t)first * sdesc_per_pyr;
+    uint8_t *s_dump = dump ? dump + (size_t)first * dump_stride : nullptr;
+    uint32_t *s_kp = kp + (size_t)first * p->max_keypoints;
+    uint32_t *s_desc = desc + (size_t)first * p->max_keypoints * p->words;
+    uint32_t *s_counts = counts + first;
+    uint32_t *ovf = alias ? c->w_ovf.as<uint32_t>() + (size_t)sub * ovf_stride : nullptr;
+    const dim3 grid((unsigned)(cdiv(n, 8) * F.runs_per_pyr * 8));
     unsigned long long *prof = nullptr;
     const size_t prof_n = (size_t)grid.x * 8;
     if (F.ablate & 8192) {                         // profiling hook: per-phase workgroup cycles -> stderr
       if (c->w_prof.ensure(prof_n * sizeof(unsigned long long)) != PISLAM_OK) return fail(c, PISLAM_ERR_NOMEM, "hipMalloc(prof)");
       prof = c->w_prof.as<unsigned long long>();
-      HIPCHK(c, hipMemsetAsync(prof, 0, prof_n * sizeof(unsigned long long), c->stream));
+      HIPCHK(c, hipMemsetAsync(prof, 0, prof_n * sizeof(unsigned long long), M));
     }
     // (profiling option "repeat_strips": the strip kernel launched n times back to back inside the stage-0
     //  event bracket, so that the per-launch duration is not inflated by the command-processor latency
     //  around a single eager launch; every launch rewrites the same outputs)
     for (int rep = 0; rep < std::max(1, c->opt_repeat_strips); rep++) {
-      if (rep && ovf) HIPCHK(c, hipMemsetAsync(ovf, 0, sizeof(uint32_t), c->stream));   // the last launch's list counts
-      hipLaunchKernelGGL(kern, grid, dim3(pf::NT), klds, c->stream, F, pyramids, stride, c->w_stage.as<uint32_t>(),
-                         c->w_stripcnt.as<uint32_t>(), dump, dump_stride, prof, ovf, c->w_stagedesc.as<uint32_t>());
+      if (rep && ovf) HIPCHK(c, hipMemsetAsync(ovf, 0, sizeof(uint32_t), M));   // the last launch's list counts
+      hipLaunchKernelGGL(kern, grid, dim3(pf::NT), klds, M, F, s_pyr, stride, s_stage, s_cnt, s_dump, dump_stride, prof, ovf,
+                         s_sdesc);
     }
     if (prof) {
       std::vector<unsigned long long> hv(prof_n);
-      HIPCHK(c, hipMemcpyAsync(hv.data(), prof, prof_n * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
-      HIPCHK(c, hipStreamSynchronize(c->stream));
+      HIPCHK(c, hipMemcpyAsync(hv.data(), prof, prof_n * sizeof(unsigned long long), hipMemcpyDeviceToHost, M));
+      HIPCHK(c, hipStreamSynchronize(M));
       double h[8] = {0};
       unsigned long long why[3] = {0, 0, 0};
       for (size_t i = 0; i < prof_n; i++) {
@@ -1265,77 +1423,48 @@ int run_fused(pislam_ctx *c, const pislam_frontend_params *p, const pf::FusedPar
       }
       fprintf(stderr, "[pislam prof] deferred strips by reason: corner queue %llu, score queue %llu, survivor buffer %llu\n",
               why[0], why[1], why[2]);
-      const double n = (double)F.strips_per_pyr * batch;
+      const double ns = (double)S * n;
       fprintf(stderr, "[pislam prof] cycles/strip: stage %.0f classify %.0f harris %.0f nms %.0f emit %.0f "
                       "(strips %.0f, carried %.0f, workgroups %u, lifetime %.0f/strip)\n",
-              h[0] / n, h[1] / n, h[2] / n, h[3] / n, h[4] / n, n, h[6], grid.x, h[7] / n);
+              h[0] / ns, h[1] / ns, h[2] / ns, h[3] / ns, h[4] / ns, ns, h[6], grid.x, h[7] / ns);
     }
     PCHK(launch_ok(c, "k_fused_strips"));
-    HIPCHK(c, hipEventRecord(c->ev[1], c->stream));     // stage 0 = the strip kernel alone
+    if (nsub > 1) {
+      // fork: the rest of this sub-batch runs on the aux stream, under the next sub-batch's strip kernel
+      HIPCHK(c, hipEventRecord(c->ev_sub[sub], M));
+      HIPCHK(c, hipStreamWaitEvent(X, c->ev_sub[sub], 0));
+      if (sub == nsub - 1) {
+        HIPCHK(c, hipEventRecord(c->ev[1], M));   // stage 0 = every sub-batch's strip kernel
+        HIPCHK(c, hipEventRecord(c->ev[2], M));   // (stage 1, the overflow passes, runs on the aux stream)
+      }
+    } else {
+      HIPCHK(c, hipEventRecord(c->ev[1], M));     // stage 0 = the strip kernel alone
+    }
     if (alias) {
-      using OvfT = void (*)(const pf::FusedParams, const uint8_t *, size_t, uint32_t *, uint32_t *, uint8_t *, size_t,
-                            const uint32_t *);
-      static const OvfT okerns[4] = {pf::k_fused_overflow<false, false>, pf::k_fused_overflow<false, true>,
-                                     pf::k_fused_overflow<true, false>, pf::k_fused_overflow<true, true>};
-      const OvfT okern = okerns[(vec ? 2 : 0) | (hooks ? 1 : 0)];
-      if (lds > 64 * 1024)
-        HIPCHK(c, hipFuncSetAttribute((const void *)okern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      hipLaunchKernelGGL(okern, dim3((unsigned)std::max(8, c->num_cus / 2)), dim3(pf::NT), lds, c->stream, F, pyramids,
-                         stride, c->w_stage.as<uint32_t>(), c->w_stripcnt.as<uint32_t>(), dump, dump_stride,
-                         (const uint32_t *)ovf);
+      hipLaunchKernelGGL(okern, dim3((unsigned)std::max(8, c->num_cus / 2)), dim3(pf::NT), lds, X, F, s_pyr, stride, s_stage,
+                         s_cnt, s_dump, dump_stride, (const uint32_t *)ovf);
       PCHK(launch_ok(c, "k_fused_overflow"));
     }
-  }
-  HIPCHK(c, hipEventRecord(c->ev[2], c->stream));       // stage 1 = the overflow pass (normally empty)
-  if (p->vstep % 16 != 0 || (size_t)p->rows * p->vstep > 0x7fffffffu) {
-    // k_gather_orb's 48-byte row windows assume a row-independent byte shift (vstep % 16 == 0) and
-    // 32-bit byte offsets inside a pyramid; other layouts take the generic gather + per-keypoint ORB kernels.
-    hipLaunchKernelGGL(pf::k_gather, dim3(batch), dim3(256), sizeof(uint32_t) * (F.strips_per_pyr + 1), c->stream,
-                       F, c->w_stage.as<uint32_t>(), c->w_stripcnt.as<uint32_t>(), kp, (size_t)p->max_keypoints,
-                       (uint32_t)p->max_keypoints, counts, ovf);
-    PCHK(launch_ok(c, "k_gather"));
-    hipLaunchKernelGGL(pk::k_orb<0>, dim3(cdiv(p->max_keypoints, 4), 1, batch), dim3(256), 0, c->stream,
-                       pyramids, p->vstep, stride, kp, (size_t)p->max_keypoints, counts, 0u,
-                       (uint32_t)p->max_keypoints, p->words, desc, (size_t)p->max_keypoints * p->words,
-                       (int32_t *)nullptr, (const uint8_t *)nullptr);
-    return launch_ok(c, "k_orb<batch>");
-  }
-  // gather + orbCompute in one launch: (chunks, batch) workgroups
-  // Workgroups per pyramid: one per ~70 k classified pixels (keypoint counts are not known to the host; ~70-100
-  // keypoints per workgroup measured best: VGA, 981 keypoints: 14 = 21 chunks > 7, 28; 1280x960, 4389 keypoints: 42-49
-  // chunks 0.36 ms against 0.41 ms with 14), at least 16 for small batches, and such that the grid is a whole number
-  // of "waves" of resident workgroups (7 per CU: 64 VGPRs, 13.5 KB LDS) — batch 256: 14 chunks = 2 x 1792 workgroups
-  // measured 0.079 ms against 0.085 ms with 16 (2.3 waves: the last one 30 % full).
-  long px = 0;
-  for (int l = 0; l < F.nlevels; l++) px += (long)(F.lv[l].ex1 - F.lv[l].ex0) * F.lv[l].nstrips * F.lv[l].R;
-  const int by_px = (int)(px / 70000);
-  int nch = std::min(64, batch >= 128 ? std::max(8, by_px) : std::max(by_px, std::max(16, 4096 / batch)));
-  {
-    const long slots = 7L * std::max(1, c->num_cus);
-    long best = nch, bestd = 1L << 40;
-    for (long m = 1; m <= 64; m++) {
-      const long cand = m * slots / batch;
-      if (cand < 4 || cand > 64) continue;
-      const long d = std::labs(cand - nch);
-      if (d < bestd) {
-        bestd = d;
-        best = cand;
-      }
+    if (nsub == 1) HIPCHK(c, hipEventRecord(c->ev[2], M));   // stage 1 = the overflow pass (normally empty)
+    if (generic_orb) {
+      hipLaunchKernelGGL(pf::k_gather, dim3(n), dim3(256), sizeof(uint32_t) * (S + 1), X, F, s_stage, s_cnt, s_kp,
+                         (size_t)p->max_keypoints, (uint32_t)p->max_keypoints, s_counts, ovf);
+      PCHK(launch_ok(c, "k_gather"));
+      hipLaunchKernelGGL(pk::k_orb<0>, dim3(cdiv(p->max_keypoints, 4), 1, n), dim3(256), 0, X, s_pyr, p->vstep, stride,
+                         s_kp, (size_t)p->max_keypoints, s_counts, 0u, (uint32_t)p->max_keypoints, p->words, s_desc,
+                         (size_t)p->max_keypoints * p->words, (int32_t *)nullptr, (const uint8_t *)nullptr);
+      PCHK(launch_ok(c, "k_orb<batch>"));
+    } else {
+      hipLaunchKernelGGL(pf::k_gather_orb, dim3(nch, n), dim3(256), olds, X, F, s_pyr, stride, s_stage, s_cnt,
+                         (const uint32_t *)s_sdesc, s_kp, (size_t)p->max_keypoints, (uint32_t)p->max_keypoints, s_counts,
+                         s_desc, (size_t)p->max_keypoints * p->words, p->words, (uint32_t)per_max, ovf);
+      PCHK(launch_ok(c, "k_gather_orb"));
     }
-    nch = (int)best;
   }
-  if (c->opt_orb_chunks > 0) nch = c->opt_orb_chunks;
-  const size_t per_max = ((size_t)p->max_keypoints + nch - 1) / nch;
-  size_t olds = (size_t)pf::OWAVES * 2 * pf::ORB_PATCH_BYTES + sizeof(uint32_t) * (((size_t)F.strips_per_pyr + 1 + 3) & ~(size_t)3) +
-                sizeof(uint32_t) * 2 * per_max;        // keypoints to describe here and their final positions
-  if (olds > 150 * 1024) return fail(c, PISLAM_ERR_INVALID, "max_keypoints too large for the fused ORB kernel");
-  if (olds > 64 * 1024)
-    HIPCHK(c, hipFuncSetAttribute((const void *)pf::k_gather_orb, hipFuncAttributeMaxDynamicSharedMemorySize, (int)olds));
-  hipLaunchKernelGGL(pf::k_gather_orb, dim3(nch, batch), dim3(256), olds, c->stream, F, pyramids, stride,
-                     c->w_stage.as<uint32_t>(), c->w_stripcnt.as<uint32_t>(), (const uint32_t *)c->w_stagedesc.as<uint32_t>(),
-                     kp, (size_t)p->max_keypoints, (uint32_t)p->max_keypoints, counts, desc,
-                     (size_t)p->max_keypoints * p->words, p->words, (uint32_t)per_max, ovf);
-  PCHK(launch_ok(c, "k_gather_orb"));
+  if (nsub > 1) {                                   // join: the call is complete, in stream order, on the context stream
+    HIPCHK(c, hipEventRecord(c->ev_join, X));
+    HIPCHK(c, hipStreamWaitEvent(M, c->ev_join, 0));
+  }
   return PISLAM_OK;
 }
 
@@ -1381,15 +1510,16 @@ PISLAM_EXPORT int pislam_frontend_reserve(pislam_ctx *c, const pislam_frontend_p
   if (c->opt_pipeline != 1) {
     pf::FusedParams F;
     size_t lds = 0, lds_alias = 0;
-    if (build_fused_plan(c, p, lv, batch, &F, &lds, &lds_alias) && F.strips_per_pyr > 0) {
-      bool grew_ovf = false;
+    const int nsub = choose_sub_batches(c, p, batch), submax = sub_max(batch, nsub);
+    if (build_fused_plan(c, p, lv, submax, &F, &lds, &lds_alias) && F.strips_per_pyr > 0) {
       if (c->w_stage.ensure(sizeof(uint32_t) * (size_t)F.slots_per_pyr * batch) != PISLAM_OK ||
           c->w_stripcnt.ensure(sizeof(uint32_t) * (size_t)F.strips_per_pyr * batch) != PISLAM_OK ||
           (F.orb_in_strip &&
-           c->w_stagedesc.ensure(sizeof(uint32_t) * (size_t)F.strips_per_pyr * batch * pf::QS_SHARED * (size_t)p->words) != PISLAM_OK) ||
-          c->w_ovf.ensure(sizeof(uint32_t) * ((size_t)F.strips_per_pyr * batch + 2), &grew_ovf) != PISLAM_OK)
+           c->w_stagedesc.ensure(sizeof(uint32_t) * (size_t)F.strips_per_pyr * batch * pf::QS_SHARED * (size_t)p->words) != PISLAM_OK))
         return fail(c, PISLAM_ERR_NOMEM, "hipMalloc(fused staging)");
-      if (grew_ovf) HIPCHK(c, hipMemsetAsync(c->w_ovf.p, 0, 2 * sizeof(uint32_t), c->stream));
+      if (c->opt_alias && submax <= 65535 && F.strips_per_pyr <= 65535)
+        PCHK(prepare_ovf(c, nsub, 2 + (size_t)F.strips_per_pyr * submax));
+      if (nsub > 1) PCHK(ensure_aux(c, nsub));
     }
   }
   return PISLAM_OK;
@@ -1411,7 +1541,8 @@ PISLAM_EXPORT int pislam_orb_frontend_batch(pislam_ctx *c, const pislam_frontend
   pf::FusedParams F;
   size_t lds = 0;
   size_t lds_alias = 0;
-  bool fused = c->opt_pipeline != 1 && build_fused_plan(c, p, lv, batch, &F, &lds, &lds_alias);
+  const int nsub = choose_sub_batches(c, p, batch);
+  bool fused = c->opt_pipeline != 1 && build_fused_plan(c, p, lv, sub_max(batch, nsub), &F, &lds, &lds_alias);
   if (c->opt_pipeline >= 2 && !fused)
     return fail(c, PISLAM_ERR_INVALID, "fused pipeline unavailable for these parameters (bucket size / LDS size)");
   c->last_pipeline = fused ? 2 : 1;
@@ -1424,7 +1555,7 @@ PISLAM_EXPORT int pislam_orb_frontend_batch(pislam_ctx *c, const pislam_frontend
     return PISLAM_OK;
   }
   if (fused) {
-    PCHK(run_fused(c, p, F, lds, lds_alias, pyramids, stride, batch, kp, desc, counts));
+    PCHK(run_fused(c, p, F, lds, lds_alias, pyramids, stride, batch, nsub, kp, desc, counts));
   } else {
   HIPCHK(c, hipMemsetAsync(counts, 0, sizeof(uint32_t) * batch, c->stream));
   // The score map workspace is laid out with stride pyr_bytes; the image with `stride`.  The stage
@@ -1486,8 +1617,12 @@ PISLAM_EXPORT int pislam_frontend_last_stats(pislam_ctx *c, uint32_t stats[2]) {
   stats[0] = stats[1] = 0;
   if (!c->w_ovf.p || !c->last_strips) return PISLAM_OK;      // staged pipeline / separate-tile layout: nothing deferred
   HIPCHK(c, hipSetDevice(c->device));
-  HIPCHK(c, hipMemcpyAsync(&stats[0], c->w_ovf.as<uint32_t>() + 1, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+  uint32_t prev[pislam_ctx::MAX_SUB] = {};
+  for (int i = 0; i < c->ovf_nsub; i++)          // one list per sub-batch: [1] = strips the last step deferred
+    HIPCHK(c, hipMemcpyAsync(&prev[i], c->w_ovf.as<uint32_t>() + (size_t)i * c->ovf_stride + 1, sizeof(uint32_t),
+                             hipMemcpyDeviceToHost, c->stream));
   PCHK(sync(c));
+  for (int i = 0; i < c->ovf_nsub; i++) stats[0] += prev[i];
   stats[1] = c->last_strips;
   return PISLAM_OK;
 }
@@ -1499,6 +1634,35 @@ PISLAM_EXPORT int pislam_frontend_last_timing(pislam_ctx *c, float *total_ms, fl
   if (total_ms) HIPCHK(c, hipEventElapsedTime(total_ms, c->ev[0], c->ev[3]));
   if (stage_ms)
     for (int i = 0; i < 3; i++) HIPCHK(c, hipEventElapsedTime(&stage_ms[i], c->ev[i], c->ev[i + 1]));
+  return PISLAM_OK;
+}
+
+// ---- measurement aid: shader clock under the current load ------------------------------------------
+namespace {
+__global__ void k_shader_clock(unsigned long long ticks_100mhz, unsigned long long *out) {
+  const unsigned long long w0 = wall_clock64(), c0 = (unsigned long long)clock64();
+  unsigned long long w1 = w0;
+  while (w1 - w0 < ticks_100mhz) w1 = wall_clock64();
+  const unsigned long long c1 = (unsigned long long)clock64();
+  if (threadIdx.x == 0) {
+    out[0] = c1 - c0;
+    out[1] = w1 - w0;
+  }
+}
+}  // namespace
+
+PISLAM_EXPORT int pislam_debug_shader_clock(pislam_ctx *c, int micros, double *ghz) {
+  if (!c || !ghz) return PISLAM_ERR_INVALID;
+  if (micros < 1 || micros > 100000) return fail(c, PISLAM_ERR_INVALID, "micros must be 1..100000");
+  HIPCHK(c, hipSetDevice(c->device));
+  if (c->w_total.ensure(2 * sizeof(unsigned long long)) != PISLAM_OK) return fail(c, PISLAM_ERR_NOMEM, "hipMalloc");
+  hipLaunchKernelGGL(k_shader_clock, dim3(1), dim3(64), 0, c->stream, (unsigned long long)micros * 100ull,
+                     c->w_total.as<unsigned long long>());
+  PCHK(launch_ok(c, "k_shader_clock"));
+  unsigned long long r[2] = {0, 0};
+  HIPCHK(c, hipMemcpyAsync(r, c->w_total.p, sizeof(r), hipMemcpyDeviceToHost, c->stream));
+  PCHK(sync(c));
+  *ghz = r[1] ? (double)r[0] / (double)r[1] * 0.1 : 0.0;
   return PISLAM_OK;
 }
 

@@ -264,7 +264,11 @@ struct ZeroPlan {
   int row0[16], ww[16], wh[16], slot_rows[16];
 };
 constexpr int ZM_COLS = 32, ZM_ROWS = 16;
-__global__ __launch_bounds__(256) void k_zero_margins(const ZeroPlan Z, uint8_t *__restrict__ pyramids, size_t stride) {
+// CHECK = true (debug flag PISLAM_BUILD_CHECK_MARGINS): nothing is written; the non-zero margin bytes are counted
+// into *dirty instead — what a caller's PISLAM_BUILD_MARGINS_CLEAN promise is verified with.
+template <bool CHECK>
+__global__ __launch_bounds__(256) void k_zero_margins(const ZeroPlan Z, uint8_t *__restrict__ pyramids, size_t stride,
+                                                      unsigned int *__restrict__ dirty) {
   const int l = blockIdx.x >> 1, bottom = blockIdx.x & 1;
   const int ww = Z.ww[l], wh = Z.wh[l];
   const int rows_all = min(Z.slot_rows[l], wh + ZM_ROWS);
@@ -281,7 +285,11 @@ __global__ __launch_bounds__(256) void k_zero_margins(const ZeroPlan Z, uint8_t 
     const int r = r0 + i / nv, v = v0 + i % nv;
     uint8_t *p = base + (size_t)r * Z.vstep;
     const int a = max(16 * v, x0), b = min(16 * v + 16, x1);
-    if (a == 16 * v && b == 16 * v + 16 && (((uintptr_t)(p + a)) & 15) == 0) {
+    if (CHECK) {
+      unsigned int nz = 0;
+      for (int x = a; x < b; x++) nz += p[x] != 0;
+      if (nz) atomicAdd(dirty, nz);
+    } else if (a == 16 * v && b == 16 * v + 16 && (((uintptr_t)(p + a)) & 15) == 0) {
       *(g_u32x4 *)(p + a) = (g_u32x4)(0u);
     } else {
       for (int x = a; x < b; x++) p[x] = 0;

@@ -108,27 +108,44 @@ def gather_counts(local_counts: torch.Tensor, world: int, shard_sizes=None) -> t
     return torch.cat([out[r * m:r * m + shard_sizes[r]] for r in range(world)])
 
 
+class ExchangeHub:
+    """ONE communicator and ONE collective stream per process (a capi.Context on which init_rccl succeeded),
+    shared by every pipeline of the process: all collectives are issued through it, in host order — the same
+    order on every rank (several communicators whose collectives a device may run in different orders on
+    different ranks are the documented NCCL/RCCL deadlock pattern)."""
+
+    def __init__(self, ctx):
+        self.ctx = ctx
+        self.issued = 0                 # collectives issued through this hub so far
+
+
 class CountExchange:
     """The per-step count all-gather taken OFF the critical path: step i's counts are gathered on the
     collective stream while step i+1 computes into the other of two output sets (the all-gather is
     latency-bound — 1 KiB per rank — and would otherwise add its tens of microseconds to every ~0.3 ms step).
 
-        xchg.before_step()        # orders the reuse of the output set written two steps ago
-        <enqueue step i's kernels into output set i % 2>
+        xchg.before_step()        # orders the reuse of the output set written `sets` steps ago
+        <enqueue step i's kernels into output set i % sets>
         xchg.start(counts_i)      # all-gather of step i's counts, asynchronous
         ...
         all_counts = xchg.finish()
 
-    `ctx` (a capi.Context on which init_rccl succeeded) selects the C-ABI RCCL path; without it the
-    exchange uses torch.distributed (gloo test mode, or the fallback bench.py reports as such)."""
+    `ctx` (a capi.Context on which init_rccl succeeded) or `hub` (an ExchangeHub: several pipelines sharing one
+    communicator) selects the C-ABI RCCL path; `stream` (raw hipStream_t) is the stream this pipeline's kernels
+    run on when it is not the hub context's own.  Without ctx / hub the exchange uses torch.distributed (gloo
+    test mode, or the fallback bench.py reports as such)."""
 
-    def __init__(self, world: int, ctx=None, always_collective: bool = False, sets: int = 2):
+    def __init__(self, world: int, ctx=None, always_collective: bool = False, sets: int = 2, hub: ExchangeHub | None = None,
+                 stream: int | None = None):
         self.world = world
-        self.sets = sets                     # output sets the caller alternates between on this context (1 or 2)
-        self.ctx = ctx
+        self.sets = sets                     # output sets the caller alternates between on this pipeline (1 or 2)
+        self.hub = hub if hub is not None else (ExchangeHub(ctx) if ctx is not None else None)
+        self.ctx = self.hub.ctx if self.hub is not None else None
+        self.stream = stream
         self.always = always_collective      # tests: run the collective path on a 1-rank group too
         self.pending = [None] * sets         # torch path: (work, out) per output set
         self.outs = [None] * sets            # C-ABI path: gathered counts per output set
+        self.ticket = [None] * sets          # C-ABI path: hub.issued when the set's last all-gather was issued
         self.last = None
         self.i = 0
 
@@ -140,16 +157,18 @@ class CountExchange:
 
     def before_step(self):
         """Call before enqueueing a step: the step overwrites the counts buffer whose all-gather was started
-        `sets` steps ago (on this context), so the launch stream first waits (on the device) for that collective."""
+        `sets` steps ago (on this pipeline), so the launch stream first waits (on the device) for that collective."""
         if self.world == 1 and not self.always:
             return
+        slot = self.i % self.sets
         if self.ctx is not None:
-            self.ctx.dist_fence(self.sets)
+            if self.ticket[slot] is not None:
+                self.ctx.dist_fence(self.hub.issued - self.ticket[slot], self.stream)
             return
-        prev = self.pending[self.i % self.sets]
+        prev = self.pending[slot]
         if prev is not None:
             prev[0].wait()
-            self.pending[self.i % self.sets] = None
+            self.pending[slot] = None
 
     def start(self, local_counts: torch.Tensor):
         slot = self.i % self.sets
@@ -161,7 +180,9 @@ class CountExchange:
             n = local_counts.numel()
             if self.outs[slot] is None or self.outs[slot].numel() != n * self.world:
                 self.outs[slot] = torch.empty(n * self.world, dtype=local_counts.dtype, device=local_counts.device)
-            self.ctx.dist_allgather_counts(local_counts, self.outs[slot])
+            self.ctx.dist_allgather_counts(local_counts, self.outs[slot], self.stream)
+            self.ticket[slot] = self.hub.issued
+            self.hub.issued += 1
             self.last = self.outs[slot]
             return
         if dist.get_backend() == "gloo":     # test mode (host tensors): synchronous

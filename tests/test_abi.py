@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/pislam_hip.h but not exported"
     assert set(names) == set(capi.SYMBOLS), "capi.SYMBOLS out of sync with the header"
-    assert lib.pislam_abi_version() == 1
+    assert lib.pislam_abi_version() == 2
 
 
 def test_no_torch_types_in_abi():

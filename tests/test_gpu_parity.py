@@ -865,3 +865,71 @@ def test_bench_two_ranks_on_one_gpu_does_not_deadlock():
     line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
     d = json.loads(line)
     assert d["n_gpus"] == 2 and d["steps"] == 6 and d["value"] > 0 and d["config"]["global_batch"] == 32
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nsub", [2, 3, 5])
+def test_sub_batch_pipelining_inside_the_call_is_exact(gpu_ctx, orc, nsub):
+    """Option "sub_batches": the batch call cuts its batch into sub-batches whose overflow pass + gather/ORB
+    kernels run on the context's second stream under the next sub-batch's strip kernel (fork / join inside the
+    call).  Ragged splits (7 pyramids over 2 / 3 / 5), a dense pyramid that takes the overflow pass in one
+    sub-batch only, buckets, a hipGraph capture of the forked call: all identical to the one-launch-group result
+    and to the oracle; pislam_frontend_last_stats sums the sub-batches' overflow lists."""
+    import torch
+    from pislam_amd import synth
+    from pislam_amd.capi import Context
+    from pislam_amd.frontend import OrbFrontend
+    levels = [(160, 120, 0), (133, 100, 120), (111, 83, 220)]
+    rows = 303
+    B = 7
+    pyr = synth.make_batch(21, B, w0=160, h0=120, vstep=160, levels=levels)
+    rng = np.random.default_rng(3)
+    for (w, h, r0) in levels:                                   # pyramid 4: uniform noise -> overflow pass
+        pyr[4, r0:r0 + h, :w] = rng.integers(0, 256, (h, w), dtype=np.uint8)
+    dev = torch.device("cuda:0")
+    d_pyr = torch.from_numpy(pyr).to(dev)
+    try:
+        for lbs, lim in ((0, 5), (3, 2)):
+            ref = [orc.pyramid(pyr[b], levels, log_bucket=lbs, bucket_limit=lim) for b in range(B)]
+            outs = {}
+            for n in (1, nsub):
+                gpu_ctx.set_option("sub_batches", n)
+                fe = OrbFrontend(levels, vstep=160, rows=rows, max_keypoints=8192, log_bucket_size=lbs, bucket_limit=lim,
+                                 ctx=gpu_ctx)
+                kp, desc, counts = fe.alloc_outputs(B, dev)
+                for rep in range(2):                              # the second call starts from emptied overflow lists
+                    fe(d_pyr, kp, desc, counts)
+                    torch.cuda.synchronize()
+                outs[n] = (tuple(t.cpu().numpy().view(np.uint32) for t in (counts, kp, desc)), fe.last_stats())
+            (c, k, d), st = outs[nsub]
+            assert st == outs[1][1] and st[0] > 0
+            for b in range(B):
+                okp, odesc, _ = ref[b]
+                n = min(len(okp), 8192)
+                assert c[b] == len(okp), (nsub, lbs, b)
+                assert (k[b, :n] == okp[:n]).all() and (d[b, :n] == odesc[:n]).all(), (nsub, lbs, b)
+            assert (outs[1][0][0] == c).all()
+    finally:
+        gpu_ctx.set_option("sub_batches", 1)
+    # the forked call inside a hipGraph capture
+    side = torch.cuda.Stream(dev)
+    with torch.cuda.stream(side):
+        ctx = Context(device=0, stream=side.cuda_stream)
+        ctx.set_option("sub_batches", nsub)
+        fe = OrbFrontend(levels, vstep=160, rows=rows, max_keypoints=8192, ctx=ctx)
+        fe.reserve(B)
+        kp, desc, counts = fe.alloc_outputs(B, dev)
+        fe(d_pyr, kp, desc, counts)
+        side.synchronize()
+        want = tuple(t.clone() for t in (kp, desc, counts))
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=side):
+            fe(d_pyr, kp, desc, counts)
+        for t in (kp, desc, counts):
+            t.zero_()
+        for _ in range(3):
+            g.replay()
+        side.synchronize()
+        for a, b in zip(want, (kp, desc, counts)):
+            assert torch.equal(a, b)
+        ctx.close()
