@@ -64,7 +64,7 @@ int pislam_ctx_set_stream(pislam_ctx *ctx, void *hip_stream);
  *   "dump_score" fused pipeline also materialises the score map (pislam_frontend_get_score_map)
  *   "strip_rows" fused strip height (0 = heuristic);  "run_len" strips per workgroup run (0 = by batch)
  *   "alias"      1 (default) score tile laid over the dead image rows + overflow pass, 0 separate tiles
- *   "xtile_cols" image x-tiles inside a strip (0 = full width);  "orb_chunks" gather+ORB workgroups per pyramid
+ *   "orb_chunks" gather+ORB workgroups per pyramid
  *   "run_order"  1 (default) a pyramid's runs are launched longest first, 0 in level order
  *   "tile_cols"  levels with more classified columns are cut into x-tiles run by separate workgroups (0 = 704, < 0 never)
  *   "orb_in_strip" 1 strips describe their own keypoints right after their NMS, 0 (default) one gather+ORB pass describes all

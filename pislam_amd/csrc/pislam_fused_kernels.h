@@ -64,9 +64,7 @@ struct FusedLevel {
   int nbx;           // 2x2 blocks per block-row
   int xend;          // one past the last classified column (Fast.h:61,149)
   int pitch;         // LDS SCORE tile pitch in bytes (multiple of 16): the score tile spans the full level width
-  int ntx;           // x-tiles the IMAGE tile is cut into (the image is staged ntx times, tcols classified columns each)
-  int tcols;         // classified columns per x-tile (multiple of 16)
-  int tpitch;        // LDS IMAGE tile pitch in bytes (multiple of 16) = tcols + halo
+  int tpitch;        // LDS IMAGE tile pitch in bytes (multiple of 16) = classified columns + halo
   int nruns, run0;   // runs (= workgroups) of this level: run_len consecutive strips each
   int apad;          // ALIAS layout: bytes between the per-wave queues and the image tile (multiple of 16)
   int qh;            // ALIAS layout: entries of the shared corner queue (>= QH_SHARED: the plan hands the LDS
@@ -349,12 +347,11 @@ struct StripArgs {
   int words, orb;
 };
 
-// All phases of one strip.  The SCORE tile covers the full level width; the IMAGE tile is staged in
-// L.ntx x-tiles of L.tcols classified columns (+ halo), one after the other, so that the workgroup's
-// LDS footprint — and with it the number of resident workgroups, to which this instruction-issue
-// bound kernel is measurably sensitive — does not grow with the level width.  Per x-tile: stage,
-// prefilter / pretest / FAST (scores of over-classified columns and corner queue), Harris for the
-// tile's corners.  NMS runs once per strip on the full-width score tile.
+// All phases of one strip of one plan entry (a level, or an x-tile of a wide level — FusedLevel): stage,
+// prefilter / pretest / FAST (scores of over-classified columns and corner queue), Harris for the corners,
+// NMS on the score tile.  (Staging a strip's image in several x-tiles INSIDE the workgroup — round 1's
+// option "xtile_cols" — was measured slower than full-width tiles and is gone: wide levels are cut into
+// plan entries run by separate workgroups instead.)
 template <bool VEC16, bool HOOKS, bool ALIAS, bool ORBK>
 __device__ __forceinline__ void strip_body(const StripArgs A, const FusedLevel L, const int pyr, const int s,
                                            const int ys, const int ye, lds_u8 *tile0, lds_u8 *sc, lds_u32 *queues,
@@ -373,8 +370,9 @@ __device__ __forceinline__ void strip_body(const StripArgs A, const FusedLevel L
   // keypoints.  (Compiled out of the default kernels: its registers would cost them 10 VGPRs.)
   constexpr bool ORB = ALIAS && VEC16 && ORBK;
   const int pitch = L.pitch, tpitch = L.tpitch;
-  lds_u8 *tile = tile0;                             // re-based per x-tile: tile + row*tpitch + x with level column x
-  int cxa = B, cxb = L.xend;                        // classified columns [cxa, cxb) of the current x-tile
+  const int cxa = B, cxb = L.xend;                  // classified columns [cxa, cxb)
+  const int xbase = (cxa - 4) & ~15;                // first staged column (16-byte aligned)
+  lds_u8 *tile = tile0 - xbase;                     // tile + row*tpitch + x with entry column x
   // profiling hook (HOOKS kernels only, ablate bit 8192): workgroup wall-clock cycles per phase
   long long t_last = 0;
   if (HOOKS && prof) t_last = clock64();
@@ -391,7 +389,7 @@ __device__ __forceinline__ void strip_body(const StripArgs A, const FusedLevel L
   // its tiles are intact.  The image rows [ys-4, ys+6) are that strip's tile rows R..R+9 and the
   // score rows [ys-1, ys+2) its score rows R..R+2, so they are moved up inside LDS instead of being
   // staged / classified / scored a second time; the NMS candidates queued for those rows move too.
-  const bool carry_img = carry && L.ntx == 1;
+  const bool carry_img = carry;
   if (carry) {
     const int R = L.R;
     if (carry_img) {
@@ -518,7 +516,7 @@ __device__ __forceinline__ void strip_body(const StripArgs A, const FusedLevel L
   const int r_lo = carry ? 3 : (ys - 1 < B) ? 1 : 0;              // rows above B are never classified
   const int r_hi = min(ye + 2, Lh - B) - (ys - 1);               // exclusive
   const uint32_t t2 = (uint32_t)thr * 0x00010001u;
-  const bool aligned4 = ((B | Lxend | L.tcols) & 3) == 0;    // x-tile edges fall on dword boundaries
+  const bool aligned4 = ((B | Lxend) & 3) == 0;    // the classified range's edges fall on dword boundaries
 
   // exact compass pretest of the 4 pixels of one group (x0 % 4 == 0), survivors -> qf
   auto pretest_batch = [&](bool valid, uint32_t key) {
@@ -541,7 +539,7 @@ __device__ __forceinline__ void strip_body(const StripArgs A, const FusedLevel L
                __builtin_amdgcn_perm(wr, wc, 0x0c060c04u), t2, bo, dd); // x+3: r.b0, r.b2
     const uint32_t re = be | de, ro = bo | dd;
     uint32_t fe = valid ? re & 0x80008000u : 0u, fo = valid ? ro & 0x80008000u : 0u;
-    if (!aligned4) {                     // generic border: mask the pixels outside this x-tile's [cxa, cxb)
+    if (!aligned4) {                     // generic border: mask the pixels outside [cxa, cxb)
       if (x0 + 0 < cxa || x0 + 0 >= cxb) fe &= ~0x00008000u;
       if (x0 + 1 < cxa || x0 + 1 >= cxb) fo &= ~0x00008000u;
       if (x0 + 2 < cxa || x0 + 2 >= cxb) fe &= ~0x80000000u;
@@ -577,11 +575,7 @@ __device__ __forceinline__ void strip_body(const StripArgs A, const FusedLevel L
 
   // ALIAS: entries [0, h_begin) of the queue are already scored (carried from the strip above)
   int h_begin = 0;
-  for (int xt = 0; xt < L.ntx; xt++) {
-    cxa = B + xt * L.tcols;
-    cxb = min(cxa + L.tcols, Lxend);
-    const int xbase = (cxa - 4) & ~15;              // first staged column (16-byte aligned)
-    tile = tile0 - xbase;
+  {
     // ---- stage image rows [ys-4, min(ye+6, h)), columns [xbase, xbase + tpitch) -----------------
     {
       const int y_lo = ys - 4;
@@ -622,11 +616,13 @@ __device__ __forceinline__ void strip_body(const StripArgs A, const FusedLevel L
             if (off + 16 <= lim) {
               d = *(const u32x4 *)(im + off);
             } else {
-              uint32_t w4[4] = {0, 0, 0, 0};      // byte-wise, zero beyond the end
+              uint32_t w0 = 0, w1 = 0, w2 = 0, w3 = 0;   // byte-wise, zero beyond the end (scalars: an indexed array lands in scratch)
 #pragma unroll
-              for (int k = 0; k < 16; k++)
-                if (off + k < lim) w4[k >> 2] |= (uint32_t)im[off + k] << (8 * (k & 3));
-              d = (u32x4){w4[0], w4[1], w4[2], w4[3]};
+              for (int k = 0; k < 16; k++) {
+                const uint32_t b = off + k < lim ? (uint32_t)im[off + k] << (8 * (k & 3)) : 0u;
+                if (k < 4) w0 |= b; else if (k < 8) w1 |= b; else if (k < 12) w2 |= b; else w3 |= b;
+              }
+              d = (u32x4){w0, w1, w2, w3};
             }
             dstv[i] = d;
           }
@@ -641,12 +637,12 @@ __device__ __forceinline__ void strip_body(const StripArgs A, const FusedLevel L
     }
     lds_barrier();
     mark(0);
-    if (ALIAS && xt == 0) h_begin = (int)sh_ctr[2]; // carried entries (sh_ctr[0] is already being appended to)
+    if (ALIAS) h_begin = (int)sh_ctr[2];            // carried entries (sh_ctr[0] is already being appended to)
     // Prefetch the next strip's R new image rows (level rows ye+6 ..) into registers now: the loads are
     // in flight during this strip's classification and are only waited for when the next strip stores
     // them (lds_barrier does not wait for global loads).
     pf_issued = false;
-    if (VEC16 && pf_want && L.ntx == 1 && L.R >= 10 && L.R * (tpitch >> 4) <= PF_MAX * NT) {
+    if (VEC16 && pf_want && L.R >= 10 && L.R * (tpitch >> 4) <= PF_MAX * NT) {
       const int vpr = tpitch >> 4;
       const int ylo_n = ye - 4, ye_n = min(ye + L.R, Lh - B);
       const int nrows_n = min(ye_n + 6, Lh) - ylo_n;
@@ -662,13 +658,13 @@ __device__ __forceinline__ void strip_body(const StripArgs A, const FusedLevel L
         pf_issued = true;
       }
     }
-    if (ablate & 1) continue;
+    if (ablate & 1) return;
 
     // Group prefilter on every 4-pixel group: a pixel can only pass the compass test if one of its
     // vertical compass points AND one of its horizontal ones differ from it by more than t, so the
     // byte-wise SADs of the group against the rows 3 above/below and the columns 3 left/right must
     // exceed t on both axes (v_sad_u8 sums |a-b| over the 4 bytes, an upper bound of each term).
-    const int xs = cxa & ~3;                        // dword-aligned start column of this x-tile
+    const int xs = cxa & ~3;                        // dword-aligned start column
     // One lane = one 4-pixel group, 256 columns per wave step: `nfull` steps with all lanes inside the
     // tile's columns and one tail step with the lanes past cxb masked off, so that the full steps need
     // no per-lane bounds test (their compare lands directly in VCC = the ballot).
@@ -677,7 +673,7 @@ __device__ __forceinline__ void strip_body(const StripArgs A, const FusedLevel L
     // the tails of `tm` = 64 / (rem / 4) consecutive rows (plan: L.tail_rows) share one wave step: lane ->
     // (row lrow, group lcol) of the step.
     const int tg = (rem + 3) >> 2;
-    const int tm = L.ntx == 1 ? L.tail_rows : 1;
+    const int tm = L.tail_rows;
     const int lrow = tm > 1 ? (int)__umulhi((uint32_t)lane, L.tail_recip) : 0;
     const int lcol = lane - lrow * tg;
     const bool tail_lane = lrow < tm && 4 * lcol < rem;
@@ -741,16 +737,10 @@ __device__ __forceinline__ void strip_body(const StripArgs A, const FusedLevel L
           const int at = min(c0 + lane, th - 1);
           harris_batch(c0 + lane < th, shq_h[at], at);
         }
-      if (ALIAS) h_begin = th;                      // the next x-tile's corners are appended behind these
     }
     lds_barrier();
     mark(2);
-    if (!ALIAS && tid == 0) {                       // fresh corner queue for the next x-tile
-      sh_ctr[0] = 0;
-      sh_ctr[1] = QH_SHARED;                        // (plain layout: qcap == QH_SHARED)
-    }
   }
-  if (ablate & 1) return;
   tile = tile0;
   if ((ablate & 512) && tid == 0) sh_ctr[3] = 1;    // test hook: force the overflow paths
   if (ablate & 512) lds_barrier();
@@ -1094,24 +1084,18 @@ __device__ __forceinline__ StripLds strip_lds(uint8_t *smem, const FusedLevel &L
   return m;
 }
 
-template <bool VEC16, bool HOOKS, bool ALIAS, bool ORBK = false>
-__global__ __launch_bounds__(NT) void k_fused_strips(
-    const FusedParams P, const uint8_t *__restrict__ pyramids, size_t pyr_stride,
-    uint32_t *__restrict__ stage_kp, uint32_t *__restrict__ strip_count,
-    uint8_t *__restrict__ score_dump, size_t score_stride, unsigned long long *__restrict__ prof,
-    uint32_t *__restrict__ ovf, uint32_t *__restrict__ stage_desc) {
-  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-  __shared__ uint32_t sh_ctr[8];
-  // XCD-aware mapping: workgroup b runs on XCD b%8; keep all strips of one pyramid on one XCD so
-  // the halo rows shared by neighbouring runs are served by that XCD's L2.
-  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-  // Run-major order: all pyramids' run 0 first, ... the short runs of the small levels last, so the
-  // tail of the grid consists of short workgroups (a run is up to run_len strips long).
-  // (A resident grid pulling runs from per-XCD atomic counters was measured: no gain at any batch.)
-  const int groups = (P.batch + 7) >> 3;
-  const int pyr = (slot % groups) * 8 + xcd;
-  if (pyr >= P.batch) return;
-  int run = slot / groups;
+// The strip role of a workgroup: run `run_idx` (launch order: FusedParams::order) of pyramid `pyr`.
+// A workgroup walks a RUN of consecutive strips of one level, top to bottom.  From the second strip
+// on, the 10 halo image rows and the 3 halo score rows it shares with the strip above are carried
+// over inside LDS (strip_body `carry`), so a run behaves like one strip of run_len * R rows at the
+// LDS footprint of R rows: the halo is staged, classified and scored once per run, not per strip.
+template <bool VEC16, bool HOOKS, bool ALIAS, bool ORBK>
+__device__ __forceinline__ void strips_role(const FusedParams &P, const uint8_t *__restrict__ pyramids, size_t pyr_stride,
+                                            uint32_t *__restrict__ stage_kp, uint32_t *__restrict__ strip_count,
+                                            uint8_t *__restrict__ score_dump, size_t score_stride,
+                                            unsigned long long *__restrict__ prof, uint32_t *__restrict__ ovf,
+                                            uint32_t *__restrict__ stage_desc, uint8_t *smem, uint32_t *sh_ctr, const int pyr,
+                                            int run) {
   int li = 0;
   if (P.order_n > 0) {
     const uint32_t o = P.order[run];
@@ -1121,10 +1105,6 @@ __global__ __launch_bounds__(NT) void k_fused_strips(
     while (li + 1 < P.nlevels && run >= P.lv[li + 1].run0) li++;
     run -= P.lv[li].run0;
   }
-  // A workgroup walks a RUN of consecutive strips of one level, top to bottom.  From the second strip
-  // on, the 10 halo image rows and the 3 halo score rows it shares with the strip above are carried
-  // over inside LDS (strip_body `carry`), so a run behaves like one strip of run_len * R rows at the
-  // LDS footprint of R rows: the halo is staged, classified and scored once per run, not per strip.
   const int s0 = run * P.run_len, s1 = min(s0 + P.run_len, P.lv[li].nstrips);
   long long t_wg = 0;
   if (HOOKS && prof) {
@@ -1167,6 +1147,27 @@ __global__ __launch_bounds__(NT) void k_fused_strips(
     }
   }
   if (HOOKS && prof && threadIdx.x == 0) prof[7] += (unsigned long long)(clock64() - t_wg);
+}
+
+template <bool VEC16, bool HOOKS, bool ALIAS, bool ORBK = false>
+__global__ __launch_bounds__(NT) void k_fused_strips(
+    const FusedParams P, const uint8_t *__restrict__ pyramids, size_t pyr_stride,
+    uint32_t *__restrict__ stage_kp, uint32_t *__restrict__ strip_count,
+    uint8_t *__restrict__ score_dump, size_t score_stride, unsigned long long *__restrict__ prof,
+    uint32_t *__restrict__ ovf, uint32_t *__restrict__ stage_desc) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  __shared__ uint32_t sh_ctr[8];
+  // XCD-aware mapping: workgroup b runs on XCD b%8; keep all strips of one pyramid on one XCD so
+  // the halo rows shared by neighbouring runs are served by that XCD's L2.
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  // Run-major order: all pyramids' run 0 first, ... the short runs of the small levels last, so the
+  // tail of the grid consists of short workgroups (a run is up to run_len strips long).
+  // (A resident grid pulling runs from per-XCD atomic counters was measured: no gain at any batch.)
+  const int groups = (P.batch + 7) >> 3;
+  const int pyr = (slot % groups) * 8 + xcd;
+  if (pyr >= P.batch) return;
+  strips_role<VEC16, HOOKS, ALIAS, ORBK>(P, pyramids, pyr_stride, stage_kp, strip_count, score_dump, score_stride, prof, ovf,
+                                         stage_desc, smem, sh_ctr, pyr, slot / groups);
 }
 
 // Strips the ALIAS kernel could not finish (a queue overflowed) are redone here, one strip per
@@ -1317,38 +1318,29 @@ __global__ __launch_bounds__(256) void k_gather(const FusedParams P,
   }
 }
 
-// ===========================================================================
-// k_gather_orb — strip lists -> final keypoint order; descriptors copied from the strips' staging slots,
-// or computed here for the strips that did not describe their own keypoints.
-//
-// grid (NCH, batch): workgroup (ch, pyr) owns the staged keypoints [ch*per, (ch+1)*per) of pyramid pyr in
-// storage order.  Every workgroup redoes the (tiny) exclusive scan of the pyramid's strip counts, then, per
-// keypoint (one thread each, its strip found by binary search): final position (final_position), keypoint
-// written there, and
-//   - the descriptor copied from the strip's descriptor slots when the strip described it (strip count
-//     bit 31, see strip_body phase E);
-//   - otherwise queued and described here: orb_fetch / orb_describe, two keypoints per wave iteration, the
-//     next pair's loads in flight while the current pair is processed.
-// ===========================================================================
-__global__ __launch_bounds__(256) void k_gather_orb(
-    const FusedParams P, const uint8_t *__restrict__ pyramids, size_t pyr_stride,
-    const uint32_t *__restrict__ stage_kp, const uint32_t *__restrict__ strip_count,
-    const uint32_t *__restrict__ stage_desc,
-    uint32_t *__restrict__ kp, size_t kp_stride, uint32_t cap, uint32_t *__restrict__ counts,
-    uint32_t *__restrict__ desc, size_t desc_stride, int words, uint32_t per_max, uint32_t *__restrict__ ovf_reset) {
-  extern __shared__ __attribute__((aligned(16))) uint8_t osm[];
-  __shared__ uint32_t wsum[4];
-  __shared__ uint32_t carry;
-  __shared__ uint32_t ntodo;
-  __shared__ uint8_t sh_rtab[256];                  // vrecpe estimate table (256 threads: one entry each)
-  sh_rtab[threadIdx.x] = ::g_vrecpe_tab.v[threadIdx.x];
-  const lds_u8 *rtab = (const lds_u8 *)sh_rtab;
-  // the overflow list of this step has been consumed (stream order): empty it for the next step
-  if (ovf_reset && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
-    ovf_reset[1] = ovf_reset[0];                     // kept for pislam_frontend_last_stats
-    ovf_reset[0] = 0;
-  }
-  const int pyr = blockIdx.y, ch = blockIdx.x, nch = gridDim.x;
+// Small shared state of the gather + ORB role, carved from the FRONT of the dynamic LDS (not static: the strip
+// role's 5-workgroups-per-CU budget has no room for another 300 static bytes).
+struct OrbShared {
+  uint32_t wsum[4];
+  uint32_t carry, ntodo, flag, pad;
+  uint8_t rtab[256];                                // vrecpe estimate table (256 threads: one entry each)
+};
+__host__ __device__ constexpr size_t orb_lds_bytes(int strips_per_pyr, size_t per_max) {
+  return sizeof(OrbShared) + (size_t)OWAVES * 2 * ORB_PATCH_BYTES + sizeof(uint32_t) * (((size_t)strips_per_pyr + 1 + 3) & ~(size_t)3) +
+         sizeof(uint32_t) * 2 * per_max;            // keypoints to describe here and their final positions
+}
+
+// The gather + ORB role of a workgroup: chunk `ch` of `nch` of pyramid `pyr` (see k_gather_orb).
+__device__ __forceinline__ void orb_role(const FusedParams &P, const uint8_t *__restrict__ pyramids, size_t pyr_stride,
+                                         const uint32_t *__restrict__ stage_kp, const uint32_t *__restrict__ strip_count,
+                                         const uint32_t *__restrict__ stage_desc, uint32_t *__restrict__ kp, size_t kp_stride,
+                                         uint32_t cap, uint32_t *__restrict__ counts, uint32_t *__restrict__ desc,
+                                         size_t desc_stride, int words, uint32_t per_max, uint8_t *osm_all, const int pyr,
+                                         const int ch, const int nch) {
+  OrbShared *sh = (OrbShared *)osm_all;
+  uint8_t *osm = osm_all + sizeof(OrbShared);
+  sh->rtab[threadIdx.x] = ::g_vrecpe_tab.v[threadIdx.x];
+  const lds_u8 *rtab = (const lds_u8 *)sh->rtab;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int S = P.strips_per_pyr;
@@ -1361,7 +1353,7 @@ __global__ __launch_bounds__(256) void k_gather_orb(
 
   // ---- exclusive scan of the strip counts (storage order) ----
   const uint32_t *cnt = strip_count + (size_t)pyr * S;
-  if (tid == 0) carry = 0;
+  if (tid == 0) sh->carry = 0;
   __syncthreads();
   for (int base = 0; base < S; base += 256) {
     const int i = base + tid;
@@ -1372,16 +1364,16 @@ __global__ __launch_bounds__(256) void k_gather_orb(
       const uint32_t t = (uint32_t)__shfl_up((int)incl, d, 64);
       if (lane >= d) incl += t;
     }
-    if (lane == 63) wsum[wv] = incl;
+    if (lane == 63) sh->wsum[wv] = incl;
     __syncthreads();
-    uint32_t pre = carry;
-    for (int w = 0; w < wv; w++) pre += wsum[w];
+    uint32_t pre = sh->carry;
+    for (int w = 0; w < wv; w++) pre += sh->wsum[w];
     if (i < S) soff[i] = pre + incl - v;
     __syncthreads();
-    if (tid == 255) carry = pre + incl;
+    if (tid == 255) sh->carry = pre + incl;
     __syncthreads();
   }
-  const uint32_t total = carry;
+  const uint32_t total = sh->carry;
   if (tid == 0) {
     soff[S] = total;
     if (ch == 0) counts[pyr] = total;
@@ -1402,7 +1394,7 @@ __global__ __launch_bounds__(256) void k_gather_orb(
   // rounds of at most per_max keypoints (one round unless the pyramid holds more keypoints than max_keypoints)
   for (uint32_t c0 = lo; c0 < hi; c0 += per_max) {
     const uint32_t c1 = min(c0 + per_max, hi);
-    if (tid == 0) ntodo = 0;
+    if (tid == 0) sh->ntodo = 0;
     __syncthreads();
     // ---- one thread per staged keypoint: strip by binary search, final position, keypoint + descriptor ----
     for (uint32_t e = c0 + tid; e < c1; e += 256) {
@@ -1421,13 +1413,13 @@ __global__ __launch_bounds__(256) void k_gather_orb(
         const uint32_t *src = sd + ((size_t)a * QS_SHARED + k) * words;
         for (int w = 0; w < words; w++) dsc[(size_t)pos * words + w] = src[w];
       } else {
-        const uint32_t slot = atomicAdd(&ntodo, 1u);   // (order irrelevant: results are positional)
+        const uint32_t slot = atomicAdd(&sh->ntodo, 1u);   // (order irrelevant: results are positional)
         kpl[slot] = v;
         kpos[slot] = pos;
       }
     }
     __syncthreads();
-    const uint32_t nt = ntodo;
+    const uint32_t nt = sh->ntodo;
     if (nt != 0 && !(P.ablate & 64)) {
       // ---- describe the rest: two keypoints per wave iteration ----
       const OrbLane G = orb_lane(lane, vstep);
@@ -1457,6 +1449,35 @@ __global__ __launch_bounds__(256) void k_gather_orb(
     }
     __syncthreads();                                  // kpl / kpos / todo are reused by the next round
   }
+}
+
+// ===========================================================================
+// k_gather_orb — strip lists -> final keypoint order; descriptors copied from the strips' staging slots,
+// or computed here for the strips that did not describe their own keypoints.
+//
+// grid (NCH, batch): workgroup (ch, pyr) owns the staged keypoints [ch*per, (ch+1)*per) of pyramid pyr in
+// storage order.  Every workgroup redoes the (tiny) exclusive scan of the pyramid's strip counts, then, per
+// keypoint (one thread each, its strip found by binary search): final position (final_position), keypoint
+// written there, and
+//   - the descriptor copied from the strip's descriptor slots when the strip described it (strip count
+//     bit 31, see strip_body phase E);
+//   - otherwise queued and described here: orb_fetch / orb_describe, two keypoints per wave iteration, the
+//     next pair's loads in flight while the current pair is processed.
+// ===========================================================================
+__global__ __launch_bounds__(256) void k_gather_orb(
+    const FusedParams P, const uint8_t *__restrict__ pyramids, size_t pyr_stride,
+    const uint32_t *__restrict__ stage_kp, const uint32_t *__restrict__ strip_count,
+    const uint32_t *__restrict__ stage_desc,
+    uint32_t *__restrict__ kp, size_t kp_stride, uint32_t cap, uint32_t *__restrict__ counts,
+    uint32_t *__restrict__ desc, size_t desc_stride, int words, uint32_t per_max, uint32_t *__restrict__ ovf_reset) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t osm[];
+  // the overflow list of this step has been consumed (stream order): empty it for the next step
+  if (ovf_reset && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+    ovf_reset[1] = ovf_reset[0];                     // kept for pislam_frontend_last_stats
+    ovf_reset[0] = 0;
+  }
+  orb_role(P, pyramids, pyr_stride, stage_kp, strip_count, stage_desc, kp, kp_stride, cap, counts, desc, desc_stride, words,
+           per_max, osm, (int)blockIdx.y, (int)blockIdx.x, (int)gridDim.x);
 }
 
 }  // namespace pf

@@ -108,7 +108,6 @@ struct pislam_ctx {
   int opt_repeat_strips = 1; // profiling: launch the strip kernel n times inside the stage-0 event bracket
   int opt_alias = 1;         // fused pipeline: score tile laid over the dead image rows (0 = separate tiles)
   int opt_run_len = 0;       // fused pipeline: strips per workgroup run (0 = default, 1 = independent strips)
-  int opt_xtile_cols = 0;    // fused pipeline: max classified columns per image x-tile (0 = full width)
   int opt_lds_pad = 0;       // profiling only: extra dynamic LDS bytes per strip workgroup
   int opt_wgs_per_cu = 0;    // fused pipeline: if > 0, size strip heights for this many workgroups per CU
   int opt_strip_px = 16384;  // profiling: pixels per strip the height heuristic aims at
@@ -463,9 +462,6 @@ PISLAM_EXPORT int pislam_ctx_set_option(pislam_ctx *c, const char *key, int valu
     return use_own_stream(c, value);
   } else if (!strcmp(key, "dump_score")) {
     c->opt_dump_score = value != 0;
-  } else if (!strcmp(key, "xtile_cols")) {
-    if (value > 0 && value < 64) return fail(c, PISLAM_ERR_INVALID, "xtile_cols must be 0 (full width), >= 64, or negative (default)");
-    c->opt_xtile_cols = value < 0 ? 0 : value;   // (the default is set in one place: here)
   } else if (!strcmp(key, "repeat_strips")) {
     if (value < 1 || value > 64) return fail(c, PISLAM_ERR_INVALID, "repeat_strips must be 1..64");
     c->opt_repeat_strips = value;
@@ -1116,21 +1112,17 @@ bool build_fused_plan_rows(const pislam_ctx *c, const pislam_frontend_params *p,
     L.nbx = (nx + 1) / 2;
     L.xend = p->border + 16 * cdiv(nx, 16);
     L.pitch = (L.xend + 4 + 15) & ~15;
-    // image x-tiles: at most opt_xtile_cols classified columns each (0 = one full-width tile)
-    const int ncols = L.xend - p->border;
-    L.ntx = c->opt_xtile_cols > 0 ? std::max(1, cdiv(ncols, c->opt_xtile_cols)) : 1;
-    L.tcols = (cdiv(ncols, L.ntx) + 15) & ~15;
-    L.ntx = cdiv(ncols, L.tcols);
     {
-      // staged columns [xbase, xbase+tpitch) with xbase = (cxa-4) & ~15 must reach column cxb+8
-      const int worst_lead = ((p->border - 4) & 15) + 4;      // cxa - xbase for cxa = border (mod 16)
-      L.tpitch = (L.tcols + worst_lead + 8 + 15) & ~15;
+      // staged columns [xbase, xbase+tpitch) with xbase = (border-4) & ~15 must reach column xend+8
+      const int ncols = L.xend - p->border;
+      const int lead = ((p->border - 4) & 15) + 4;            // border - xbase
+      L.tpitch = (ncols + lead + 8 + 15) & ~15;
     }
     L.vpr_recip = (uint32_t)(((1ull << 32) + (L.tpitch / 16) - 1) / (L.tpitch / 16));
     {
       // prefilter tail step (strip_body): 4-pixel groups of a row left over after the full 256-column steps
       const int xs = p->border & ~3, tg = ((((L.xend - xs) & 255)) + 3) >> 2;
-      L.tail_rows = (L.ntx == 1 && tg > 1) ? 64 / tg : 1;   // (tg == 1: the reciprocal does not fit 32 bits)
+      L.tail_rows = tg > 1 ? 64 / tg : 1;   // (tg == 1: the reciprocal does not fit 32 bits)
       L.tail_recip = tg > 0 ? (uint32_t)(((1ull << 32) + tg - 1) / tg) : 0;
     }
     strips += L.nstrips;
@@ -1368,8 +1360,7 @@ int run_fused(pislam_ctx *c, const pislam_frontend_params *p, const pf::FusedPar
     }
     if (c->opt_orb_chunks > 0) nch = c->opt_orb_chunks;
     per_max = ((size_t)p->max_keypoints + nch - 1) / nch;
-    olds = (size_t)pf::OWAVES * 2 * pf::ORB_PATCH_BYTES + sizeof(uint32_t) * (((size_t)S + 1 + 3) & ~(size_t)3) +
-           sizeof(uint32_t) * 2 * per_max;        // keypoints to describe here and their final positions
+    olds = pf::orb_lds_bytes(S, per_max);
     if (olds > 150 * 1024) return fail(c, PISLAM_ERR_INVALID, "max_keypoints too large for the fused ORB kernel");
     if (olds > 64 * 1024)
       HIPCHK(c, hipFuncSetAttribute((const void *)pf::k_gather_orb, hipFuncAttributeMaxDynamicSharedMemorySize, (int)olds));

@@ -33,7 +33,7 @@ def make_case(seed):
                log_bucket_size=int(rng.choice([0, 0, 2, 3, 4, 5])), bucket_limit=int(rng.integers(1, 7)),
                words=int(rng.choice([1, 2, 4, 8])), max_keypoints=int(rng.choice([16, 300, 4096])))
     opts = dict(pipeline=int(rng.choice([0, 1, 2, 2])), alias=int(rng.integers(0, 2)), run_len=int(rng.choice([0, 1, 3, 9])),
-                strip_rows=int(rng.choice([0, 0, 10, 16, 22, 32])), xtile_cols=int(rng.choice([0, 0, 0, 64, 96])),
+                strip_rows=int(rng.choice([0, 0, 10, 16, 22, 32])), sub_batches=1 + int(rng.choice([0, 0, 0, 64, 96])) // 48,
                 orb_in_strip=int(rng.integers(0, 2)), tile_cols=int(rng.choice([0, -1, 64, 96, 160])),
                 strip_rows_max=int(rng.choice([0, 0, 36, 56, 64])))
     return levels, vstep, rows, pyr, par, opts
@@ -66,7 +66,7 @@ def test_random_configurations_match_the_oracle(gpu_ctx, orc, chunk):
                 assert (k[b, :m] == okp[:m]).all(), (seed, b, par, opts, levels)
                 assert (d[b, :m].reshape(m, par["words"]) == odesc[:m]).all(), (seed, b, par, opts, levels)
     finally:
-        for k, v in dict(pipeline=0, alias=1, run_len=0, strip_rows=0, xtile_cols=-1, orb_in_strip=0, tile_cols=0,
+        for k, v in dict(pipeline=0, alias=1, run_len=0, strip_rows=0, sub_batches=1, orb_in_strip=0, tile_cols=0,
                          strip_rows_max=0).items():
             gpu_ctx.set_option(k, v)
 
@@ -155,7 +155,7 @@ def test_random_packed_layouts_match_the_oracle(gpu_ctx, orc):
                 pyr = (pyr.astype(np.int32) + rng.integers(-6, 7, pyr.shape)).clip(0, 255).astype(np.uint8)
             lbs, lim, border = int(rng.choice([0, 0, 3, 4])), int(rng.integers(1, 6)), int(rng.integers(16, 20))
             opts = dict(pipeline=int(rng.choice([1, 2, 2])), alias=int(rng.integers(0, 2)), run_len=int(rng.choice([0, 1, 5])),
-                        strip_rows=int(rng.choice([0, 16, 22])), xtile_cols=int(rng.choice([0, 0, 64])),
+                        strip_rows=int(rng.choice([0, 16, 22])), sub_batches=1 + int(rng.choice([0, 0, 64])) // 48,
                         orb_in_strip=int(rng.integers(0, 2)), tile_cols=int(rng.choice([0, 64, 128])),
                         strip_rows_max=int(rng.choice([0, 44, 56])))
             for k, v in opts.items():
@@ -179,7 +179,7 @@ def test_random_packed_layouts_match_the_oracle(gpu_ctx, orc):
                 assert c[b] == len(exp) and (k_[b, :len(exp)] == exp).all(), (t, b, levels, opts)
                 assert (d_[b, :len(exp)] == orc.orb_compute(pyr[b], exp)).all(), (t, b, levels, opts)
     finally:
-        for k, v in dict(pipeline=0, alias=1, run_len=0, strip_rows=0, xtile_cols=-1, orb_in_strip=0, tile_cols=0,
+        for k, v in dict(pipeline=0, alias=1, run_len=0, strip_rows=0, sub_batches=1, orb_in_strip=0, tile_cols=0,
                          strip_rows_max=0).items():
             gpu_ctx.set_option(k, v)
 

@@ -274,12 +274,12 @@ def test_brief_describe_all_rotations(gpu_ctx, orc, demo):
         assert (g[i] == exp).all(), (i, rots[i])
 
 
-@pytest.mark.parametrize("strip_rows,xtile_cols,run_len",
-                         [(0, 0, 0), (16, 0, 1), (16, 0, 3), (32, 0, 2), (2, 0, 0), (64, 0, 64), (0, 320, 0), (0, 224, 1),
-                          (16, 64, 5), (32, 100, 0), (0, 4096, 0), (10, 0, 64), (12, 0, 7), (8, 0, 4)])
-def test_fused_strip_heights(gpu_ctx, orc, strip_rows, xtile_cols, run_len):
-    """The fused pipeline's result must not depend on how levels are cut into strips, x-tiles and
-    runs of strips (halo rows carried over in LDS between the strips of a run)."""
+@pytest.mark.parametrize("strip_rows,sub_batches,run_len",
+                         [(0, 1, 0), (16, 1, 1), (16, 1, 3), (32, 1, 2), (2, 1, 0), (64, 1, 64), (0, 2, 0), (0, 3, 1),
+                          (16, 2, 5), (32, 3, 0), (0, 16, 0), (10, 1, 64), (12, 1, 7), (8, 1, 4)])
+def test_fused_strip_heights(gpu_ctx, orc, strip_rows, sub_batches, run_len):
+    """The fused pipeline's result must not depend on how levels are cut into strips and runs of strips (halo
+    rows carried over in LDS between the strips of a run), nor on the batch being cut into sub-batches."""
     import torch
     from pislam_amd import synth
     from pislam_amd.frontend import OrbFrontend
@@ -289,7 +289,7 @@ def test_fused_strip_heights(gpu_ctx, orc, strip_rows, xtile_cols, run_len):
     gpu_ctx.set_option("pipeline", 2)
     gpu_ctx.set_option("dump_score", 1)
     gpu_ctx.set_option("strip_rows", strip_rows)
-    gpu_ctx.set_option("xtile_cols", xtile_cols)
+    gpu_ctx.set_option("sub_batches", sub_batches)
     gpu_ctx.set_option("run_len", run_len)
     try:
         ref = [orc.pyramid(pyr[b], levels, return_score=True) for b in range(3)]
@@ -318,7 +318,7 @@ def test_fused_strip_heights(gpu_ctx, orc, strip_rows, xtile_cols, run_len):
         gpu_ctx.set_option("pipeline", 0)
         gpu_ctx.set_option("dump_score", 0)
         gpu_ctx.set_option("strip_rows", 0)
-        gpu_ctx.set_option("xtile_cols", -1)
+        gpu_ctx.set_option("sub_batches", 1)
         gpu_ctx.set_option("run_len", 0)
         gpu_ctx.set_option("alias", 1)
         gpu_ctx.set_option("ablate", 0)
@@ -933,3 +933,4 @@ def test_sub_batch_pipelining_inside_the_call_is_exact(gpu_ctx, orc, nsub):
         for a, b in zip(want, (kp, desc, counts)):
             assert torch.equal(a, b)
         ctx.close()
+
