@@ -252,6 +252,38 @@ int pislam_frontend_last_timing(pislam_ctx *ctx, float *total_ms, float stage_ms
  * than the fast path is sized for.  Synchronises the context stream. */
 int pislam_frontend_last_stats(pislam_ctx *ctx, uint32_t stats[2]);
 
+/* ---- batches in flight ---------------------------------------------------
+ * A pipeline = `depth` (1..8) contexts behind one object, each with its own workspace and non-blocking stream:
+ * batch k runs on lane k % depth, so that the tail of one batch (partly filled CUs, the latency-bound gather+ORB
+ * kernel, launch gaps) runs under the head of the next.  MI355X, 256 VGA pyramids per batch: 0.277 ms per batch
+ * one call at a time, 0.24 ms with depth 3.  The reference loop (demo/demo.cpp:77-101: frames are independent)
+ * becomes
+ *     for each batch k:  pislam_pipeline_submit(pipe, ..., inputs_k, outputs_k, producer_stream, 1, &t[k]);
+ *     before consuming outputs_k on stream s:  pislam_pipeline_wait(pipe, t[k], s);
+ * submit: the lane's stream first waits (device side) for everything `input_stream` (hipStream_t as void*) holds
+ * so far when order_after_input != 0 — the producer of `pyramids` — then runs pislam_orb_frontend_batch.  Outputs
+ * of a batch must stay untouched until its ticket has been waited for; a lane's batches are ordered among
+ * themselves.  pislam_pipeline_stream gives the lane's stream of a ticket (e.g. for
+ * pislam_dist_allgather_counts_on), pislam_pipeline_lane its context (statistics).  A call that repeats exactly
+ * (same buffers, same shape: a steady stream of batches) is replayed from a hipGraph from its third occurrence
+ * on (option "graphs" 0 = always eager); pislam_pipeline_set_option applies any context option to every lane. */
+typedef struct pislam_pipeline pislam_pipeline;
+int pislam_pipeline_create(int device, int depth, pislam_pipeline **pipe);
+int pislam_pipeline_destroy(pislam_pipeline *pipe);
+int pislam_pipeline_depth(const pislam_pipeline *pipe);
+int pislam_pipeline_set_option(pislam_pipeline *pipe, const char *key, int value);
+int pislam_pipeline_reserve(pislam_pipeline *pipe, const pislam_frontend_params *params, const pislam_level *levels,
+                            int batch);
+int pislam_pipeline_submit(pislam_pipeline *pipe, const pislam_frontend_params *params, const pislam_level *levels,
+                           const uint8_t *pyramids, size_t pyramid_stride, int batch, uint32_t *keypoints,
+                           uint32_t *descriptors, uint32_t *counts, void *input_stream, int order_after_input,
+                           uint64_t *ticket);
+int pislam_pipeline_wait(pislam_pipeline *pipe, uint64_t ticket, void *stream);
+int pislam_pipeline_synchronize(pislam_pipeline *pipe);
+void *pislam_pipeline_stream(pislam_pipeline *pipe, uint64_t ticket);
+pislam_ctx *pislam_pipeline_lane(pislam_pipeline *pipe, int lane);
+const char *pislam_pipeline_last_error(const pislam_pipeline *pipe);
+
 /* Measurement aid: the shader clock in GHz while the device is doing whatever else it is doing — one wave on the
  * context stream compares the shader cycle counter (s_memtime) with the constant 100 MHz counter
  * (s_memrealtime) over ~`micros` microseconds.  Synchronises.  bench.py prices the VALU issue rate with it. */

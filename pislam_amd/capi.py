@@ -63,6 +63,18 @@ SYMBOLS = {
     "pislam_frontend_last_timing": (_i, [_vp, ctypes.POINTER(ctypes.c_float),
                                          ctypes.POINTER(ctypes.c_float * 3)]),
     "pislam_frontend_last_stats": (_i, [_vp, ctypes.POINTER(ctypes.c_uint32 * 2)]),
+    "pislam_pipeline_create": (_i, [_i, _i, ctypes.POINTER(_vp)]),
+    "pislam_pipeline_destroy": (_i, [_vp]),
+    "pislam_pipeline_depth": (_i, [_vp]),
+    "pislam_pipeline_set_option": (_i, [_vp, ctypes.c_char_p, _i]),
+    "pislam_pipeline_reserve": (_i, [_vp, ctypes.POINTER(FrontendParams), ctypes.POINTER(Level), _i]),
+    "pislam_pipeline_submit": (_i, [_vp, ctypes.POINTER(FrontendParams), ctypes.POINTER(Level), _vp, _sz, _i, _vp, _vp, _vp,
+                                    _vp, _i, ctypes.POINTER(ctypes.c_uint64)]),
+    "pislam_pipeline_wait": (_i, [_vp, ctypes.c_uint64, _vp]),
+    "pislam_pipeline_synchronize": (_i, [_vp]),
+    "pislam_pipeline_stream": (_vp, [_vp, ctypes.c_uint64]),
+    "pislam_pipeline_lane": (_vp, [_vp, _i]),
+    "pislam_pipeline_last_error": (ctypes.c_char_p, [_vp]),
     "pislam_match_hamming": (_i, [_vp, _i, _vp, _sz, _vp, _sz, _vp, _vp, _vp]),
     "pislam_match_hamming_batch": (_i, [_vp, _i, _vp, _vp, _sz, _vp, _vp, _sz, _i, _vp, _vp, _vp]),
     "pislam_dist_shard": (_i, [_i, _i, _i, ctypes.POINTER(_i), ctypes.POINTER(_i)]),
@@ -243,6 +255,58 @@ class Context:
 
     def synchronize(self):
         self.check(self.lib.pislam_ctx_synchronize(self.h), "pislam_ctx_synchronize")
+
+
+class Pipeline:
+    """pislam_pipeline_*: `depth` contexts behind one object, batch k on lane k % depth (batches in flight)."""
+
+    def __init__(self, device: int = -1, depth: int = 3):
+        self.lib = load()
+        h = _vp()
+        rc = self.lib.pislam_pipeline_create(device, depth, ctypes.byref(h))
+        if rc != PISLAM_OK:
+            raise PislamError(f"pislam_pipeline_create failed ({rc})")
+        self.h, self.depth = h, depth
+
+    def check(self, rc: int, what: str):
+        if rc != PISLAM_OK:
+            msg = self.lib.pislam_pipeline_last_error(self.h)
+            raise PislamError(f"{what} failed ({rc}): {msg.decode() if msg else ''}")
+
+    def set_option(self, key: str, value: int):
+        self.check(self.lib.pislam_pipeline_set_option(self.h, key.encode(), int(value)), f"pipeline set_option({key})")
+
+    def reserve(self, params, levels, batch: int):
+        self.check(self.lib.pislam_pipeline_reserve(self.h, ctypes.byref(params), levels, batch), "pislam_pipeline_reserve")
+
+    def submit(self, params, levels, pyramids, kp, desc, counts, input_stream: int | None = None) -> int:
+        t = ctypes.c_uint64(0)
+        stride = int(pyramids.stride(0))
+        self.check(self.lib.pislam_pipeline_submit(self.h, ctypes.byref(params), levels, ptr(pyramids), stride,
+                                                   int(pyramids.shape[0]), ptr(kp), ptr(desc), ptr(counts),
+                                                   _vp(input_stream or 0), 0 if input_stream is None else 1,
+                                                   ctypes.byref(t)), "pislam_pipeline_submit")
+        return int(t.value)
+
+    def wait(self, ticket: int, stream: int):
+        self.check(self.lib.pislam_pipeline_wait(self.h, ticket, _vp(stream)), "pislam_pipeline_wait")
+
+    def stream_of(self, ticket: int) -> int:
+        return int(self.lib.pislam_pipeline_stream(self.h, ticket) or 0)
+
+    def synchronize(self):
+        self.check(self.lib.pislam_pipeline_synchronize(self.h), "pislam_pipeline_synchronize")
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.pislam_pipeline_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def brief_table() -> np.ndarray:

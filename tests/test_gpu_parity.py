@@ -934,3 +934,50 @@ def test_sub_batch_pipelining_inside_the_call_is_exact(gpu_ctx, orc, nsub):
             assert torch.equal(a, b)
         ctx.close()
 
+
+
+@pytest.mark.parametrize("depth", [1, 3])
+def test_pipeline_api_keeps_batches_in_flight_and_exact(orc, depth):
+    """pislam_pipeline_*: batch k on lane k % depth, ordered after the producer of its input (a copy enqueued on the
+    caller's stream right before the submit) and waited for per ticket; every batch equals the oracle."""
+    import torch
+    from pislam_amd import capi, synth
+    from pislam_amd.frontend import OrbFrontend
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    levels = synth.level_table(320, 240, 4)
+    rows = synth.pyramid_rows(levels)
+    dev = torch.device("cuda:0")
+    NB, B = 7, 3
+    host = [synth.make_batch(900 + 10 * k, B, w0=320, h0=240, nlevels=4, levels=levels, nshapes=30) for k in range(NB)]
+    fe = OrbFrontend(levels, vstep=320, rows=rows, max_keypoints=2048)          # (parameter / level structs only)
+    pipe = capi.Pipeline(device=0, depth=depth)
+    assert pipe.lib.pislam_pipeline_depth(pipe.h) == depth
+    pipe.reserve(fe.params, fe.levels, B)
+    prod = torch.cuda.Stream(dev)
+    cons = torch.cuda.Stream(dev)
+    d_in = [torch.empty((B, rows, 320), dtype=torch.uint8, device=dev) for _ in range(NB)]
+    outs = [fe.alloc_outputs(B, dev) for _ in range(NB)]
+    pinned = [torch.from_numpy(h).pin_memory() for h in host]
+    tickets = []
+    with torch.cuda.stream(prod):
+        for k in range(NB):
+            d_in[k].copy_(pinned[k], non_blocking=True)                        # the producer of batch k's input
+            tickets.append(pipe.submit(fe.params, fe.levels, d_in[k], *outs[k], input_stream=prod.cuda_stream))
+    assert tickets == list(range(NB))
+    assert len({pipe.stream_of(t) for t in tickets}) == min(depth, NB)
+    res = []
+    with torch.cuda.stream(cons):
+        for k in reversed(range(NB)):                                          # consumers wait per ticket, any order
+            pipe.wait(tickets[k], cons.cuda_stream)
+            res.append((k, [t.to("cpu", non_blocking=True) for t in outs[k]]))
+    cons.synchronize()
+    with pytest.raises(capi.PislamError):
+        pipe.wait(NB, cons.cuda_stream)
+    for k, (kp, desc, counts) in res:
+        c, kk, d = (t.numpy().view(np.uint32) for t in (counts, kp, desc))
+        for b in range(B):
+            okp, odesc, _ = orc.pyramid(host[k][b], levels)
+            assert c[b] == len(okp) and (kk[b, :len(okp)] == okp).all() and (d[b, :len(okp)] == odesc).all(), (k, b)
+    pipe.synchronize()
+    pipe.close()
