@@ -300,3 +300,106 @@ def test_synth_small_fixture_regression(synth_small, orc):
     assert (p == synth_small["img"]).all(), "synthetic generator changed"
     kp, desc, _ = orc.pyramid(p, lv)
     assert (kp == synth_small["kp"]).all() and (desc == synth_small["desc"]).all()
+
+
+def _neon_harris_numpy(P, threshold):
+    """harrisScoreSobel (reference Harris.h:80-248) restated at REGISTER level in numpy for N patches at once:
+    every NEON intrinsic the reference issues is spelled out on arrays of 8 byte lanes (vhsub_u8 / vhadd_s8 with
+    their widened floor-halving, the u64 lane shifts, vmull / vmlal wrapping in int16, the u16 / s16 pairwise
+    widening adds, the 'rubbish' high word left out by Harris.h:226-239, harrisEval's mod-2^32 arithmetic and the
+    float-bits byte).  Independent of oracle/pislam_oracle.c, which restates the same path in per-pixel scalar
+    arithmetic.  P: uint8 [N][8][8] = rows y-3..y+4, columns x-3..x+4."""
+    P = P.astype(np.int64)
+    N = len(P)
+
+    def s8(v):                     # reinterpret the low 8 bits as int8
+        v = v & 0xFF
+        return np.where(v >= 128, v - 256, v)
+
+    def vhsub_u8(a, b):            # (a - b) >> 1 on the widened difference, low 8 bits kept
+        return ((a - b) >> 1) & 0xFF
+
+    def vhadd_s8(a, b):            # (a + b) >> 1 on the widened sum of signed lanes
+        return s8((a + b) >> 1)
+
+    def shr_u64(v, lanes):         # vshr_n_u64 by 8 * lanes bits: lane j <- lane j + lanes, zeros shifted in
+        out = np.zeros_like(v)
+        out[:, :8 - lanes] = v[:, lanes:]
+        return out
+
+    row = [P[:, r, :] for r in range(8)]
+    dy = []
+    for n0 in range(6):            # PISLAM_HARRIS_DY_SOBEL(n0, n0+1, n0+2)
+        t1 = vhsub_u8(row[n0 + 2], row[n0])                 # bytes, then read as s8
+        t2 = s8(shr_u64(t1, 2))
+        d = s8(shr_u64(t1, 1))
+        t1 = vhadd_s8(s8(t1), t2)
+        dy.append(vhadd_s8(d, t1))
+    dx = [s8(vhsub_u8(shr_u64(row[n], 2), row[n])) for n in range(8)]     # PISLAM_HARRIS_DX_SOBEL_1
+    for n0 in range(6):            # PISLAM_HARRIS_DX_SOBEL_2(n0, n0+1, n0+2): overwrites dx[n0] only
+        dx[n0] = vhadd_s8(dx[n0], dx[n0 + 2])
+        dx[n0] = vhadd_s8(dx[n0], dx[n0 + 1])
+
+    def s16(v):
+        v = v & 0xFFFF
+        return np.where(v >= 32768, v - 65536, v)
+
+    xx32 = np.zeros((N, 4), np.int64)
+    yy32 = np.zeros((N, 4), np.int64)
+    xy32 = np.zeros((N, 4), np.int64)
+    for n in (0, 2, 4):
+        xx = s16(dx[n] * dx[n] + dx[n + 1] * dx[n + 1])      # vmull_s8 + vmlal_s8: int16 lanes wrap
+        yy = s16(dy[n] * dy[n] + dy[n + 1] * dy[n + 1])
+        xy = s16(dx[n] * dy[n] + dx[n + 1] * dy[n + 1])
+        ux, uy = xx & 0xFFFF, yy & 0xFFFF                    # vreinterpretq_u16_s16
+        xx32 = (xx32 + ux[:, 0::2] + ux[:, 1::2]) & 0xFFFFFFFF      # vpaddlq_u16 / vpadalq_u16
+        yy32 = (yy32 + uy[:, 0::2] + uy[:, 1::2]) & 0xFFFFFFFF
+        xy32 = xy32 + xy[:, 0::2] + xy[:, 1::2]                      # vpaddlq_s16 / vpadalq_s16 (no wrap possible: |.| < 2^18)
+    # vpaddl of the LOW register's two words, lane 0 of (that + the high register): words 0 + 1 + 2; word 3 holds
+    # the two rubbish columns and is never added
+    Ixx = ((xx32[:, 0] + xx32[:, 1] + xx32[:, 2]) & 0xFFFFFFFF) >> 4
+    Iyy = ((yy32[:, 0] + yy32[:, 1] + yy32[:, 2]) & 0xFFFFFFFF) >> 4
+    Ixy = (xy32[:, 0] + xy32[:, 1] + xy32[:, 2]) >> 4                # vshr_n_s32: arithmetic
+    M = 0xFFFFFFFF
+    tr = (Ixx + Iyy) & M
+    tr = ((tr * tr) & M) >> 4
+    det = ((Ixx * Iyy) & M)
+    det = (det - ((Ixy * Ixy) & M)) & M                      # vmls_s32 on the reinterpreted bits
+    score = (det - tr) & M
+    score = np.where(score >= (1 << 31), score - (1 << 32), score)   # vsub_s32
+    bits = score.astype(np.float32).view(np.uint32).astype(np.int64)  # vcvt_f32_s32 (round to nearest even)
+    return np.where(score > threshold, (bits >> 20) & 0xFF, 0).astype(np.uint8)
+
+
+def test_harris_against_a_register_level_numpy_restatement_of_the_neon_code(orc):
+    """>= 100 000 patches: uniform random, low-contrast, binary 0 / 255 (the saturating edge cases of the 8-bit
+    halving arithmetic and the 16-bit product lanes: Harris.h:188-203), checkerboards, steps — several thresholds."""
+    L = orc.lib()
+    rng = np.random.default_rng(2024)
+    parts = [rng.integers(0, 256, (60000, 8, 8), dtype=np.uint8),
+             rng.choice(np.array([0, 255], np.uint8), (30000, 8, 8)),
+             (128 + rng.integers(-12, 13, (10000, 8, 8))).astype(np.uint8),
+             rng.choice(np.array([0, 1, 254, 255], np.uint8), (10000, 8, 8))]
+    yy, xx = np.mgrid[0:8, 0:8]
+    special = [((yy + xx) % 2 * 255).astype(np.uint8), ((yy + xx + 1) % 2 * 255).astype(np.uint8),
+               ((xx >= 4) * 255).astype(np.uint8), ((yy >= 4) * 255).astype(np.uint8),
+               ((xx % 2) * 255).astype(np.uint8), ((yy % 2) * 255).astype(np.uint8),
+               np.zeros((8, 8), np.uint8), np.full((8, 8), 255, np.uint8),
+               (((yy >= 3) & (xx >= 3)) * 255).astype(np.uint8), (((yy // 2 + xx // 2) % 2) * 255).astype(np.uint8)]
+    P = np.concatenate(parts + [np.stack(special)])
+    assert len(P) >= 100000
+    # the oracle reads patches out of an image: lay the patches side by side, 16 rows x (8 N) columns of context
+    vstep = 8 * 512
+    for thr in (1 << 15, 0, -(1 << 31), 1 << 22):
+        want = _neon_harris_numpy(P, thr)
+        got = np.zeros(len(P), np.uint8)
+        for c0 in range(0, len(P), 512):
+            blk = P[c0:c0 + 512]
+            img = np.zeros((8, vstep), np.uint8)
+            img[:, :8 * len(blk)] = blk.transpose(1, 0, 2).reshape(8, -1)
+            for i in range(len(blk)):
+                got[c0 + i] = L.orc_harris_score_sobel(vstep, img.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)), 8 * i + 3, 3, thr)
+        bad = np.flatnonzero(got != want)
+        assert len(bad) == 0, (thr, bad[:5], got[bad[:5]], want[bad[:5]])
+        if thr == 1 << 15:
+            assert (want != 0).sum() > 10000            # the comparison is not vacuous
