@@ -707,6 +707,9 @@ def worker_main(args):
         dts = [float(x.item()) for x in allt]
         dt = max(dts)                                    # the contract: MAX over ranks
 
+    def local_kp_fn(c_):
+        return int(torch.clamp(c_.to(torch.int64), max=args.max_keypoints).sum().item())
+
     # ---- one batch call at a time (the figure a caller without any stream choreography gets) ----
     ev = []
     for _ in range(min(8, max(3, args.steps))):
@@ -732,6 +735,34 @@ def worker_main(args):
         one_ms = e0.elapsed_time(e1) / REPS
     except Exception:                                    # noqa: BLE001
         pass
+    # ---- the same batches-in-flight scheme as LIBRARY API (pislam_pipeline_*: what a C++ caller gets from one object,
+    # INTEGRATION.md): K batches submitted to a pipeline of 3 lanes, repeated calls replayed from hipGraphs inside ----
+    lib_pipe = None
+    if world == 1 and builder is None and m_out is None:
+        try:
+            from pislam_amd import capi
+            depth = 3
+            pl = capi.Pipeline(device=local_rank, depth=depth)
+            for k, v in extra_opts:
+                pl.set_option(k, v)
+            pl.reserve(fe.params, fe.levels, B)
+            pouts = [fe.alloc_outputs(B, dev) for _ in range(depth)]
+            for k in range(4 * depth):                    # first / second / third occurrence per lane: eager, capture, replay
+                pl.submit(fe.params, fe.levels, d_pyr, *pouts[k % depth])
+            pl.synchronize()
+            K = max(30, min(200, args.steps))
+            tp = time.perf_counter()
+            for k in range(K):
+                pl.submit(fe.params, fe.levels, d_pyr, *pouts[k % depth])
+            pl.synchronize()
+            tp = time.perf_counter() - tp
+            same = bool(torch.equal(pouts[0][2], counts))
+            lib_pipe = {"depth": depth, "ms_per_batch": tp / K * 1e3, "value": local_kp_fn(pouts[0][2]) * K / tp,
+                        "counts_equal_to_the_timed_path": same, "batches": K,
+                        "api": "pislam_pipeline_create / _submit / _synchronize (include/pislam_hip.h)"}
+            pl.close()
+        except Exception as e:                           # noqa: BLE001
+            lib_pipe = {"error": repr(e)}
     # dominant kernel alone: REP back-to-back launches inside one hipEvent bracket (a single eager launch is
     # bracketed together with ~10 us of command-processor latency)
     strip_ms = None
@@ -858,6 +889,7 @@ def worker_main(args):
                 "communicators_per_rank": 1 if (hub is not None or (world > 1 and not gloo_mode)) else 0,
                 "dist_fallbacks": fallbacks,
                 "library_options": dict(extra_opts),
+                "library_pipeline": lib_pipe,
                 "ms_per_step_ranks": {"min": min(dts) / args.steps * 1e3, "max": max(dts) / args.steps * 1e3,
                                       "rank0": dt_rank / args.steps * 1e3},
                 **({"pyramid_build": build_info} if build_info else {}),

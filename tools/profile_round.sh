@@ -1,27 +1,33 @@
 #!/bin/bash
-# usage (on the GPU box, from the repo root): bash tools/profile_round.sh <tag>   e.g. r02
-# Produces under gpurun_out/<tag>/ everything profiles/ keeps for a round: bench lines of the three workloads,
-# rocprofv3 --kernel-trace --stats of the same commands, HBM traffic (separate --pmc passes) and SQ counters.
-tag=${1:-r02}
+# usage (on the GPU box, from the repo root): bash tools/profile_round.sh <tag>   e.g. r03
+# Produces under gpurun_out/<tag>/ everything profiles/ keeps for a round — per workload the PMC counters
+# (separate --pmc passes: FETCH_SIZE | WRITE_SIZE | TCC | SQ), the bench lines (which quote those counters when the
+# kernel sources match), rocprofv3 --kernel-trace --stats of the same commands — and copies the counter JSONs to
+# profiles/ so that the bench lines of THIS run can already quote them.
+tag=${1:-r03}
 root=${GRAFT_REPO_ROOT:-$(pwd)}
 out=$root/gpurun_out/$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
-# HBM traffic first (separate --pmc passes), so that the bench lines below can report it: bench.py reads
-# profiles/<tag>_hbm_traffic.json and uses it only when its source_hash matches the kernels it runs
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $root/gpurun_out/${tag}hbm_fetch -o p -- python $root/bench.py --steps 3 --warmup 1 --streams 1 --no-cpu-baseline > /dev/null 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $root/gpurun_out/${tag}hbm_write -o p -- python $root/bench.py --steps 3 --warmup 1 --streams 1 --no-cpu-baseline > /dev/null 2>&1
-rocprofv3 --kernel-trace --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_HIT_sum TCC_MISS_sum --output-format csv -d $root/gpurun_out/${tag}hbm_tcc -o p -- python $root/bench.py --steps 3 --warmup 1 --streams 1 --no-cpu-baseline > /dev/null 2>&1
-rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VMEM_RD SQ_WAIT_INST_ANY --output-format csv -d $out/pmc_sq -o p -- python $root/bench.py --steps 2 --warmup 1 --streams 1 --no-cpu-baseline > /dev/null 2>&1
-cd $root
-python tools/hbm_traffic.py ${tag}hbm $out/hbm_traffic.json "round 2 kernels"
-cp $out/hbm_traffic.json $root/profiles/${tag}_hbm_traffic.json
+for w in vga 1280x960 720p-build; do
+  b=256; [ $w = 720p-build ] && b=64
+  args="--steps 3 --warmup 1 --streams 1 --graph 0 --no-cpu-baseline --spin-s 0.2 --workload $w --batch $b"
+  i=0
+  for pmc in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_BUSY_CYCLES"; do
+    rocprofv3 --kernel-trace --pmc $pmc --output-format csv -d $out/pmc_${w}_$i -o p -- python $root/bench.py $args > /dev/null 2>&1
+    i=$((i+1))
+  done
+  (cd $root && python tools/counters_json.py $out/counters_$w.json $w $b "bench.py $args" $out/pmc_${w}_0 $out/pmc_${w}_1 $out/pmc_${w}_2 $out/pmc_${w}_3)
+  cp $out/counters_$w.json $root/profiles/${tag}_counters_$w.json
+  rm -rf $out/pmc_${w}_*
+done
 cd /tmp
-python $root/bench.py --steps 20 --warmup 5 > $out/bench_vga.json 2> $out/bench_vga.err
-python $root/bench.py --steps 20 --warmup 5 --workload 1280x960 --batch 256 --cpu-seconds 5 > $out/bench_1280x960.json 2> $out/bench_1280x960.err
-python $root/bench.py --steps 20 --warmup 5 --workload 720p-build --batch 64 --cpu-seconds 5 > $out/bench_720p_build.json 2> $out/bench_720p_build.err
-python $root/bench.py --steps 20 --warmup 5 --streams 1 --no-cpu-baseline > $out/bench_vga_streams1.json 2> /dev/null
-python $root/bench.py --steps 20 --warmup 5 --log-bucket-size 4 --bucket-limit 3 --no-cpu-baseline > $out/bench_vga_buckets43.json 2> /dev/null
+python $root/bench.py --steps 50 --warmup 10 > $out/bench_vga.json 2> $out/bench_vga.err
+python $root/bench.py --steps 50 --warmup 10 --workload 1280x960 --batch 256 --cpu-seconds 5 > $out/bench_1280x960.json 2> $out/bench_1280x960.err
+python $root/bench.py --steps 50 --warmup 10 --workload 720p-build --batch 64 --cpu-seconds 5 > $out/bench_720p-build.json 2> $out/bench_720p-build.err
+python $root/bench.py --steps 50 --warmup 10 --streams 1 --no-cpu-baseline > $out/bench_vga_streams1.json 2> /dev/null
+python $root/bench.py --steps 50 --warmup 10 --log-bucket-size 4 --bucket-limit 3 --no-cpu-baseline > $out/bench_vga_buckets43.json 2> /dev/null
+python $root/bench.py --gpus 2 --dist-backend gloo --steps 20 --warmup 5 --batch 128 --no-cpu-baseline > $out/bench_vga_2ranks_one_gpu_gloo.json 2> $out/bench_2ranks.err
 for w in vga 1280x960 720p-build; do
   b=256; [ $w = 720p-build ] && b=64
   rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace_$w -o p -- python $root/bench.py --steps 20 --warmup 5 --no-cpu-baseline --workload $w --batch $b > $out/bench_under_rocprof_$w.json 2>/dev/null
@@ -31,10 +37,6 @@ for w in vga 1280x960 720p-build; do
   rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace1_$w -o p -- python $root/bench.py --steps 20 --warmup 5 --no-cpu-baseline --streams 1 --workload $w --batch $b > /dev/null 2>&1
   cp $out/trace1_$w/p_kernel_stats.csv $out/kernel_stats_${w}_streams1.csv
 done
-cd $root
-python tools/pmc_aggregate.py gpurun_out/${tag}hbm_fetch/p_counter_collection.csv $out/pmc_fetch_size.csv
-python tools/pmc_aggregate.py gpurun_out/${tag}hbm_write/p_counter_collection.csv $out/pmc_write_size.csv
-python tools/pmc_aggregate.py $out/pmc_sq/p_counter_collection.csv $out/pmc_sq_counters.csv
-cat $out/pmc_sq_counters.csv | cut -d, -f1-4
-rm -rf $out/trace_* $out/trace1_* $out/pmc_sq
+python $root/tools/probes/pipeline_api.py 1 2 3 > $out/pipeline_api.txt 2>/dev/null
+rm -rf $out/trace_* $out/trace1_*
 ls -la $out
