@@ -184,10 +184,10 @@ int run_dropin(bool buckets, const char *out_path, std::vector<uint32_t> *points
 }
 
 // the measured path from C++: device-resident batch, optional shard over `world` processes, `streams` batches in
-// flight (one context + HIP stream + output set + communicator per pipeline; step s runs on pipeline s % streams)
-struct Pipe {
-  pislam_ctx *ctx = nullptr;
-  hipStream_t stream = nullptr;
+// flight through ONE pislam_pipeline (lanes of contexts inside the library; repeated calls replayed from hipGraphs)
+// and ONE communicator per process (a context of its own; the all-gathers are ordered after / fence the lanes'
+// streams with pislam_dist_allgather_counts_on / pislam_dist_fence_on)
+struct OutSet {
   uint32_t *d_kp = nullptr, *d_desc = nullptr, *d_counts = nullptr, *d_all = nullptr;
 };
 
@@ -205,41 +205,39 @@ int run_batch(int batch, int steps, bool buckets, const char *out_path, int rank
   }
   const int device = rank % ndev;
   HIP_OK(hipSetDevice(device));
-  std::vector<Pipe> pipes((size_t)streams);
+  pislam_pipeline *pipe = nullptr;
+  if (pislam_pipeline_create(device, streams, &pipe) != PISLAM_OK) return 11;
+  pislam_ctx *comm = nullptr;                            // holds the communicator and the collective stream
+  if (pislam_ctx_create(device, &comm) != PISLAM_OK) return 11;
+  // ---- one process per GPU: ONE communicator from a unique id handed over through a file ----
   const bool need_id = world > 1 || rccl_single;
-  for (int k = 0; k < streams; k++) {
-    Pipe &p = pipes[(size_t)k];
-    if (pislam_ctx_create(device, &p.ctx) != PISLAM_OK) return 11;
-    HIP_OK(hipStreamCreateWithFlags(&p.stream, hipStreamNonBlocking));
-    PISLAM_OK_(p.ctx, pislam_ctx_set_stream(p.ctx, p.stream));
-    // ---- one process per GPU: communicator from a unique id handed over through a file (one per pipeline) ----
-    uint8_t id[PISLAM_DIST_ID_BYTES];
-    memset(id, 0, sizeof(id));
-    if (need_id) {
-      const std::string path = std::string(id_file) + "." + std::to_string(k);
-      if (rank == 0) {
-        if (pislam_dist_get_unique_id(id) != PISLAM_OK) {
-          fprintf(stderr, "pislam_dist_get_unique_id failed (RCCL not loadable?)\n");
-          return 13;
-        }
-        const std::string tmp = path + ".tmp";
-        FILE *f = fopen(tmp.c_str(), "wb");
-        if (!f || fwrite(id, 1, sizeof(id), f) != sizeof(id)) return 13;
-        fclose(f);
-        rename(tmp.c_str(), path.c_str());               // atomic: readers never see a partial id
-      } else {
-        FILE *f = nullptr;
-        for (int tries = 0; tries < 6000 && !(f = fopen(path.c_str(), "rb")); tries++) usleep(10000);
-        if (!f || fread(id, 1, sizeof(id), f) != sizeof(id)) {
-          fprintf(stderr, "rank %d: no unique id at %s\n", rank, path.c_str());
-          return 13;
-        }
-        fclose(f);
+  uint8_t id[PISLAM_DIST_ID_BYTES];
+  memset(id, 0, sizeof(id));
+  if (need_id) {
+    const std::string path = std::string(id_file) + ".0";
+    if (rank == 0) {
+      if (pislam_dist_get_unique_id(id) != PISLAM_OK) {
+        fprintf(stderr, "pislam_dist_get_unique_id failed (RCCL not loadable?)\n");
+        return 13;
       }
-      if (rccl_single) PISLAM_OK_(p.ctx, pislam_ctx_set_option(p.ctx, "dist_rccl_single", 1));
+      const std::string tmp = path + ".tmp";
+      FILE *f = fopen(tmp.c_str(), "wb");
+      if (!f || fwrite(id, 1, sizeof(id), f) != sizeof(id)) return 13;
+      fclose(f);
+      rename(tmp.c_str(), path.c_str());               // atomic: readers never see a partial id
+    } else {
+      FILE *f = nullptr;
+      for (int tries = 0; tries < 6000 && !(f = fopen(path.c_str(), "rb")); tries++) usleep(10000);
+      if (!f || fread(id, 1, sizeof(id), f) != sizeof(id)) {
+        fprintf(stderr, "rank %d: no unique id at %s\n", rank, path.c_str());
+        return 13;
+      }
+      fclose(f);
     }
-    PISLAM_OK_(p.ctx, pislam_dist_init(p.ctx, need_id ? id : nullptr, rank, world));
+    if (rccl_single) PISLAM_OK_(comm, pislam_ctx_set_option(comm, "dist_rccl_single", 1));
   }
+  PISLAM_OK_(comm, pislam_dist_init(comm, need_id ? id : nullptr, rank, world));
+  const int rccl_ranks = pislam_dist_comm_count(comm);   // what RCCL itself reports (0: no communicator)
 
   // ---- this rank's shard of the world * batch pyramids (all copies of the one input here) ----
   int first = 0, count = 0;
@@ -255,68 +253,79 @@ int run_batch(int batch, int steps, bool buckets, const char *out_path, int rank
   uint8_t *d_pyr = nullptr;
   HIP_OK(hipMalloc(&d_pyr, pyr_bytes * count));
   for (int b = 0; b < count; b++) HIP_OK(hipMemcpy(d_pyr + b * pyr_bytes, img, pyr_bytes, hipMemcpyHostToDevice));
-  for (Pipe &p : pipes) {
-    HIP_OK(hipMalloc(&p.d_kp, sizeof(uint32_t) * (size_t)P.max_keypoints * count));
-    HIP_OK(hipMalloc(&p.d_desc, sizeof(uint32_t) * (size_t)P.max_keypoints * P.words * count));
-    HIP_OK(hipMalloc(&p.d_counts, sizeof(uint32_t) * count));
-    HIP_OK(hipMalloc(&p.d_all, sizeof(uint32_t) * (size_t)count * world));
-    PISLAM_OK_(p.ctx, pislam_frontend_reserve(p.ctx, &P, lv, count));
-    PISLAM_OK_(p.ctx, pislam_orb_frontend_batch(p.ctx, &P, lv, d_pyr, pyr_bytes, count, p.d_kp, p.d_desc, p.d_counts));   // warm-up
-    HIP_OK(hipStreamSynchronize(p.stream));
+  std::vector<OutSet> sets((size_t)streams);            // one output set per lane
+  for (OutSet &o : sets) {
+    HIP_OK(hipMalloc(&o.d_kp, sizeof(uint32_t) * (size_t)P.max_keypoints * count));
+    HIP_OK(hipMalloc(&o.d_desc, sizeof(uint32_t) * (size_t)P.max_keypoints * P.words * count));
+    HIP_OK(hipMalloc(&o.d_counts, sizeof(uint32_t) * count));
+    HIP_OK(hipMalloc(&o.d_all, sizeof(uint32_t) * (size_t)count * world));
   }
+  if (pislam_pipeline_reserve(pipe, &P, lv, count) != PISLAM_OK) {
+    fprintf(stderr, "pislam_pipeline_reserve: %s\n", pislam_pipeline_last_error(pipe));
+    return 15;
+  }
+  auto submit = [&](int s) -> int {
+    OutSet &o = sets[(size_t)(s % streams)];
+    uint64_t t = 0;
+    // the lane's stream is in order, so its previous batch is behind it; the all-gather that READ this output set
+    // (`streams` exchanges ago) must be done before the batch overwrites it
+    void *lane_stream = pislam_pipeline_stream(pipe, (uint64_t)s);       // (lane s % streams)
+    if (pislam_dist_fence_on(comm, streams, lane_stream) != PISLAM_OK) return 1;
+    if (pislam_pipeline_submit(pipe, &P, lv, d_pyr, pyr_bytes, count, o.d_kp, o.d_desc, o.d_counts, nullptr, 0, &t) != PISLAM_OK) {
+      fprintf(stderr, "pislam_pipeline_submit: %s\n", pislam_pipeline_last_error(pipe));
+      return 1;
+    }
+    return pislam_dist_allgather_counts_on(comm, pislam_pipeline_stream(pipe, t), o.d_counts, (size_t)count, o.d_all) != PISLAM_OK;
+  };
+  for (int s = 0; s < 3 * streams; s++)                  // warm-up: eager, capture, first replay on every lane
+    if (submit(s)) return 15;
+  if (pislam_pipeline_synchronize(pipe) != PISLAM_OK) return 15;
+  PISLAM_OK_(comm, pislam_dist_synchronize(comm));
 
-  pislam_ctx *ctx = pipes[0].ctx;
   double barrier = 0;
-  PISLAM_OK_(ctx, pislam_dist_allreduce_max(ctx, &barrier));        // all ranks start together
+  PISLAM_OK_(comm, pislam_dist_allreduce_max(comm, &barrier));      // all ranks start together
   const double t0 = now_ms();
-  for (int s = 0; s < steps; s++) {
-    Pipe &p = pipes[(size_t)(s % streams)];
-    PISLAM_OK_(p.ctx, pislam_dist_fence(p.ctx, 1));                  // one output set per pipeline: wait for its previous all-gather
-    PISLAM_OK_(p.ctx, pislam_orb_frontend_batch(p.ctx, &P, lv, d_pyr, pyr_bytes, count, p.d_kp, p.d_desc, p.d_counts));
-    PISLAM_OK_(p.ctx, pislam_dist_allgather_counts(p.ctx, p.d_counts, (size_t)count, p.d_all));
-  }
-  for (Pipe &p : pipes) {
-    HIP_OK(hipStreamSynchronize(p.stream));
-    PISLAM_OK_(p.ctx, pislam_dist_synchronize(p.ctx));
-  }
+  for (int s = 0; s < steps; s++)
+    if (submit(3 * streams + s)) return 15;
+  if (pislam_pipeline_synchronize(pipe) != PISLAM_OK) return 15;
+  PISLAM_OK_(comm, pislam_dist_synchronize(comm));
   double dt = now_ms() - t0;
-  PISLAM_OK_(ctx, pislam_dist_allreduce_max(ctx, &dt));             // the slowest rank
+  PISLAM_OK_(comm, pislam_dist_allreduce_max(comm, &dt));           // the slowest rank
 
-  float total_ms = 0, stage_ms[3] = {0, 0, 0};
-  PISLAM_OK_(ctx, pislam_frontend_last_timing(ctx, &total_ms, stage_ms));
   std::vector<uint32_t> all((size_t)count * world);
-  HIP_OK(hipMemcpy(all.data(), pipes[0].d_all, all.size() * 4, hipMemcpyDeviceToHost));
+  HIP_OK(hipMemcpy(all.data(), sets[0].d_all, all.size() * 4, hipMemcpyDeviceToHost));
   unsigned long long total = 0;
   for (uint32_t c : all) total += c < (uint32_t)P.max_keypoints ? c : (uint32_t)P.max_keypoints;
   int bad = 0;
-  for (size_t k = 1; k < pipes.size() && steps >= streams; k++) {   // every pipeline gathered the same counts
+  for (size_t k = 1; k < sets.size(); k++) {            // every lane gathered the same counts
     std::vector<uint32_t> other(all.size());
-    HIP_OK(hipMemcpy(other.data(), pipes[k].d_all, other.size() * 4, hipMemcpyDeviceToHost));
+    HIP_OK(hipMemcpy(other.data(), sets[k].d_all, other.size() * 4, hipMemcpyDeviceToHost));
     bad += other != all;
   }
   if (rank == 0) {
-    printf("GPU  Time: %.3f ms per batch of %d x %d pyramids, %d in flight  (device stages of the last call: detect+score+nms %.3f, "
-           "overflow pass %.3f, gather+orb %.3f ms; %d ranks, count all-gather: %s)\n",
-           dt / steps, world, count, streams, stage_ms[0], stage_ms[1], stage_ms[2], world,
-           (world > 1 || rccl_single) ? "ncclAllGather via pislam_dist_allgather_counts" : "single GPU");
+    printf("GPU  Time: %.3f ms per batch of %d x %d pyramids, %d in flight (pislam_pipeline); %d ranks, count all-gather: %s, "
+           "RCCL reports %d ranks\n",
+           dt / steps, world, count, streams, world,
+           (world > 1 || rccl_single) ? "ncclAllGather via pislam_dist_allgather_counts_on, one communicator" : "single GPU",
+           rccl_ranks);
     printf("%llu features in %d pyramids (%u per pyramid), %.3e features/s\n", total, world * count, all[0],
            (double)total * steps / (dt * 1e-3));
-    if (out_path) {                                      // pyramid 0 of rank 0 (of the last pipeline that ran)
-      const Pipe &p = pipes[(size_t)((steps - 1) % streams)];
+    if (out_path) {                                      // pyramid 0 of rank 0
+      const OutSet &o = sets[0];
       const uint32_t n = all[0] < (uint32_t)P.max_keypoints ? all[0] : (uint32_t)P.max_keypoints;
       std::vector<uint32_t> kp(n), desc((size_t)n * P.words);
-      HIP_OK(hipMemcpy(kp.data(), p.d_kp, n * 4, hipMemcpyDeviceToHost));
-      HIP_OK(hipMemcpy(desc.data(), p.d_desc, desc.size() * 4, hipMemcpyDeviceToHost));
+      HIP_OK(hipMemcpy(kp.data(), o.d_kp, n * 4, hipMemcpyDeviceToHost));
+      HIP_OK(hipMemcpy(desc.data(), o.d_desc, desc.size() * 4, hipMemcpyDeviceToHost));
       write_result(out_path, kp, desc);
     }
   }
   // every pyramid is the same image here, so every gathered count must be equal — on every rank
   for (uint32_t c : all) bad += c != all[0];
-  for (Pipe &p : pipes) {
-    pislam_dist_finalize(p.ctx);
-    pislam_ctx_destroy(p.ctx);
-    (void)hipFree(p.d_kp); (void)hipFree(p.d_desc); (void)hipFree(p.d_counts); (void)hipFree(p.d_all);
-    (void)hipStreamDestroy(p.stream);
+  pislam_dist_finalize(comm);
+  pislam_ctx_destroy(comm);
+  pislam_pipeline_destroy(pipe);
+  for (OutSet &o : sets) {
+    (void)hipFree(o.d_kp); (void)hipFree(o.d_desc); (void)hipFree(o.d_counts); (void)hipFree(o.d_all);
   }
   (void)hipFree(d_pyr);
   return bad ? 14 : 0;
@@ -332,7 +341,7 @@ int main(int argc, char **argv) {
   }
   bool buckets = false, rccl_single = false;
   const char *out_path = nullptr, *paint_path = nullptr;
-  int batch = 0, steps = 10, world = 1, threads = 1, streams = 1;
+  int batch = 0, steps = 10, world = 1, threads = 1, streams = 3;
   for (int i = 2; i < argc; i++) {
     if (!strcmp(argv[i], "--buckets")) buckets = true;
     else if (!strcmp(argv[i], "--rccl-single")) rccl_single = true;

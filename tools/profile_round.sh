@@ -40,3 +40,10 @@ done
 python $root/tools/probes/pipeline_api.py 1 2 3 > $out/pipeline_api.txt 2>/dev/null
 rm -rf $out/trace_* $out/trace1_*
 ls -la $out
+# the C++ host (no Python / torch in the process) on the reference's demo pyramid x 256: pislam_pipeline, 3 and 1 lanes
+python - <<P
+import numpy as np
+z = np.load("$root/tests/golden/demo_pyramid.npz")
+z["img"].astype(np.uint8).tofile("/tmp/demo_pyramid.raw")
+P
+(cd $root && make -s -C tools pislam_demo > /dev/null 2>&1; for s in 3 1; do tools/pislam_demo /tmp/demo_pyramid.raw --batch 256 --steps 100 --streams $s; done) > $out/cpp_tool_demo_photo_x256.txt 2>&1
