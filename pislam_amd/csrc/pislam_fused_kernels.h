@@ -113,6 +113,16 @@ __device__ __forceinline__ void lds_barrier() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 
+// ONE lane's LDS atomic add with return as ONE instruction.  A source-level atomicAdd inside `if (lane == 0)` is
+// wrapped by hipcc's atomic optimiser in a wave reduction of its own (2 v_mbcnt, compare, multiply-add, two moves:
+// 7 VALU for an add that a single lane executes) — once per FAST batch and per NMS batch.
+__device__ __forceinline__ uint32_t lds_add_rtn(uint32_t *p, uint32_t v) {
+  uint32_t old;
+  const uint32_t a = (uint32_t)(uintptr_t)(lds_u32 *)p;
+  asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=v"(old) : "v"(a), "v"(v) : "memory");
+  return old;
+}
+
 constexpr int PF_MAX = 4;              // 16-byte vectors a thread can hold for the next strip's prefetch
 
 // candidate coordinates packed as x | (tile_row << 16)
@@ -456,7 +466,7 @@ __device__ __forceinline__ void strip_body(const StripArgs A, const FusedLevel L
     if (m) {
       const int cnt = __popcll(m);
       int base = 0;
-      if (lane == 0) base = (int)atomicAdd(&sh_ctr[2], (uint32_t)cnt);
+      if (lane == 0) base = (int)lds_add_rtn(&sh_ctr[2], (uint32_t)cnt);
       base = __builtin_amdgcn_readfirstlane(base);
       if (base + cnt <= QN_SHARED) {
         if (nz) shq_n[base + ballot_rank(m)] = e;
@@ -498,7 +508,7 @@ __device__ __forceinline__ void strip_body(const StripArgs A, const FusedLevel L
     if (m) {
       const int cnt = __popcll(m);
       int base = 0;
-      if (lane == 0) base = (int)atomicAdd(&sh_ctr[0], (uint32_t)cnt);
+      if (lane == 0) base = (int)lds_add_rtn(&sh_ctr[0], (uint32_t)cnt);
       base = __builtin_amdgcn_readfirstlane(base);
       if (base + cnt <= qcap) {
         if (q) shq_h[base + ballot_rank(m)] = (ALIAS && !toh) ? e | 0xff000000u : e;
@@ -819,7 +829,7 @@ __device__ __forceinline__ void strip_body(const StripArgs A, const FusedLevel L
       if (m) {
         const int cnt = __popcll(m);
         int base = 0;
-        if (lane == 0) base = (int)atomicAdd(&sh_ctr[4], (uint32_t)cnt);
+        if (lane == 0) base = (int)lds_add_rtn(&sh_ctr[4], (uint32_t)cnt);
         base = __builtin_amdgcn_readfirstlane(base);
         if (base + cnt <= QS_SHARED) {
           if (res) {

@@ -135,3 +135,41 @@ int run(int rank, int world, int local_device, void *my_stream, const pislam_fro
     assert r.returncode == 0, r.stderr
     r = subprocess.run(["make", "-C", os.path.join(ROOT, "tools"), "pislam_demo"], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
+
+
+def test_pipeline_binding_of_integration_md_compiles(tmp_path):
+    """The batches-in-flight loop of INTEGRATION.md (pislam_pipeline_*: create, reserve, submit ordered after the
+    producer stream, wait per ticket, one communicator for all lanes through the *_on entry points) compiles as C
+    and as C++ against include/pislam_hip.h with a plain host compiler."""
+    body = r'''
+#include "pislam_hip.h"
+int run(int device, void *my_stream, const pislam_frontend_params *p, const pislam_level *lv, const uint8_t *const *d_pyr,
+        size_t stride, int batch, uint32_t *d_kp[3], uint32_t *d_desc[3], uint32_t *d_counts[3], uint32_t *d_all[3],
+        pislam_ctx *comm, int nbatches) {
+  pislam_pipeline *pipe = 0;
+  uint64_t t[3] = {0, 0, 0};
+  int k;
+  if (pislam_pipeline_create(device, 3, &pipe) != PISLAM_OK) return 1;
+  if (pislam_pipeline_set_option(pipe, "graphs", 1) != PISLAM_OK) return 2;
+  if (pislam_pipeline_reserve(pipe, p, lv, batch) != PISLAM_OK) return 3;
+  for (k = 0; k < nbatches; k++) {
+    if (k >= 3) pislam_pipeline_wait(pipe, t[k % 3], my_stream);          /* the consumer of the batch three back */
+    if (comm) pislam_dist_fence_on(comm, 3, pislam_pipeline_stream(pipe, (uint64_t)k));
+    if (pislam_pipeline_submit(pipe, p, lv, d_pyr[k], stride, batch, d_kp[k % 3], d_desc[k % 3], d_counts[k % 3], my_stream, 1,
+                               &t[k % 3]) != PISLAM_OK)
+      return 4 + (pislam_pipeline_last_error(pipe) != 0);
+    if (comm)
+      pislam_dist_allgather_counts_on(comm, pislam_pipeline_stream(pipe, t[k % 3]), d_counts[k % 3], (size_t)batch, d_all[k % 3]);
+  }
+  pislam_pipeline_synchronize(pipe);
+  k = pislam_pipeline_depth(pipe) == 3 && pislam_pipeline_lane(pipe, 0) != 0 && (!comm || pislam_dist_comm_count(comm) >= 0);
+  pislam_pipeline_destroy(pipe);
+  return k ? 0 : 9;
+}
+'''
+    for name, cc, std in (("pipe_usage.c", "gcc", "-std=c99"), ("pipe_usage.cpp", "g++", "-std=c++11")):
+        src = tmp_path / name
+        src.write_text(body)
+        r = subprocess.run([cc, std, "-fsyntax-only", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(src)],
+                           capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
