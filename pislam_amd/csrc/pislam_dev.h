@@ -92,10 +92,23 @@ __device__ __forceinline__ bool fast9_mm(const P *c, int pitch, int thr) {
     tb[j >> 1] = __builtin_amdgcn_udot4(gb & 0x80808080u, wt, tb[j >> 1], false);
     td[j >> 1] = __builtin_amdgcn_udot4(~nd & 0x80808080u, wt, td[j >> 1], false);
   }
-  uint32_t bm = (tb[0] >> 7) | (tb[1] << 1);
-  const uint32_t dm = (td[0] >> 7) | (td[1] << 1);
-  if (hi1 > 255) bm = 0;
-  return has_arc9(dm) || has_arc9(bm);
+  // Both 16-bit ring masks in ONE dword (dark low, bright high) and the 9-run test on both halves at once with
+  // packed 16-bit shifts: a rotation inside each half is v_pk_lshrrev_b16 | v_pk_lshlrev_b16, the rotation by 8 a
+  // byte swap (v_perm_b32).  Same decision as has_arc9(dm) || has_arc9(bm) — whose `||` hipcc turned into a branch
+  // around the second side that is taken by nearly every batch — in 12 instead of 24 VALU.
+  typedef unsigned short us2_t __attribute__((ext_vector_type(2)));
+  uint32_t pm = (td[0] >> 7) | (td[1] << 1) | (tb[0] << 9) | (tb[1] << 17);
+  pm = hi1 > 255 ? (pm & 0xffffu) : pm;
+  auto rotr16x2 = [](uint32_t x, int k) -> uint32_t {
+    const us2_t v = __builtin_bit_cast(us2_t, x);
+    const us2_t a = v >> (us2_t)((unsigned short)k), b = v << (us2_t)((unsigned short)(16 - k));
+    return __builtin_bit_cast(uint32_t, a) | __builtin_bit_cast(uint32_t, b);
+  };
+  uint32_t r = pm & rotr16x2(pm, 1);                             // runs of 2 (circular, per half)
+  r &= rotr16x2(r, 2);                                           // runs of 4
+  r &= rotr16x2(r, 4);                                           // runs of 8
+  r &= __builtin_amdgcn_perm(0u, pm, 0x02030001u);               // runs of 9: the mask rotated by 8 = bytes swapped per half
+  return r != 0;
 }
 
 // ---------------------------------------------------------------------------

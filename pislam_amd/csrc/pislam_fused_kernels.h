@@ -531,12 +531,12 @@ __device__ __forceinline__ void strip_body(const StripArgs A, const FusedLevel L
   // exact compass pretest of the 4 pixels of one group (x0 % 4 == 0), survivors -> qf
   auto pretest_batch = [&](bool valid, uint32_t key) {
     const int x0 = key & 0xffff, r = key >> 16;
-    const lds_u8 *trow = tile + (r + 3) * tpitch;
-    const uint32_t wc = *(const lds_u32 *)(trow + x0);
-    const uint32_t wl = *(const lds_u32 *)(trow + x0 - 4);
-    const uint32_t wr = *(const lds_u32 *)(trow + x0 + 4);
-    const uint32_t wu = *(const lds_u32 *)(trow + x0 - 3 * tpitch);
-    const uint32_t wd = *(const lds_u32 *)(trow + x0 + 3 * tpitch);
+    const lds_u8 *pb = tile + (r + 3) * tpitch + x0 - 4;     // (left neighbour first: DS offsets are unsigned)
+    const uint32_t wl = *(const lds_u32 *)pb;
+    const uint32_t wc = *(const lds_u32 *)(pb + 4);
+    const uint32_t wr = *(const lds_u32 *)(pb + 8);
+    const uint32_t wu = *(const lds_u32 *)(pb + 4 - 3 * tpitch);
+    const uint32_t wd = *(const lds_u32 *)(pb + 4 + 3 * tpitch);
     // even pixels (x0, x0+2) and odd pixels (x0+1, x0+3), zero-extended to 16 bit by v_perm_b32
     uint32_t be, de, bo, dd;
     pretest_pk(__builtin_amdgcn_perm(0, wc, 0x0c020c00u), __builtin_amdgcn_perm(0, wu, 0x0c020c00u),
@@ -689,11 +689,13 @@ __device__ __forceinline__ void strip_body(const StripArgs A, const FusedLevel L
     const bool tail_lane = lrow < tm && 4 * lcol < rem;
     const int tail_ofs = lrow * tpitch + 4 * lcol;
     const uint32_t tail_key = ((uint32_t)lrow << 16) + (uint32_t)(4 * lcol);
-    auto prefilter_step = [&](const lds_u8 *pc, const lds_u8 *pu, const lds_u8 *pd, bool lane_ok, uint32_t key) {
+    // `pm` = the group's centre dword MINUS 4 bytes: the three dwords of the row are then pm + 0 / 4 / 8 — DS offsets
+    // are unsigned, a loop pointer at the centre costs a v_add for the left neighbour in every step
+    auto prefilter_step = [&](const lds_u8 *pm, const lds_u8 *pu, const lds_u8 *pd, bool lane_ok, uint32_t key) {
       // aligned dword reads; lanes past the tile's columns read harmless bytes of the next tile row
-      const uint32_t wc = *(const lds_u32 *)pc;
-      const uint32_t wl = *(const lds_u32 *)(pc - 4);
-      const uint32_t wr = *(const lds_u32 *)(pc + 4);
+      const uint32_t wl = *(const lds_u32 *)pm;
+      const uint32_t wc = *(const lds_u32 *)(pm + 4);
+      const uint32_t wr = *(const lds_u32 *)(pm + 8);
       const uint32_t wu = *(const lds_u32 *)pu;
       const uint32_t wd = *(const lds_u32 *)pd;
       const uint32_t sv = max(__builtin_amdgcn_sad_u8(wu, wc, 0u), __builtin_amdgcn_sad_u8(wd, wc, 0u));
@@ -714,12 +716,12 @@ __device__ __forceinline__ void strip_body(const StripArgs A, const FusedLevel L
     //  4859 -> 6481 instructions for 3 VALU per step.)
     if (nfull > 0)
       for (int r = r_lo + wave; r < r_hi; r += WAVES) {
-        const lds_u8 *pc = tile + (r + 3) * tpitch + xs + 4 * lane;
-        const lds_u8 *pu = pc - 3 * tpitch, *pd = pc + 3 * tpitch;
+        const lds_u8 *pm = tile + (r + 3) * tpitch + xs + 4 * lane - 4;
+        const lds_u8 *pu = pm + 4 - 3 * tpitch, *pd = pm + 4 + 3 * tpitch;
         uint32_t key = pack_xy(xs, r) + (uint32_t)(4 * lane);    // column of this lane's group | row << 16
         for (int it = 0; it < nfull; it++) {
-          prefilter_step(pc, pu, pd, true, key);
-          pc += 256;
+          prefilter_step(pm, pu, pd, true, key);
+          pm += 256;
           pu += 256;
           pd += 256;
           key += 256;
@@ -730,7 +732,7 @@ __device__ __forceinline__ void strip_body(const StripArgs A, const FusedLevel L
       for (int r = r_lo + wave * tm; r < r_hi; r += WAVES * tm) {
         const bool ok = tail_lane && lrow < r_hi - r;
         const lds_u8 *pc = tile + (r + 3) * tpitch + xt0 + (ok ? tail_ofs : 0);
-        prefilter_step(pc, pc - 3 * tpitch, pc + 3 * tpitch, ok, pack_xy(xt0, r) + tail_key);
+        prefilter_step(pc - 4, pc - 3 * tpitch, pc + 3 * tpitch, ok, pack_xy(xt0, r) + tail_key);
       }
     }
     if (ng > 0 && !(ablate & 16)) pretest_batch(lane < ng, lane < ng ? qg[lane] : pack_xy(xs, r_lo));
