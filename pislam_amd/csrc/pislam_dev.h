@@ -367,6 +367,39 @@ __device__ __forceinline__ uint32_t angle_bin_with(int32_t x, int32_t y, RECIP r
   if (!(0 <= angle && angle < 30)) angle = 0;                  // Orb.h:377-380
   return (uint32_t)angle;
 }
+// The same function with the integers doing what they can (Orb.h:318-380; results identical for every int32 pair):
+//  * |float(x)| = float(|x|) (round-to-nearest-even is symmetric) and the int -> float conversion is monotone, so
+//    zmax / zmin are the conversions of max / min of the ABSOLUTE INTEGERS — no float max / min (hipcc canonicalises
+//    their operands with an extra instruction each), and |x| > |y| is the swap test anyway;
+//  * vrecpe's argument is then a non-negative float with an exponent field of 0 (zero) or 127..158: of the ARM ARM
+//    special cases only "zero -> +infinity" can occur;
+//  * the octant logic as selects: negate iff [(x ^ y) < 0] == [|x| > |y|].
+// `tab`: the 8-bit estimate table (VrecpeTab::v), in LDS or global memory.
+template <class TAB>
+__device__ __forceinline__ uint32_t angle_bin_fast(int32_t x, int32_t y, const TAB *tab) {
+  const uint32_t ax = x < 0 ? 0u - (uint32_t)x : (uint32_t)x;
+  const uint32_t ay = y < 0 ? 0u - (uint32_t)y : (uint32_t)y;
+  const bool swap = ax > ay;
+  const uint32_t imax = max(ax, ay), imin = min(ax, ay);
+  const float zmax = (float)imax, zmin = (float)imin;          // v_cvt_f32_u32 (RNE), Orb.h:318-325
+  const uint32_t u = __float_as_uint(zmax);
+  uint32_t r = ((253u - (u >> 23)) << 23) | ((uint32_t)tab[(u >> 15) & 0xffu] << 15);   // FPRecipEstimate, Orb.h:329
+  r = imax == 0 ? 0x7f800000u : r;
+  const float z = __fmul_rn(zmin, __uint_as_float(r));         // Orb.h:327-329
+  const float c0 = (float)(256 * 14.999998);                   // Orb.h:336
+  const float c1 = (float)(256 * 4.723436);                    // Orb.h:343
+  const float c2 = (float)(256 * 1.266240);                    // Orb.h:344
+  const float t1 = __fadd_rn(c1, __fmul_rn(c2, z));
+  const float t3 = __fmul_rn(__fsub_rn(z, 1.0f), t1);
+  const float af = __fmul_rn(z, __fsub_rn(c0, t3));            // Orb.h:345
+  int32_t angle;
+  asm("v_cvt_i32_f32 %0, %1" : "=v"(angle) : "v"(af));        // vcvt.s32.f32 (Orb.h:348): truncates, saturates, NaN -> 0
+  const bool opp = (x ^ y) < 0;
+  angle = (opp == swap) ? -angle : angle;                      // Orb.h:355-374
+  const int32_t add = swap ? (x < 0 ? 256 * 60 : (angle < 0 ? 256 * 120 : 0)) : (y >= 0 ? 256 * 30 : 256 * 90);
+  angle = (angle + add) >> 10;                                 // Orb.h:376
+  return (0 <= angle && angle < 30) ? (uint32_t)angle : 0u;    // Orb.h:377-380
+}
 __device__ __forceinline__ uint32_t angle_bin(int32_t x, int32_t y) {
   return angle_bin_with(x, y, [](float f) { return vrecpe_f32(f); });
 }

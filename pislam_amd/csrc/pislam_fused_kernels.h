@@ -306,7 +306,7 @@ __device__ __forceinline__ void orb_describe(const OrbLane &G, const OrbWin &cur
   for (int k = 4; k < 8; k++) right = __builtin_amdgcn_udot4(row[k], G.mdx[k], right, false);      // dx 1 .. 15 (16 masked)
   const int m10 = half_sum((int)right - (int)left, half);
   const int m01 = half_sum((r - 15) * (int)sv, half);
-  const uint32_t rot = angle_bin_with(m10, m01, [&](float f) { return vrecpe_f32_tab(f, rtab); });
+  const uint32_t rot = angle_bin_fast(m10, m01, rtab);
   // BRIEF: pair k = 32*round + r of this half's keypoint -> bit r of word `round`
   const uint32_t *tab = ::g_brief_ofs.v + rot * 256 + r;   // defined by the including TU
   // the patch's byte (dy,dx) sits at orb_row_ofs(dy+15) + sh + dx+15 (the table holds the first and last term); sh is
@@ -556,14 +556,16 @@ __device__ __forceinline__ void strip_body(const StripArgs A, const FusedLevel L
       if (x0 + 3 < cxa || x0 + 3 >= cxb) fo &= ~0x80000000u;
     }
     if (__ballot((fe | fo) != 0) == 0) return;
-    const uint64_t m0 = __ballot((fe & 0x8000u) != 0), m1 = __ballot((fo & 0x8000u) != 0);
+    // (bit 15 as the sign of the low half: one 16-bit compare instead of mask + compare)
+    const bool e0 = (int16_t)(uint16_t)fe < 0, o0 = (int16_t)(uint16_t)fo < 0;
+    const uint64_t m0 = __ballot(e0), m1 = __ballot(o0);
     const uint64_t m2 = __ballot((int32_t)fe < 0), m3 = __ballot((int32_t)fo < 0);
     // two half-pushes (<= 128 each) with a pop in between keep the queue below 64 + 128 entries
     {
       lds_u32 *q = qf + nf;
-      if (fe & 0x8000u) q[ballot_rank(m0)] = key;
+      if (e0) q[ballot_rank(m0)] = key;
       q += __popcll(m0);
-      if (fo & 0x8000u) q[ballot_rank(m1)] = key + 1;
+      if (o0) q[ballot_rank(m1)] = key + 1;
       nf += __popcll(m0) + __popcll(m1);
     }
     while (nf >= 64) {

@@ -280,7 +280,7 @@ __global__ __launch_bounds__(256) void k_orb(
       }
       return;
     }
-    rot = angle_bin(m10, m01);
+    rot = angle_bin_fast(m10, m01, ::g_vrecpe_tab.v);
   } else {
     rot = rots[i];
     if (rot >= 30) return;   // Brief.h:641-732: switch without default writes nothing
@@ -306,7 +306,7 @@ __global__ void k_angles(const int32_t *__restrict__ xys, int nslots, uint8_t *_
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= nslots) return;
   const int g = i >> 2, s = i & 3;
-  ang[i] = (uint8_t)angle_bin(xys[8 * g + s], xys[8 * g + 4 + s]);
+  ang[i] = (uint8_t)angle_bin_fast(xys[8 * g + s], xys[8 * g + 4 + s], ::g_vrecpe_tab.v);
 }
 
 }  // namespace pk

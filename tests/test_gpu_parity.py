@@ -254,6 +254,18 @@ def test_harris_and_angle_primitives(gpu_ctx, orc, demo):
     ys = np.pad(ys, (0, n - len(ys))).astype(np.int32)
     grouped = np.stack([xs.reshape(-1, 4), ys.reshape(-1, 4)], axis=1).reshape(-1)
     assert (fe.atan2(grouped, ctx=gpu_ctx) == orc.atan2_bins(grouped)).all()
+    # the whole int32 domain of the public helper (pislam::atan2 takes any vector<int32_t>): extremes, powers of two
+    # and their neighbours (float rounding boundaries of the int -> float conversion), random full-range pairs
+    edge = np.array([0, 1, -1, 2, 3, 255, 256, 257, (1 << 24) - 1, 1 << 24, (1 << 24) + 1, (1 << 24) + 2, (1 << 25) + 1,
+                     (1 << 30) - 1, 1 << 30, (1 << 31) - 1, -(1 << 31), -(1 << 31) + 1, 0x7fffff80, 0x7fffffbf, 0x7fffffc0], np.int64)
+    edge = np.concatenate([edge, -edge[edge > -(1 << 31)]]).astype(np.int32)
+    ex, ey = np.meshgrid(edge, edge)
+    wx = np.concatenate([ex.reshape(-1), rng.integers(-(1 << 31), 1 << 31, 60000)]).astype(np.int32)
+    wy = np.concatenate([ey.reshape(-1), rng.integers(-(1 << 31), 1 << 31, 60000)]).astype(np.int32)
+    n = (len(wx) + 3) // 4 * 4
+    wx = np.pad(wx, (0, n - len(wx))); wy = np.pad(wy, (0, n - len(wy)))
+    grouped = np.stack([wx.reshape(-1, 4), wy.reshape(-1, 4)], axis=1).reshape(-1).astype(np.int32)
+    assert (fe.atan2(grouped, ctx=gpu_ctx) == orc.atan2_bins(grouped)).all()
     small = np.arange(-40, 41, dtype=np.int32)
     gx, gy = np.meshgrid(small, small)
     gx, gy = gx.reshape(-1), gy.reshape(-1)
