@@ -271,7 +271,9 @@ __device__ __forceinline__ void orb_describe(const OrbLane &G, const OrbWin &cur
   const uint32_t pme = half ? p1 : p0;
   const bool valid = pme != 0;
   const int x = decode_x(pme), y = decode_y(pme);
-  const uint32_t sh = (uint32_t)(((y - 15) * vstep + (x - 15)) & 15);   // same for every row
+  // byte shift of the patch inside its 16-byte chunks: ((y - 15) * vstep + (x - 15)) & 15 with vstep % 16 == 0
+  // (the precondition of this scheme) — the same for every row, and independent of y
+  const uint32_t sh = (uint32_t)(x + 1) & 15u;
   // (the skewed row starts are only 4-byte aligned: four dword stores per chunk instead of one 16-byte store)
 #pragma unroll
   for (int j = 0; j < 3; j++)
