@@ -3,7 +3,7 @@
 # (1 = stop after staging, 16 = prefilter only, 2 = + pretest, 4 = + FAST-9, 8 = + Harris, 65536 = everything)
 cd /tmp && export TMPDIR=/tmp
 root=${GRAFT_REPO_ROOT:-/root/repo}
-for a in 1 16 2 4 8 65536 0; do
+for a in 1 16 2 4 8 65536 0; do   # (0 = the product kernel)
   rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_INST_ANY --output-format csv -d $root/gpurun_out/abl_$a -o p -- python $root/bench.py --steps 2 --warmup 1 --no-cpu-baseline --graph 0 --ablate $a "$@" > /dev/null 2>&1
   python - <<P
 import csv, collections

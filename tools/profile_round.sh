@@ -47,3 +47,6 @@ z = np.load("$root/tests/golden/demo_pyramid.npz")
 z["img"].astype(np.uint8).tofile("/tmp/demo_pyramid.raw")
 P
 (cd $root && make -s -C tools pislam_demo > /dev/null 2>&1; for s in 3 1; do tools/pislam_demo /tmp/demo_pyramid.raw --batch 256 --steps 100 --streams $s; done) > $out/cpp_tool_demo_photo_x256.txt 2>&1
+# per-phase instruction counts of the strip kernel (cumulative ablations of the profiling build)
+(cd $root && bash tools/pmc_ablate.sh --streams 1) > $out/phase_ablation.txt 2>&1
+rm -rf $root/gpurun_out/abl_*
