@@ -815,21 +815,32 @@ __device__ __forceinline__ void strip_body(const StripArgs A, const FusedLevel L
       const uint32_t e = nq[min(c0 + lane, tn - 1)];
       const bool valid = c0 + lane < tn && (!ALIAS || (e >> 24) != 0);
       const int x = e & 0xffff, r = (e >> 16) & 0xff;
-      const int bx = B + ((x - B) & ~1), rb = 1 + ((r - 1) & ~1);   // block origin (column, score row)
+      const int bx = B + ((x - B) & ~1);            // column of the pixel's 2x2 block
       const bool owned = valid && r >= 1 && r <= own_rows && bx >= ex0q && bx < ex1q;
+      // The block rule of Fast.h:228-312 seen from ONE pixel: the block's candidate is the LAST maximum of the block
+      // in raster order (s0 / s1 / s2 chain, Fast.h:264-298), and its outer comparisons are >= against the neighbours
+      // that precede it in raster order and > against those that follow (Fast.h:265-305) — together exactly "this
+      // pixel is the strict maximum of its 3x3 neighbourhood under (score, raster position)".  So an entry decides
+      // for itself, on three rows instead of the block's four, four comparisons per instruction:
+      //   me >= e for the 4 preceding neighbours  <=>  bit 7 of v_lerp_u8(me, ~e, 1) in every byte,
+      //   me >  l for the 4 following ones        <=>  bit 7 of v_lerp_u8(l, ~me, 1) in no byte.
       uint32_t res = 0;
       if (owned) {
-        const int cb = (bx - 1) & ~3;               // aligned dword holding column bx-1
-        const uint32_t shb = (uint32_t)(bx - 1) & 3u;
-        uint32_t w[4];
+        const int cb = (x - 1) & ~3;                // aligned dword holding column x-1
+        const uint32_t shb = (uint32_t)(x - 1) & 3u;
+        uint32_t w[3];
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-          const lds_u8 *rowp = sc + (rb - 1 + k) * pitch + cb;
-          w[k] = __builtin_amdgcn_alignbyte(*(const lds_u32 *)(rowp + 4), *(const lds_u32 *)rowp, shb);
+        for (int k = 0; k < 3; k++) {
+          const lds_u8 *rowp = sc + (r - 1 + k) * pitch + cb;
+          w[k] = __builtin_amdgcn_alignbyte(*(const lds_u32 *)(rowp + 4), *(const lds_u32 *)rowp, shb);   // columns x-1 .. x+2
         }
-        res = nms_block_regs(w[0], w[1], w[2], w[3], bx, ys + rb - 1);
-        // only the block's winner emits (the other non-zero pixels of the block stay silent)
-        if (decode_x(res) != x || decode_y(res) != ys - 1 + r) res = 0;
+        const uint32_t me = (w[1] >> 8) & 0xffu;
+        const uint32_t rep = me * 0x01010101u;
+        const uint32_t before = __builtin_amdgcn_perm(w[1], w[0], 0x04020100u);   // (r-1: x-1, x, x+1), (r: x-1)
+        const uint32_t after = __builtin_amdgcn_perm(w[2], w[1], 0x06050402u);    // (r: x+1), (r+1: x-1, x, x+1)
+        const uint32_t ge = __builtin_amdgcn_lerp(rep, ~before, 0x01010101u);     // bit 7: me >= that neighbour
+        const uint32_t le = __builtin_amdgcn_lerp(after, ~rep, 0x01010101u);      // bit 7: that neighbour >= me
+        if (((~ge | le) & 0x80808080u) == 0) res = encode_fast(me, (uint32_t)x, (uint32_t)(ys - 1 + r));
       }
       const uint64_t m = __ballot(res != 0);
       if (m) {
