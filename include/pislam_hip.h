@@ -255,8 +255,8 @@ int pislam_frontend_last_stats(pislam_ctx *ctx, uint32_t stats[2]);
 /* ---- batches in flight ---------------------------------------------------
  * A pipeline = `depth` (1..8) contexts behind one object, each with its own workspace and non-blocking stream:
  * batch k runs on lane k % depth, so that the tail of one batch (partly filled CUs, the latency-bound gather+ORB
- * kernel, launch gaps) runs under the head of the next.  MI355X, 256 VGA pyramids per batch: 0.277 ms per batch
- * one call at a time, 0.24 ms with depth 3.  The reference loop (demo/demo.cpp:77-101: frames are independent)
+ * kernel, launch gaps) runs under the head of the next.  MI355X, 256 VGA pyramids per batch: 0.27 ms per batch
+ * one call at a time, 0.23 ms with depth 3.  The reference loop (demo/demo.cpp:77-101: frames are independent)
  * becomes
  *     for each batch k:  pislam_pipeline_submit(pipe, ..., inputs_k, outputs_k, producer_stream, 1, &t[k]);
  *     before consuming outputs_k on stream s:  pislam_pipeline_wait(pipe, t[k], s);

@@ -1748,8 +1748,8 @@ PISLAM_EXPORT int pislam_match_hamming_batch(pislam_ctx *c, int words, const uin
 
 // ---- batches in flight: a pipeline of contexts behind one object --------------------------------
 // One batch call at a time leaves the GPU's issue slots idle at the seams of a step (the strip kernel's tail of
-// partly filled CUs, the latency-bound gather + ORB kernel, launch gaps): 0.277 ms per 256 VGA pyramids against
-// 0.241 ms with three whole batches in flight.  (Overlapping INSIDE one call was built twice and measured slower
+// partly filled CUs, the latency-bound gather + ORB kernel, launch gaps): 0.27 ms per 256 VGA pyramids against
+// 0.23 ms with three whole batches in flight.  (Overlapping INSIDE one call was built twice and measured slower
 // both times — sub-batches on a second stream, strip and ORB workgroups in one grid: DESIGN.md.)  The pipeline
 // object is that choreography as library API: `depth` lanes, each a context (workspace + non-blocking stream)
 // of its own; batch k runs on lane k % depth, ordered after the producer of its input (an event on the caller's
@@ -1757,7 +1757,7 @@ PISLAM_EXPORT int pislam_match_hamming_batch(pislam_ctx *c, int words, const uin
 //
 // A steady stream of batches repeats its calls exactly (same buffers, same shape): a lane replays such a call from
 // a hipGraph — first occurrence eager (it may size the workspace), second captured, replayed from then on
-// (3 launches + 4 event records per call become one graph launch: 0.256 -> 0.250 ms per batch at depth 3).
+// (3 launches + 4 event records per call become one graph launch: -2.5 % per batch at depth 3).
 struct LaneCall {
   pislam_frontend_params p;
   std::vector<pislam_level> lv;
