@@ -180,3 +180,30 @@ def test_pyramid_build_equals_reference_functions_in_sequence(gpu_ctx, orc):
         for b in (1, 2):
             okp, odesc, _ = orc.pyramid(got[b], [l[:3] for l in pb.levels])
             assert c[b] == len(okp) and (k[b, :len(okp)] == okp).all() and (d[b, :len(okp)] == odesc).all()
+
+
+@pytest.mark.gpu
+def test_pyramid_build_flags_are_checked(gpu_ctx):
+    """ABI 2: the last argument of pislam_pyramid_build_batch is a PISLAM_BUILD_* bitmask (ABI 1: `blur`, any non-zero
+    value): unknown bits are refused instead of being read as flags, and PISLAM_BUILD_CHECK_MARGINS verifies a
+    caller's PISLAM_BUILD_MARGINS_CLEAN promise (dirty margins -> PISLAM_ERR_INVALID, clean ones pass)."""
+    import ctypes
+    import torch
+    from pislam_amd import capi
+    from pislam_amd.frontend import PyramidBuilder
+    pb = PyramidBuilder(320, 240, (2, 1), ctx=gpu_ctx)
+    B = 2
+    d_fr = torch.randint(0, 256, (B, 240, 320), dtype=torch.uint8, device="cuda")
+    d_pyr = torch.full((B, pb.rows, pb.vstep), 0x5A, dtype=torch.uint8, device="cuda")
+
+    def build(flags):
+        return gpu_ctx.lib.pislam_pyramid_build_batch(gpu_ctx.h, pb.nlevels, pb.steps, pb.levels_c, capi.ptr(d_fr), 320, 240 * 320, B,
+                                                      capi.ptr(d_pyr), pb.vstep, pb.rows, pb.rows * pb.vstep, flags)
+    for bad in (8, -1, 1 | 16, 0x100):
+        assert build(bad) == -1                                  # PISLAM_ERR_INVALID, nothing launched
+    assert build(1 | 2 | 4) == -1                                # the buffer is dirty (0x5A everywhere): the promise is false
+    assert b"margins" in gpu_ctx.lib.pislam_last_error(gpu_ctx.h)
+    assert build(1) == 0                                         # a normal build establishes the margins ...
+    torch.cuda.synchronize()
+    assert build(1 | 2 | 4) == 0                                 # ... and now the promise holds
+    torch.cuda.synchronize()
