@@ -455,25 +455,18 @@ def worker_main(args):
         k, _, v = kv.partition("=")
         extra_opts.append((k.strip(), int(v)))
 
-    def make_context(stream):
-        c = Context(device=local_rank, stream=stream.cuda_stream)
-        c.set_option("pipeline", args.pipeline)
-        c.set_option("strip_rows", args.strip_rows)
-        c.set_option("orb_chunks", args.orb_chunks)
-        c.set_option("lds_pad", args.lds_pad)
-        for key, val, on in (("alias", args.alias, args.alias >= 0), ("run_order", args.run_order, args.run_order >= 0),
-                             ("strip_px", args.strip_px, args.strip_px), ("strip_rows_max", args.strip_rows_max, args.strip_rows_max),
-                             ("tile_cols", args.tile_cols, args.tile_cols), ("orb_in_strip", args.orb_in_strip, args.orb_in_strip >= 0),
-                             ("match_mfma", args.match_mfma, args.match_mfma >= 0), ("run_len", args.run_len, args.run_len),
-                             ("wgs_per_cu", args.wgs_per_cu, args.wgs_per_cu)):
-            if on:
-                c.set_option(key, val)
-        for k, v in extra_opts:
-            c.set_option(k, v)
-        c.set_option("ablate", args.ablate)
-        return c
+    lib_opts = [("pipeline", args.pipeline), ("strip_rows", args.strip_rows), ("orb_chunks", args.orb_chunks),
+                ("lds_pad", args.lds_pad)]
+    for key, val, on in (("alias", args.alias, args.alias >= 0), ("run_order", args.run_order, args.run_order >= 0),
+                         ("strip_px", args.strip_px, args.strip_px), ("strip_rows_max", args.strip_rows_max, args.strip_rows_max),
+                         ("tile_cols", args.tile_cols, args.tile_cols), ("orb_in_strip", args.orb_in_strip, args.orb_in_strip >= 0),
+                         ("match_mfma", args.match_mfma, args.match_mfma >= 0), ("run_len", args.run_len, args.run_len),
+                         ("wgs_per_cu", args.wgs_per_cu, args.wgs_per_cu)):
+        if on:
+            lib_opts.append((key, val))
+    lib_opts += extra_opts + [("ablate", args.ablate)]
 
-    # ---- the resident input (shared by every pipeline; the 720p workload builds its pyramids per pipeline) ----
+    # ---- the resident input (shared by every lane; the 720p workload builds its pyramids per lane) ----
     host = d_frames = d_pyr0 = None
     if args.workload == "720p-build":
         fr = np.stack([synth.make_level0(first + i, w0, h0) for i in range(min(distinct, B))])
@@ -487,20 +480,27 @@ def worker_main(args):
         if distinct < B:
             d_pyr0 = d_pyr0[torch.arange(B, device=dev) % distinct].contiguous()
 
-    # ---- S independent pipelines: batch k runs on pipeline k % S — its own HIP stream, context (workspace),
-    # outputs and hipGraph — so that the tail of one batch call runs under the head of the next.  Every batch is
-    # still processed completely (strips -> overflow pass -> gather+ORB, then the count all-gather) inside the
-    # timed region.
-    class Pipe:
+    # ---- batches in flight: the LIBRARY's pipeline object (pislam_pipeline_*, include/pislam_hip.h) — S lanes, each a
+    # context (workspace) + non-blocking HIP stream of its own; batch k is submitted to lane k % S, so that the tail of
+    # one batch call runs under the head of the next; a call that repeats exactly is replayed from a hipGraph inside
+    # the library (option "graphs").  Every batch is still processed completely (strips -> overflow pass ->
+    # gather+ORB, then the count all-gather) inside the timed region.
+    from pislam_amd import capi
+    pl = capi.Pipeline(device=local_rank, depth=S)
+    pl.set_option("graphs", 1 if args.graph else 0)
+    for k_, v_ in lib_opts:
+        pl.set_option(k_, v_)
+
+    class Lane:
         pass
 
     pipes = []
     for i in range(S):
-        P = Pipe()
-        P.stream = torch.cuda.Stream(dev)
-        P.ctx = make_context(P.stream)
+        P = Lane()
+        P.ctx = pl.lane(i)                                # borrowed: the pipeline owns it
+        P.stream_handle = pl.stream_of(i)                 # (ticket i runs on lane i)
+        P.stream = torch.cuda.ExternalStream(P.stream_handle, device=dev)
         P.builder = None
-        P.graphs = None
         with torch.cuda.stream(P.stream):
             if args.workload == "720p-build":
                 P.builder = PyramidBuilder(w0, h0, ctx=P.ctx)
@@ -512,19 +512,29 @@ def worker_main(args):
                     host = P.d_pyr[:min(distinct, B)].cpu().numpy()
             else:
                 P.d_pyr = d_pyr0
-            P.fe = OrbFrontend(levels, vstep=vstep, rows=rows, max_keypoints=args.max_keypoints, ctx=P.ctx,
-                               log_bucket_size=args.log_bucket_size, bucket_limit=args.bucket_limit)
-            P.fe.reserve(B)
-            P.outs = [P.fe.alloc_outputs(B, dev) for _ in range(nsets)]
         pipes.append(P)
-    ctx, fe, builder, d_pyr = pipes[0].ctx, pipes[0].fe, pipes[0].builder, pipes[0].d_pyr
-    stream = pipes[0].stream
-    kp, desc, counts = pipes[0].outs[0]
+    fe = OrbFrontend(levels, vstep=vstep, rows=rows, max_keypoints=args.max_keypoints, ctx=pipes[0].ctx,
+                     log_bucket_size=args.log_bucket_size, bucket_limit=args.bucket_limit)   # parameter / level structs
+    pl.reserve(fe.params, fe.levels, B)
+    for P in pipes:
+        P.outs = [fe.alloc_outputs(B, dev) for _ in range(nsets)]
+    # one plain context for everything measured OUTSIDE the timed region (one call at a time, the strip kernel alone)
+    side_stream = torch.cuda.Stream(dev)
+    ctx = Context(device=local_rank, stream=side_stream.cuda_stream)
+    for k_, v_ in lib_opts:
+        ctx.set_option(k_, v_)
+    fe1 = OrbFrontend(levels, vstep=vstep, rows=rows, max_keypoints=args.max_keypoints, ctx=ctx,
+                      log_bucket_size=args.log_bucket_size, bucket_limit=args.bucket_limit)
+    fe1.reserve(B)
+    builder1 = PyramidBuilder(w0, h0, ctx=ctx) if args.workload == "720p-build" else None
+    builder = pipes[0].builder
+    d_pyr, stream = pipes[0].d_pyr, side_stream
+    kp, desc, counts = fe.alloc_outputs(B, dev)
 
-    # ---- the count all-gather: ONE communicator and ONE collective stream per process, shared by all pipelines
-    # (pislam_amd.dist.ExchangeHub over the C ABI's pislam_dist_*).  Ranks sharing one GPU (gloo test mode) cannot
-    # form an RCCL communicator; if the C-ABI path fails on any rank, all ranks fall back to torch.distributed's
-    # all-gather and the JSON line says so.
+    # ---- the count all-gather: ONE communicator and ONE collective stream per process, shared by all lanes
+    # (pislam_amd.dist.ExchangeHub over the C ABI's pislam_dist_*; the all-gathers are ordered after / fence the lanes'
+    # streams).  Ranks sharing one GPU (gloo test mode) cannot form an RCCL communicator; if the C-ABI path fails on
+    # any rank, all ranks fall back to torch.distributed's all-gather and the JSON line says so.
     hub = None
     if world > 1 and not gloo_mode and args.exchange == "cabi":
         err = pdist.init_rccl(ctx, rank, world, dev)
@@ -535,12 +545,11 @@ def worker_main(args):
         else:
             hub = pdist.ExchangeHub(ctx)
     if force:
-        from pislam_amd import capi
         ctx.set_option("dist_rccl_single", 1)
         ctx.dist_init(capi.dist_unique_id(), 0, 1)
         hub = pdist.ExchangeHub(ctx)
     for P in pipes:
-        P.xchg = pdist.CountExchange(world, hub=hub, always_collective=force, sets=nsets, stream=P.stream.cuda_stream)
+        P.xchg = pdist.CountExchange(world, hub=hub, always_collective=force, sets=nsets, stream=P.stream_handle)
     xchg = pipes[0].xchg
     rccl_ranks = None
     if hub is not None:
@@ -553,75 +562,41 @@ def worker_main(args):
         # train side: the neighbouring pyramid's descriptors (static inputs -> made once, outside the step)
         from pislam_amd.frontend import matchHammingBatch
         with torch.cuda.stream(stream):
-            fe(d_pyr, kp, desc, counts)
+            fe1(d_pyr, kp, desc, counts)
         torch.cuda.synchronize()
         t_desc, t_counts = torch.roll(desc, 1, 0).contiguous(), torch.roll(counts, 1, 0).contiguous()
         m_out = [torch.empty((B, args.max_keypoints), dtype=torch.int32, device=dev) for _ in range(3)]
-    nstep = [0]
-
-    def launches(P, k_, d_, c_):
-        if P.builder is not None:
-            # steady state of a stream: the same pyramid buffer is refilled every step by the same builder
-            # (its first fill, before the timed region, established the zero margins)
-            P.builder(d_frames, P.d_pyr, margins_clean=bool(args.margins_clean))
-        P.fe(P.d_pyr, k_, d_, c_)
-        if m_out is not None:
-            matchHammingBatch(d_, c_, t_desc, t_counts, *m_out, ctx=P.ctx)
-
-    use_graphs = False
-    if args.graph:
-        # The batch call allocates nothing and never synchronises once the workspace is reserved, so a step's
-        # launches can be replayed from a hipGraph.  Any failure (capture error, replay not reproducing the
-        # eager counts) falls back to eager launches: the measurement must never depend on this.
-        graph_err = None
-        try:
-            for P in pipes:
-                with torch.cuda.stream(P.stream):
-                    for o in P.outs:
-                        launches(P, *o)                 # warm-up outside the capture (allocations, module load)
-            torch.cuda.synchronize()
-            for P in pipes:
-                want = [o[2].clone() for o in P.outs]
-                P.graphs = []
-                for o in P.outs:
-                    g = torch.cuda.CUDAGraph()
-                    # thread_local: API calls of other threads (the RCCL watchdog of a multi-rank run) must not
-                    # invalidate the capture
-                    with torch.cuda.graph(g, stream=P.stream, capture_error_mode="thread_local"):
-                        launches(P, *o)
-                    P.graphs.append(g)
-                for o, g, w in zip(P.outs, P.graphs, want):
-                    o[2].zero_()
-                    torch.cuda.synchronize()
-                    with torch.cuda.stream(P.stream):
-                        g.replay()
-                    torch.cuda.synchronize()
-                    if not torch.equal(o[2], w):
-                        raise RuntimeError("graph replay does not reproduce the eager result")
-        except Exception as e:                          # noqa: BLE001
-            graph_err = repr(e)
-            print(f"[bench rank {rank}] hipGraph path disabled: {graph_err}", file=sys.stderr)
-            torch.cuda.synchronize()
-        # every rank takes the same path (a rank replaying graphs beside ranks launching eagerly would be a
-        # different measurement per rank)
-        if agree_any(graph_err is not None, dev):
-            fallbacks.append("hipGraph capture failed on a rank -> eager launches" + (f" ({graph_err})" if graph_err else ""))
-        else:
-            use_graphs = True
+    nstep, tick, last_out = [0], [0], [None]
 
     def step():
-        k = nstep[0]
+        """Batch k: on lane k % S — [pyramid build on the lane's stream] -> pislam_pipeline_submit -> [matcher] ->
+        count all-gather ordered after the lane's stream."""
+        k = tick[0]                                     # == the library's ticket: lane k % S
+        tick[0] += 1
         nstep[0] += 1
         P = pipes[k % S]
-        i = (k // S) % nsets
+        o = P.outs[(k // S) % nsets]
+        last_out[0] = o
         with torch.cuda.stream(P.stream):
-            P.xchg.before_step()                        # this pipeline's stream waits for the all-gather that read set i
-            if use_graphs:
-                P.graphs[i].replay()
-            else:
-                launches(P, *P.outs[i])
-            P.xchg.start(P.outs[i][2])
+            P.xchg.before_step()                        # the lane's stream waits for the all-gather that read this output set
+            if P.builder is not None:
+                # steady state of a stream: the same pyramid buffer is refilled every step by the same builder
+                # (its first fill, before the timed region, established the zero margins)
+                P.builder(d_frames, P.d_pyr, margins_clean=bool(args.margins_clean))
+            t = pl.submit(fe.params, fe.levels, P.d_pyr, *o)
+            assert t == k, "tickets and steps out of phase"
+            if m_out is not None:
+                matchHammingBatch(o[1], o[2], t_desc, t_counts, *m_out, ctx=P.ctx)
+            P.xchg.start(o[2])
         return P
+
+    def launches1(k_, d_, c_):
+        """One call at a time on the plain context (outside the timed region)."""
+        if builder1 is not None:
+            builder1(d_frames, d_pyr, margins_clean=bool(args.margins_clean))
+        fe1(d_pyr, k_, d_, c_)
+        if m_out is not None:
+            matchHammingBatch(d_, c_, t_desc, t_counts, *m_out, ctx=ctx)
 
     def finish_all(last=None):
         r = None
@@ -631,13 +606,33 @@ def worker_main(args):
                 r = v
         return r
 
+    # ---- warm-up of the lanes: every (lane, output set) call three times — eager, captured, first replay — and the
+    # replayed result checked against a plain eager call: the measurement must never depend on the graphs
+    for _ in range(3 * S * nsets):
+        step()
+    finish_all()
+    torch.cuda.synchronize()
+    with torch.cuda.stream(stream):
+        launches1(kp, desc, counts)
+    torch.cuda.synchronize()
+    graph_bad = any(not torch.equal(o[2], counts) for P in pipes for o in P.outs)
+    st0 = pl.stats()
+    use_graphs = bool(args.graph) and st0["replayed_from_graphs"] > 0
+    if agree_any(graph_bad, dev):
+        # every rank takes the same path (a rank replaying graphs beside ranks launching eagerly would be a
+        # different measurement per rank)
+        pl.set_option("graphs", 0)
+        use_graphs = False
+        fallbacks.append("a hipGraph replay did not reproduce the eager counts on a rank -> eager launches")
+    elif args.graph and agree_any(st0["capture_failed"] > 0 or st0["replayed_from_graphs"] == 0, dev):
+        pl.set_option("graphs", 0)
+        use_graphs = False
+        fallbacks.append("hipGraph capture failed on a rank -> eager launches")
+    nstep[0] = 0
+
     def spin_once():
-        for P in pipes:
-            with torch.cuda.stream(P.stream):
-                if use_graphs:
-                    P.graphs[0].replay()
-                else:
-                    launches(P, *P.outs[0])
+        for _ in range(S):
+            step()
 
     # ---- start-up self-check (N > 1): two untimed steps per pipeline INCLUDING the exchange, under a hard timeout
     # — a collective that cannot complete must end this worker (the supervisors then walk the ladder), not the
@@ -645,13 +640,12 @@ def worker_main(args):
     if world > 1 or force:
         with Watchdog(args.selfcheck_timeout, "start-up self-check (2 steps per pipeline + count all-gather)"):
             _inject("selfcheck", args.attempt, rank)
-            n_chk = 2 * S
-            for _ in range(n_chk):
-                step()
-            Pl = pipes[(n_chk - 1) % S]
+            Pl = None
+            for _ in range(2 * S):
+                Pl = step()
             chk = finish_all(Pl)
             torch.cuda.synchronize()
-            mine = Pl.outs[((n_chk - 1) // S) % nsets][2]
+            mine = last_out[0][2]
             bad = not torch.equal(chk[rank * B:(rank + 1) * B].cpu(), mine.cpu())
             if agree_any(bad, dev):
                 raise SystemExit("start-up self-check: the gathered counts do not hold this rank's counts")
@@ -710,59 +704,45 @@ def worker_main(args):
     def local_kp_fn(c_):
         return int(torch.clamp(c_.to(torch.int64), max=args.max_keypoints).sum().item())
 
-    # ---- one batch call at a time (the figure a caller without any stream choreography gets) ----
+    # ---- one batch call at a time (the figure a caller without any stream choreography gets): a pipeline of depth 1
+    # (same library path, same graphs), and the stage times of eager calls on a plain context ----
     ev = []
     for _ in range(min(8, max(3, args.steps))):
         with torch.cuda.stream(stream):
-            launches(pipes[0], kp, desc, counts)
-        ev.append(fe.last_timing())
+            launches1(kp, desc, counts)
+        ev.append(fe1.last_timing())
     ev_total_ms = float(np.mean([e[0] for e in ev]))
     ev_stage_ms = [float(np.mean([e[1][i] for e in ev])) for i in range(3)]
     one_ms = None
     try:
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        pl1 = capi.Pipeline(device=local_rank, depth=1)
+        pl1.set_option("graphs", 1 if use_graphs else 0)
+        for k_, v_ in lib_opts:
+            pl1.set_option(k_, v_)
+        pl1.reserve(fe.params, fe.levels, B)
+        c1 = pl1.lane(0)
+        s1 = torch.cuda.ExternalStream(pl1.stream_of(0), device=dev)
+        b1 = PyramidBuilder(w0, h0, ctx=c1) if builder is not None else None
+        o1 = fe.alloc_outputs(B, dev)
         REPS = 20
-        with torch.cuda.stream(stream):
-            for i in range(REPS + 3):
-                if i == 3:
-                    e0.record(stream)
-                if use_graphs:
-                    pipes[0].graphs[0].replay()
-                else:
-                    launches(pipes[0], *pipes[0].outs[0])
-            e1.record(stream)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        with torch.cuda.stream(s1):
+            for i in range(REPS + 4):
+                if i == 4:
+                    e0.record(s1)
+                if b1 is not None:
+                    b1(d_frames, d_pyr, margins_clean=bool(args.margins_clean))
+                pl1.submit(fe.params, fe.levels, d_pyr, *o1)
+                if m_out is not None:
+                    matchHammingBatch(o1[1], o1[2], t_desc, t_counts, *m_out, ctx=c1)
+            e1.record(s1)
         torch.cuda.synchronize()
         one_ms = e0.elapsed_time(e1) / REPS
-    except Exception:                                    # noqa: BLE001
-        pass
-    # ---- the same batches-in-flight scheme as LIBRARY API (pislam_pipeline_*: what a C++ caller gets from one object,
-    # INTEGRATION.md): K batches submitted to a pipeline of 3 lanes, repeated calls replayed from hipGraphs inside ----
-    lib_pipe = None
-    if world == 1 and builder is None and m_out is None:
-        try:
-            from pislam_amd import capi
-            depth = 3
-            pl = capi.Pipeline(device=local_rank, depth=depth)
-            for k, v in extra_opts:
-                pl.set_option(k, v)
-            pl.reserve(fe.params, fe.levels, B)
-            pouts = [fe.alloc_outputs(B, dev) for _ in range(depth)]
-            for k in range(4 * depth):                    # first / second / third occurrence per lane: eager, capture, replay
-                pl.submit(fe.params, fe.levels, d_pyr, *pouts[k % depth])
-            pl.synchronize()
-            K = max(30, min(200, args.steps))
-            tp = time.perf_counter()
-            for k in range(K):
-                pl.submit(fe.params, fe.levels, d_pyr, *pouts[k % depth])
-            pl.synchronize()
-            tp = time.perf_counter() - tp
-            same = bool(torch.equal(pouts[0][2], counts))
-            lib_pipe = {"depth": depth, "ms_per_batch": tp / K * 1e3, "value": local_kp_fn(pouts[0][2]) * K / tp,
-                        "counts_equal_to_the_timed_path": same, "batches": K,
-                        "api": "pislam_pipeline_create / _submit / _synchronize (include/pislam_hip.h)"}
-            pl.close()
-        except Exception as e:                           # noqa: BLE001
-            lib_pipe = {"error": repr(e)}
+        pl1.close()
+    except Exception as e:                               # noqa: BLE001
+        print(f"[bench] one-call-at-a-time measurement failed: {e!r}", file=sys.stderr)
+    lib_pipe = {"api": "pislam_pipeline_create / _submit / _wait (include/pislam_hip.h): the timed steps ARE submits to this object",
+                "depth": S, **pl.stats()}
     # dominant kernel alone: REP back-to-back launches inside one hipEvent bracket (a single eager launch is
     # bracketed together with ~10 us of command-processor latency)
     strip_ms = None
@@ -772,8 +752,8 @@ def worker_main(args):
         try:
             rr = []
             for _ in range(3):
-                fe(d_pyr, kp, desc, counts)
-                rr.append(fe.last_timing()[1][0] / REP)
+                fe1(d_pyr, kp, desc, counts)
+                rr.append(fe1.last_timing()[1][0] / REP)
             strip_ms = float(np.mean(rr))
         finally:
             ctx.set_option("repeat_strips", 1)
@@ -787,7 +767,7 @@ def worker_main(args):
                 with torch.cuda.stream(stream):
                     e0.record(stream)
                     for _ in range(10):
-                        builder(d_frames, d_pyr, margins_clean=clean)
+                        builder1(d_frames, d_pyr, margins_clean=clean)
                     e1.record(stream)
                 torch.cuda.synchronize()
                 tm.append(e0.elapsed_time(e1) / 10)
@@ -812,7 +792,7 @@ def worker_main(args):
                       "matched_within_64_bits": int(((m_out[1] <= 64) & (torch.arange(args.max_keypoints, device=dev)[None, :]
                                                                           < cq[:, None])).sum().item())}
 
-    deferred, nstrips = fe.last_stats()
+    deferred, nstrips = fe1.last_stats()
     # counts are the reference's un-clamped totals; keypoints beyond the capacity are neither stored nor
     # described, so only min(count, max_keypoints) per pyramid is credited
     capped = int((allc.to(torch.int64) > args.max_keypoints).sum().item())
@@ -879,9 +859,10 @@ def worker_main(args):
                 "pipeline": "fused" if fused else "staged",
                 "launch": "hipGraph replay" if use_graphs else "eager",
                 "streams": S,
-                "batches_in_flight": (f"{S}: step k runs on pipeline k % {S} (own HIP stream, context/workspace, outputs, "
-                                      "graph); each step is one whole batch, all K steps start and finish inside the "
-                                      "timed region; one_batch_ms = one call at a time, no caller-side overlap" if S > 1 else "1"),
+                "batches_in_flight": (f"{S}: step k is pislam_pipeline_submit to lane k % {S} of ONE library pipeline object (own "
+                                      "HIP stream, context/workspace, outputs, hipGraph inside the library); each step is one whole "
+                                      "batch, all K steps start and finish inside the timed region; one_batch_ms = the same "
+                                      "through a pipeline of depth 1" if S > 1 else "1"),
                 "strips_redone_by_overflow_pass": f"{deferred} of {nstrips}",
                 "max_keypoints": args.max_keypoints, "pyramids_over_capacity": capped,
                 "count_allgather": xchg.path,
@@ -924,6 +905,7 @@ def worker_main(args):
             ctx.dist_finalize()                          # our RCCL communicator first, while every rank is still alive
         except Exception:                                # noqa: BLE001
             pass
+        pl.synchronize()
         torch.distributed.destroy_process_group()
     return 0
 

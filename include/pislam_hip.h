@@ -280,6 +280,9 @@ int pislam_pipeline_submit(pislam_pipeline *pipe, const pislam_frontend_params *
                            uint64_t *ticket);
 int pislam_pipeline_wait(pislam_pipeline *pipe, uint64_t ticket, void *stream);
 int pislam_pipeline_synchronize(pislam_pipeline *pipe);
+/* stats[0] batches submitted, [1] of them replayed from a hipGraph, [2] calls captured, [3] captures that failed
+ * (such a call stays eager). */
+int pislam_pipeline_stats(const pislam_pipeline *pipe, uint64_t stats[4]);
 void *pislam_pipeline_stream(pislam_pipeline *pipe, uint64_t ticket);
 pislam_ctx *pislam_pipeline_lane(pislam_pipeline *pipe, int lane);
 const char *pislam_pipeline_last_error(const pislam_pipeline *pipe);

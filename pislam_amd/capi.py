@@ -72,6 +72,7 @@ SYMBOLS = {
                                     _vp, _i, ctypes.POINTER(ctypes.c_uint64)]),
     "pislam_pipeline_wait": (_i, [_vp, ctypes.c_uint64, _vp]),
     "pislam_pipeline_synchronize": (_i, [_vp]),
+    "pislam_pipeline_stats": (_i, [_vp, ctypes.POINTER(ctypes.c_uint64 * 4)]),
     "pislam_pipeline_stream": (_vp, [_vp, ctypes.c_uint64]),
     "pislam_pipeline_lane": (_vp, [_vp, _i]),
     "pislam_pipeline_last_error": (ctypes.c_char_p, [_vp]),
@@ -185,9 +186,19 @@ class Context:
         if stream is not None:
             self.set_stream(stream)
 
+    @classmethod
+    def borrowed(cls, handle):
+        """A Context object over a pislam_ctx someone else owns (a pipeline lane): never destroyed from here."""
+        c = cls.__new__(cls)
+        c.lib = load()
+        c.h = _vp(handle)
+        c.owned = False
+        return c
+
     def close(self):
         if getattr(self, "h", None):
-            self.lib.pislam_ctx_destroy(self.h)
+            if getattr(self, "owned", True):
+                self.lib.pislam_ctx_destroy(self.h)
             self.h = None
 
     def __del__(self):
@@ -293,6 +304,19 @@ class Pipeline:
 
     def stream_of(self, ticket: int) -> int:
         return int(self.lib.pislam_pipeline_stream(self.h, ticket) or 0)
+
+    def lane(self, i: int) -> "Context":
+        """The context of lane i (owned by the pipeline): for work that has to run on that lane's stream
+        (a pyramid build in front of a batch, statistics)."""
+        h = self.lib.pislam_pipeline_lane(self.h, i)
+        if not h:
+            raise PislamError("no such lane")
+        return Context.borrowed(h)
+
+    def stats(self) -> dict:
+        st = (ctypes.c_uint64 * 4)()
+        self.check(self.lib.pislam_pipeline_stats(self.h, ctypes.byref(st)), "pislam_pipeline_stats")
+        return {"submitted": int(st[0]), "replayed_from_graphs": int(st[1]), "captured": int(st[2]), "capture_failed": int(st[3])}
 
     def synchronize(self):
         self.check(self.lib.pislam_pipeline_synchronize(self.h), "pislam_pipeline_synchronize")

@@ -1784,6 +1784,7 @@ struct pislam_pipeline {
   std::vector<hipEvent_t> done;        // completion of the lane's last batch
   hipEvent_t in_ready = nullptr;       // producer stream -> lane stream
   unsigned long long submitted = 0;
+  unsigned long long n_replayed = 0, n_captured = 0, n_capture_failed = 0;
   std::string err;
 };
 
@@ -1940,6 +1941,9 @@ PISLAM_EXPORT int pislam_pipeline_submit(pislam_pipeline *q, const pislam_fronte
         hit->exec = nullptr;
         hit->failed = true;            // (whatever went wrong: this call stays eager)
         rc = PISLAM_OK;
+        q->n_capture_failed++;
+      } else {
+        q->n_captured++;
       }
     }
   }
@@ -1951,6 +1955,7 @@ PISLAM_EXPORT int pislam_pipeline_submit(pislam_pipeline *q, const pislam_fronte
       return PISLAM_ERR_HIP;
     }
     c->timing_valid = false;           // (the timing events were recorded inside the captured call)
+    q->n_replayed++;
   } else {
     rc = pislam_orb_frontend_batch(c, p, lv, pyramids, stride, batch, kp, desc, counts);
     if (rc != PISLAM_OK) {
@@ -1980,6 +1985,15 @@ PISLAM_EXPORT int pislam_pipeline_wait(pislam_pipeline *q, uint64_t ticket, void
     (void)hipGetLastError();
     return PISLAM_ERR_HIP;
   }
+  return PISLAM_OK;
+}
+
+PISLAM_EXPORT int pislam_pipeline_stats(const pislam_pipeline *q, uint64_t stats[4]) {
+  if (!q || !stats) return PISLAM_ERR_INVALID;
+  stats[0] = q->submitted;
+  stats[1] = q->n_replayed;
+  stats[2] = q->n_captured;
+  stats[3] = q->n_capture_failed;
   return PISLAM_OK;
 }
 

@@ -993,3 +993,54 @@ def test_pipeline_api_keeps_batches_in_flight_and_exact(orc, depth):
             assert c[b] == len(okp) and (kk[b, :len(okp)] == okp).all() and (d[b, :len(okp)] == odesc).all(), (k, b)
     pipe.synchronize()
     pipe.close()
+
+
+@pytest.mark.gpu
+def test_pipeline_replays_repeated_calls_from_graphs_and_says_so(orc):
+    """A call that repeats exactly on a lane: eager the first time, captured the second, replayed from the third
+    (pislam_pipeline_stats counts each); replays equal the oracle; option "graphs"=0 keeps every call eager; a lane's
+    context (pislam_pipeline_lane) takes other calls of the C ABI on the lane's stream."""
+    import torch
+    from pislam_amd import capi, synth
+    from pislam_amd.frontend import OrbFrontend
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    levels = synth.level_table(320, 240, 4)
+    rows = synth.pyramid_rows(levels)
+    dev = torch.device("cuda:0")
+    B, D, R = 2, 2, 5
+    host = synth.make_batch(4200, B, w0=320, h0=240, nlevels=4, levels=levels, nshapes=30)
+    d_in = torch.from_numpy(host).to(dev)
+    fe = OrbFrontend(levels, vstep=320, rows=rows, max_keypoints=2048)
+    want = [orc.pyramid(host[b], levels) for b in range(B)]
+    for graphs in (1, 0):
+        pipe = capi.Pipeline(device=0, depth=D)
+        pipe.set_option("graphs", graphs)
+        pipe.reserve(fe.params, fe.levels, B)
+        outs = [fe.alloc_outputs(B, dev) for _ in range(D)]
+        for r in range(R):
+            for l in range(D):
+                for t in outs[l]:
+                    t.zero_()                                  # (on torch's stream; the submit below is ordered after it)
+                pipe.submit(fe.params, fe.levels, d_in, *outs[l], input_stream=torch.cuda.current_stream().cuda_stream)
+            pipe.synchronize()
+            for l in range(D):
+                c = outs[l][2].cpu().numpy().view(np.uint32)
+                kk = outs[l][0].cpu().numpy().view(np.uint32)
+                dd = outs[l][1].cpu().numpy().view(np.uint32)
+                for b in range(B):
+                    okp, odesc, _ = want[b]
+                    assert c[b] == len(okp) and (kk[b, :len(okp)] == okp).all() and (dd[b, :len(okp)] == odesc).all(), (graphs, r, l, b)
+        st = pipe.stats()
+        assert st["submitted"] == D * R
+        if graphs:
+            assert st["captured"] == D and st["capture_failed"] == 0 and st["replayed_from_graphs"] == D * (R - 2), st
+        else:
+            assert st["captured"] == 0 and st["replayed_from_graphs"] == 0, st
+        lane = pipe.lane(1)                                    # borrowed context: plain batch call on the lane's stream
+        k2, d2, c2 = fe.alloc_outputs(B, dev)
+        OrbFrontend(levels, vstep=320, rows=rows, max_keypoints=2048, ctx=lane)(d_in, k2, d2, c2)
+        pipe.synchronize()
+        assert torch.equal(c2, outs[0][2]) and torch.equal(k2, outs[0][0])
+        pipe.close()
+
