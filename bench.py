@@ -138,10 +138,10 @@ def build_parser():
     ap.add_argument("--tile-cols", type=int, default=0, help="levels with more classified columns are cut into x-tiles (0 = default 704, < 0 never)")
     ap.add_argument("--orb-in-strip", type=int, default=-1, help="1: strips describe their own keypoints; 0 (default): one gather+ORB pass")
     ap.add_argument("--graph", type=int, default=1,
-                    help="1 (default): capture the step's launches into a hipGraph (torch.cuda.CUDAGraph) per output set "
-                         "and replay it — falls back to eager launches if the capture or its check fails; 0: eager")
+                    help="1 (default): the library pipeline replays a repeated batch call from a hipGraph (pislam_pipeline option "
+                         "'graphs') — falls back to eager launches if a capture or the replay check fails; 0: eager")
     ap.add_argument("--streams", type=int, default=0,
-                    help="caller-side pipelines (HIP stream + context + outputs + graph); step k runs on pipeline k %% S, so "
+                    help="lanes of the library pipeline (pislam_pipeline_create depth: HIP stream + context each); step k runs on lane k %% S, so "
                          "consecutive batches overlap on the GPU.  0 = default (3); 1 = strictly one batch call at a time")
     ap.add_argument("--opt", action="append", default=[], metavar="KEY=VALUE",
                     help="any library option (pislam_ctx_set_option), e.g. --opt sub_batches=2; repeatable")
