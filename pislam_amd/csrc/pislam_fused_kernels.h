@@ -72,8 +72,7 @@ struct FusedLevel {
   int tbytes;        // plain layout: bytes reserved for the image tile = max((R+10)*tpitch, the scan
                      // fallbacks' survivor / per-cell buffers — larger only with narrow x-tiles)
   uint32_t vpr_recip; // ceil(2^32 / (tpitch/16)): row = umulhi(i, vpr_recip) for a vector index i < 2^16
-  int tail_rows;      // prefilter: rows whose last, partial 256-column step share one wave step (64 / groups in it)
-  uint32_t tail_recip; // ceil(2^32 / groups in the tail step): row of a lane = umulhi(lane, tail_recip)
+  uint32_t tp_recip;  // ceil(2^32 / tpitch): tile row of a byte offset k < 2^16 into the tile = umulhi(k, tp_recip)
   // A plan entry is a whole pyramid level, or one X-TILE of a wide level: a column range handled by its own
   // workgroups like a level of its own (w / col0 describe the tile plus a halo of real image columns in place
   // of the border), so that the LDS footprint — and with it the number of resident workgroups — does not grow
@@ -493,12 +492,19 @@ __device__ __forceinline__ void strip_body(const StripArgs A, const FusedLevel L
     }
     if (!ALIAS) push_nonzero(score != 0, e);
   };
-  auto fast_batch = [&](bool valid, uint32_t e) {
+  // Candidates travel through the per-wave queues as TILE OFFSETS k = r * tpitch + (x - xbase) (the pixel's byte
+  // offset from the first classified row's tile row): the prefilter scans the tile linearly, the pretest and FAST
+  // address the pixel as tile3 + k, and (x, r) is recovered by one multiply-high where a corner is queued.
+  const lds_u8 *tile3 = tile0 + 3 * tpitch;
+  const uint32_t tp_recip = L.tp_recip;
+  auto fast_batch = [&](bool valid, uint32_t k) {
     bool corner = false;
-    const int x = e & 0xffff, r = e >> 16;
     // (a one-sided test keyed on which compass side fired was measured: 16 % of the candidates fire on
     //  both sides, so nearly every 64-lane batch needed the second pass and it was slower)
-    if (valid) corner = fast9_mm(tile + (r + 3) * tpitch + x, tpitch, thr);
+    if (valid) corner = fast9_mm(tile3 + k, tpitch, thr);
+    const int r = (int)__umulhi(k, tp_recip);
+    const int x = (int)k - r * tpitch + xbase;
+    const uint32_t e = (uint32_t)x | ((uint32_t)r << 16);
     // Fast.h:172: only x < w-B is scored; over-classified columns keep 0xff
     const bool toh = corner && x < L.xscore;
     if (!ALIAS) {
@@ -531,9 +537,14 @@ __device__ __forceinline__ void strip_body(const StripArgs A, const FusedLevel L
   const bool aligned4 = ((B | Lxend) & 3) == 0;    // the classified range's edges fall on dword boundaries
 
   // exact compass pretest of the 4 pixels of one group (x0 % 4 == 0), survivors -> qf
-  auto pretest_batch = [&](bool valid, uint32_t key) {
-    const int x0 = key & 0xffff, r = key >> 16;
-    const lds_u8 *pb = tile + (r + 3) * tpitch + x0 - 4;     // (left neighbour first: DS offsets are unsigned)
+  // (the linear prefilter also passes groups of the halo columns: they are dropped here, where x is known)
+  const uint32_t cspan = (uint32_t)((cxb + 3) & ~3) - (uint32_t)(cxa & ~3);   // dword groups that hold classified columns
+  const int xrel = xbase - (cxa & ~3);
+  auto pretest_batch = [&](const bool lane_valid, uint32_t key) {
+    const int x0r = (int)key - (int)__umulhi(key, tp_recip) * tpitch + xrel;   // x0 - (cxa & ~3)
+    const bool valid = lane_valid && (uint32_t)x0r < cspan;
+    const int x0 = x0r + (cxa & ~3);
+    const lds_u8 *pb = tile3 + key - 4;                      // (left neighbour first: DS offsets are unsigned)
     const uint32_t wl = *(const lds_u32 *)pb;
     const uint32_t wc = *(const lds_u32 *)(pb + 4);
     const uint32_t wr = *(const lds_u32 *)(pb + 8);
@@ -678,23 +689,12 @@ __device__ __forceinline__ void strip_body(const StripArgs A, const FusedLevel L
     // vertical compass points AND one of its horizontal ones differ from it by more than t, so the
     // byte-wise SADs of the group against the rows 3 above/below and the columns 3 left/right must
     // exceed t on both axes (v_sad_u8 sums |a-b| over the 4 bytes, an upper bound of each term).
-    const int xs = cxa & ~3;                        // dword-aligned start column
-    // One lane = one 4-pixel group, 256 columns per wave step: `nfull` steps with all lanes inside the
-    // tile's columns and one tail step with the lanes past cxb masked off, so that the full steps need
-    // no per-lane bounds test (their compare lands directly in VCC = the ballot).
-    const int nfull = (cxb - xs) >> 8, rem = (cxb - xs) & 255;
-    // The tail step of a row uses only rem / 4 lanes (VGA: 24, 61, 39, 21, 6, 57, 46, 37 of 64 for levels 0..7), so
-    // the tails of `tm` = 64 / (rem / 4) consecutive rows (plan: L.tail_rows) share one wave step: lane ->
-    // (row lrow, group lcol) of the step.
-    const int tg = (rem + 3) >> 2;
-    const int tm = L.tail_rows;
-    const int lrow = tm > 1 ? (int)__umulhi((uint32_t)lane, L.tail_recip) : 0;
-    const int lcol = lane - lrow * tg;
-    const bool tail_lane = lrow < tm && 4 * lcol < rem;
-    const int tail_ofs = lrow * tpitch + 4 * lcol;
-    const uint32_t tail_key = ((uint32_t)lrow << 16) + (uint32_t)(4 * lcol);
-    // `pm` = the group's centre dword MINUS 4 bytes: the three dwords of the row are then pm + 0 / 4 / 8 — DS offsets
-    // are unsigned, a loop pointer at the centre costs a v_add for the left neighbour in every step
+    // The tile's rows are contiguous in LDS, so the classified rows [r_lo, r_hi) are ONE run of bytes: a wave step
+    // covers 256 consecutive bytes of it (one lane = one aligned 4-pixel group, halo columns included — 4 .. 16 %
+    // of a row, dropped by the pretest), the steps go round-robin to the waves, and only the run's last step is
+    // partial.  Nothing is set up per row, the three pointers and the key advance by constants.
+    const int lin_lo = r_lo * tpitch, lin_n = max(r_hi - r_lo, 0) * tpitch;
+    const int nfull = lin_n >> 8, rem = lin_n & 255;
     auto prefilter_step = [&](const lds_u8 *pm, const lds_u8 *pu, const lds_u8 *pd, bool lane_ok, uint32_t key) {
       // aligned dword reads; lanes past the tile's columns read harmless bytes of the next tile row
       const uint32_t wl = *(const lds_u32 *)pm;
@@ -715,31 +715,24 @@ __device__ __forceinline__ void strip_body(const StripArgs A, const FusedLevel L
         if (!(ablate & 16)) pretest_batch(true, qg[ng + lane]);
       }
     };
-    // (Unrolling the full steps so that their 256-byte strides become immediate DS offsets instead of three
+    // (Unrolling the full steps so that their strides become immediate DS offsets instead of three
     //  pointer increments was tried: every copy of the step inlines the pretest / FAST batch code behind it,
     //  4859 -> 6481 instructions for 3 VALU per step.)
-    if (nfull > 0)
-      for (int r = r_lo + wave; r < r_hi; r += WAVES) {
-        const lds_u8 *pm = tile + (r + 3) * tpitch + xs + 4 * lane - 4;
-        const lds_u8 *pu = pm + 4 - 3 * tpitch, *pd = pm + 4 + 3 * tpitch;
-        uint32_t key = pack_xy(xs, r) + (uint32_t)(4 * lane);    // column of this lane's group | row << 16
-        for (int it = 0; it < nfull; it++) {
-          prefilter_step(pm, pu, pd, true, key);
-          pm += 256;
-          pu += 256;
-          pd += 256;
-          key += 256;
-        }
+    {
+      const lds_u8 *pm = tile3 + lin_lo + 256 * wave + 4 * lane - 4;
+      const lds_u8 *pu = pm + 4 - 3 * tpitch, *pd = pm + 4 + 3 * tpitch;
+      uint32_t key = (uint32_t)(lin_lo + 256 * wave + 4 * lane);
+      for (int st = wave; st < nfull; st += WAVES) {
+        prefilter_step(pm, pu, pd, true, key);
+        pm += 256 * WAVES;
+        pu += 256 * WAVES;
+        pd += 256 * WAVES;
+        key += 256 * WAVES;
       }
-    if (rem) {
-      const int xt0 = xs + (nfull << 8);
-      for (int r = r_lo + wave * tm; r < r_hi; r += WAVES * tm) {
-        const bool ok = tail_lane && lrow < r_hi - r;
-        const lds_u8 *pc = tile + (r + 3) * tpitch + xt0 + (ok ? tail_ofs : 0);
-        prefilter_step(pc - 4, pc - 3 * tpitch, pc + 3 * tpitch, ok, pack_xy(xt0, r) + tail_key);
-      }
+      // (after the loop the pointers stand at the first step >= nfull of this wave: the partial step for one wave)
+      if (rem && (nfull & (WAVES - 1)) == wave) prefilter_step(pm, pu, pd, 4 * lane < rem, key);
     }
-    if (ng > 0 && !(ablate & 16)) pretest_batch(lane < ng, lane < ng ? qg[lane] : pack_xy(xs, r_lo));
+    if (ng > 0 && !(ablate & 16)) pretest_batch(lane < ng, lane < ng ? qg[lane] : (uint32_t)lin_lo);
     ng = 0;
     // left-over candidates (< 64): one partial batch per wave — cheaper than a barrier to merge them
     if (nf > 0 && !(ablate & 2)) fast_batch(lane < nf, qf[min(lane, nf - 1)]);

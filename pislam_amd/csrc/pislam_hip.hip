@@ -1119,12 +1119,7 @@ bool build_fused_plan_rows(const pislam_ctx *c, const pislam_frontend_params *p,
       L.tpitch = (ncols + lead + 8 + 15) & ~15;
     }
     L.vpr_recip = (uint32_t)(((1ull << 32) + (L.tpitch / 16) - 1) / (L.tpitch / 16));
-    {
-      // prefilter tail step (strip_body): 4-pixel groups of a row left over after the full 256-column steps
-      const int xs = p->border & ~3, tg = ((((L.xend - xs) & 255)) + 3) >> 2;
-      L.tail_rows = tg > 1 ? 64 / tg : 1;   // (tg == 1: the reciprocal does not fit 32 bits)
-      L.tail_recip = tg > 0 ? (uint32_t)(((1ull << 32) + tg - 1) / tg) : 0;
-    }
+    L.tp_recip = (uint32_t)(((1ull << 32) + L.tpitch - 1) / L.tpitch);
     strips += L.nstrips;
     slots += L.nstrips * (R / 2) * L.nbx;
     // scan fallbacks reuse the image tile: row buffers of R/2 x nbx dwords, or per-cell results (<= one

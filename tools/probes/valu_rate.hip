@@ -27,6 +27,16 @@ __global__ void k(uint32_t *out, int iters) {
         if (OP == 9) asm volatile("v_pk_mul_lo_u16 %0, %0, %1" : "+v"(a[i]) : "v"(a[(i + 1) & 7]));
         if (OP == 10) asm volatile("v_mad_u32_u24 %0, %0, %1, %0" : "+v"(a[i]) : "v"(a[(i + 1) & 7]));
         if (OP == 11) asm volatile("v_add3_u32 %0, %0, %1, %0" : "+v"(a[i]) : "v"(a[(i + 1) & 7]));
+        if (OP == 12) asm volatile("v_mul_hi_u32 %0, %0, %1" : "+v"(a[i]) : "v"(a[(i + 1) & 7]));
+        if (OP == 13) asm volatile("v_mul_u32_u24 %0, %0, %1" : "+v"(a[i]) : "v"(a[(i + 1) & 7]));
+        if (OP == 14) asm volatile("v_mul_hi_u32_u24 %0, %0, %1" : "+v"(a[i]) : "v"(a[(i + 1) & 7]));
+        if (OP == 15) asm volatile("v_lerp_u8 %0, %0, %1, %0" : "+v"(a[i]) : "v"(a[(i + 1) & 7]));
+        if (OP == 16) asm volatile("v_mbcnt_lo_u32_b32 %0, %1, %0" : "+v"(a[i]) : "v"(a[(i + 1) & 7]));
+        if (OP == 17) asm volatile("v_pk_add_u16 %0, %0, %1" : "+v"(a[i]) : "v"(a[(i + 1) & 7]));
+        if (OP == 18) asm volatile("v_add_u32_sdwa %0, %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD" : "+v"(a[i]) : "v"(a[(i + 1) & 7]));
+        if (OP == 19) asm volatile("v_cvt_f32_u32 %0, %1" : "+v"(a[i]) : "v"(a[(i + 1) & 7]));
+        if (OP == 20) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(a[i]) : "v"(a[(i + 1) & 7]));
+        if (OP == 21) asm volatile("v_bitop3_b32 %0, %0, %1, %0 bitop3:0xc8" : "+v"(a[i]) : "v"(a[(i + 1) & 7]));
       }
     }
   }
@@ -91,5 +101,15 @@ int main() {
   run<9>("v_pk_mul_lo_u16", d);
   run<10>("v_mad_u32_u24", d);
   run<11>("v_add3_u32", d);
+  run<12>("v_mul_hi_u32", d);
+  run<13>("v_mul_u32_u24", d);
+  run<14>("v_mul_hi_u32_u24", d);
+  run<15>("v_lerp_u8", d);
+  run<16>("v_mbcnt_lo", d);
+  run<17>("v_pk_add_u16", d);
+  run<18>("v_add_u32_sdwa", d);
+  run<19>("v_cvt_f32_u32", d);
+  run<20>("v_mul_f32", d);
+  run<21>("v_bitop3_b32", d);
   return 0;
 }
