@@ -103,6 +103,7 @@ struct pislam_ctx {
   int opt_dump_score = 0;    // fused pipeline: also materialise the score map (parity hook)
   int opt_strip_rows = 0;    // fused pipeline: strip height override (0 = heuristic)
   int opt_ablate = 0;        // profiling only: skip phases of the fused kernel (results invalid)
+  int opt_bucket_round_up = 0;  // profiling: bucket mode always rounds the strip height up to whole bucket rows (round-2 rule)
   int opt_orb_chunks = 0;    // fused pipeline: workgroups per pyramid in k_gather_orb (0 = heuristic)
   uint32_t last_strips = 0;  // strips of the last fused batch call (pislam_frontend_last_stats)
   int opt_repeat_strips = 1; // profiling: launch the strip kernel n times inside the stage-0 event bracket
@@ -490,6 +491,8 @@ PISLAM_EXPORT int pislam_ctx_set_option(pislam_ctx *c, const char *key, int valu
     c->opt_orb_in_strip = value != 0;
   } else if (!strcmp(key, "dist_rccl_single")) {
     c->opt_dist_rccl_single = value != 0;
+  } else if (!strcmp(key, "bucket_round_up")) {
+    c->opt_bucket_round_up = value != 0;
   } else if (!strcmp(key, "orb_chunks")) {
     if (value < 0 || value > 1024) return fail(c, PISLAM_ERR_INVALID, "orb_chunks must be 0..1024");
     c->opt_orb_chunks = value;
@@ -1100,11 +1103,15 @@ bool build_fused_plan_rows(const pislam_ctx *c, const pislam_frontend_params *p,
     }
     if (p->log_bucket_size) {            // strips hold whole bucket rows
       const int bs = 1 << p->log_bucket_size;
-      if (c->opt_strip_rows == 0 && c->opt_alias)
+      if (c->opt_strip_rows == 0 && c->opt_alias) {
         // heuristic height: round UP to whole bucket rows (16-px buckets: 32-row strips — measured 0.315 ms
-        // vs 0.371 ms with 16-row strips, although level 0 then keeps only 4 workgroups per CU)
-        R = std::min(std::max(bs, 32), ((R + bs - 1) / bs) * bs);
-      else
+        // vs 0.371 ms with 16-row strips) where that still fits the residency budget, DOWN on the levels where it
+        // does not: the launch has ONE LDS size, a single level over the budget costs every level its fifth workgroup
+        const int up = std::min(std::max(bs, 32), ((R + bs - 1) / bs) * bs), down = std::max(bs, (R / bs) * bs);
+        const int tp = (xend_l - p->border + ((p->border - 4) & 15) + 4 + 8 + 15) & ~15;
+        const long need = (long)(pf::WAVES * pf::QCAP + pf::QH_SHARED) * 4 + (long)(up + 10) * tp;
+        R = (c->opt_bucket_round_up || need <= 160 * 1024 / alias_wgs - 1280) ? up : down;
+      } else
         R = std::max(bs, (R / bs) * bs);
     }
     L.R = R;
