@@ -702,10 +702,16 @@ __device__ __forceinline__ void strip_body(const StripArgs A, const FusedLevel L
       const uint32_t wr = *(const lds_u32 *)(pm + 8);
       const uint32_t wu = *(const lds_u32 *)pu;
       const uint32_t wd = *(const lds_u32 *)pd;
-      const uint32_t sv = max(__builtin_amdgcn_sad_u8(wu, wc, 0u), __builtin_amdgcn_sad_u8(wd, wc, 0u));
-      const uint32_t sh = max(__builtin_amdgcn_sad_u8(__builtin_amdgcn_alignbyte(wc, wl, 1), wc, 0u),
-                              __builtin_amdgcn_sad_u8(__builtin_amdgcn_alignbyte(wr, wc, 3), wc, 0u));
-      const bool g = lane_ok && (min(sv, sh) > (uint32_t)thr);
+      // both axes in one register: v_sad_hi_u8 puts its sum into the high half ({left : up}, {right : down}), one packed
+      // max gives {max(left, right) : max(up, down)}, an SDWA min of the two halves the value to compare (7 VALU
+      // instead of 8: two v_max + v_min)
+      const uint32_t a = __builtin_amdgcn_sad_hi_u8(__builtin_amdgcn_alignbyte(wc, wl, 1), wc, __builtin_amdgcn_sad_u8(wu, wc, 0u));
+      const uint32_t b = __builtin_amdgcn_sad_hi_u8(__builtin_amdgcn_alignbyte(wr, wc, 3), wc, __builtin_amdgcn_sad_u8(wd, wc, 0u));
+      typedef unsigned short us2v __attribute__((ext_vector_type(2)));
+      const uint32_t mm = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(us2v, a), __builtin_bit_cast(us2v, b)));
+      uint32_t lo;
+      asm("v_min_u32_sdwa %0, %1, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:WORD_1" : "=v"(lo) : "v"(mm));
+      const bool g = lane_ok && (lo > (uint32_t)thr);
       const uint64_t m = __ballot(g);
       if (m == 0) return;
       if (g) qg[ng + ballot_rank(m)] = key;                               // pack_xy(x0, r)
