@@ -300,6 +300,34 @@ __device__ __forceinline__ int patch_umax(int ady) {
   return (int)((tab >> (4 * ady)) & 0xf);
 }
 
+// The circle mask of the moment patch as dot-product weights, one row of the table per patch row r (dy = r - 15; row 31
+// idle = all zero): dwords 0..7 hold 1 in every byte (dx = 4 k + b - 15) that belongs to the patch, dwords 8..15 hold
+// |dx| there (Orb.h:118-126).  Built at compile time; the ORB lanes load their row (computing the 16 words per lane
+// cost ~150 VALU per wave and workgroup: 8 % of k_gather_orb).
+struct OrbMaskTab {
+  uint32_t v[32][16];
+};
+static constexpr OrbMaskTab make_orb_mask_tab() {
+  OrbMaskTab t{};
+  constexpr int UMAX[16] = {15, 15, 15, 15, 15, 15, 14, 14, 13, 13, 12, 11, 10, 9, 7, 5};   // == patch_umax
+  for (int r = 0; r < 31; r++) {
+    const int dy = r - 15, u = UMAX[dy < 0 ? -dy : dy];
+    for (int k = 0; k < 8; k++) {
+      uint32_t m = 0, w = 0;
+      for (int b = 0; b < 4; b++) {
+        const int dx = 4 * k + b - 15, adx = dx < 0 ? -dx : dx;
+        if (adx <= u) {
+          m |= 1u << (8 * b);
+          w |= (uint32_t)adx << (8 * b);
+        }
+      }
+      t.v[r][k] = m;
+      t.v[r][8 + k] = w;
+    }
+  }
+  return t;
+}
+
 // NEON vrecpe.f32 (Orb.h:329): ARM ARM FPRecipEstimate, 8-bit, flush-to-zero.
 __device__ __forceinline__ float vrecpe_f32(float f) {
   const uint32_t u = __float_as_uint(f), sign = u & 0x80000000u, e = (u >> 23) & 0xff,

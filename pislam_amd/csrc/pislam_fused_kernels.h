@@ -213,21 +213,12 @@ __device__ __forceinline__ OrbLane orb_lane(int lane, int vstep) {
   OrbLane G;
   G.half = lane >> 5;
   G.r = lane & 31;
-  const int dy = G.r - 15;
-  const int u = (G.r < 31) ? patch_umax(dy < 0 ? -dy : dy) : -1;
+  // (the row's 16 mask words come from a compile-time table: four 16-byte loads instead of ~150 VALU)
+  const uint32_t *row = ::g_orb_masks.v[G.r];        // defined by the including TU
 #pragma unroll
   for (int k = 0; k < 8; k++) {
-    uint32_t m = 0, w = 0;
-#pragma unroll
-    for (int b = 0; b < 4; b++) {
-      const int dx = 4 * k + b - 15, adx = dx < 0 ? -dx : dx;
-      if (adx <= u) {
-        m |= 1u << (8 * b);
-        w |= (uint32_t)adx << (8 * b);
-      }
-    }
-    G.m01[k] = m;
-    G.mdx[k] = w;
+    G.m01[k] = row[k];
+    G.mdx[k] = row[8 + k];
   }
 #pragma unroll
   for (int j = 0; j < 3; j++) {
@@ -1490,7 +1481,7 @@ __device__ __forceinline__ void orb_role(const FusedParams &P, const uint8_t *__
 //   - otherwise queued and described here: orb_fetch / orb_describe, two keypoints per wave iteration, the
 //     next pair's loads in flight while the current pair is processed.
 // ===========================================================================
-__global__ __launch_bounds__(256) void k_gather_orb(
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7))) void k_gather_orb(
     const FusedParams P, const uint8_t *__restrict__ pyramids, size_t pyr_stride,
     const uint32_t *__restrict__ stage_kp, const uint32_t *__restrict__ strip_count,
     const uint32_t *__restrict__ stage_desc,

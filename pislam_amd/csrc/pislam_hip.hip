@@ -43,6 +43,7 @@ __device__ const BriefOfsTab g_brief_ofs = make_brief_ofs();
 
 #include "pislam_dev.h"
 __device__ const pdev::VrecpeTab g_vrecpe_tab = pdev::make_vrecpe_tab();   // used by pf::k_gather_orb
+__device__ const pdev::OrbMaskTab g_orb_masks = pdev::make_orb_mask_tab();  // used by pf::orb_lane
 #include "pislam_stage_kernels.h"
 #include "pislam_fused_kernels.h"
 static_assert(brief_row_ofs(0) == pf::orb_row_ofs(0) && brief_row_ofs(15) == pf::orb_row_ofs(15) &&
