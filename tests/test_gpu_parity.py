@@ -880,6 +880,27 @@ def test_bench_two_ranks_on_one_gpu_does_not_deadlock():
 
 
 @pytest.mark.gpu
+def test_bench_eight_ranks_self_launched_on_one_gpu():
+    """The rank count of BASELINE configs[2] through the path the driver takes without torchrun: `python bench.py
+    --gpus 8` starts its own supervised workers (gloo test mode: the eight ranks share this box's one GPU, the count
+    exchange goes through torch.distributed); one JSON line with n_gpus 8, the global batch, per-rank step times and
+    an empty fallback list."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "6", "--warmup", "2", "--batch", "8",
+           "--dist-backend", "gloo", "--no-cpu-baseline", "--spin-s", "0.2"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=400, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    c = d["config"]
+    assert d["n_gpus"] == 8 and d["steps"] == 6 and d["value"] > 0 and c["global_batch"] == 64
+    assert c["dist_fallbacks"] == [] and c["ms_per_step_ranks"]["max"] >= c["ms_per_step_ranks"]["min"] > 0
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("nsub", [2, 3, 5])
 def test_sub_batch_pipelining_inside_the_call_is_exact(gpu_ctx, orc, nsub):
     """Option "sub_batches": the batch call cuts its batch into sub-batches whose overflow pass + gather/ORB

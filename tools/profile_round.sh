@@ -28,6 +28,7 @@ python $root/bench.py --steps 50 --warmup 10 --workload 720p-build --batch 64 --
 python $root/bench.py --steps 50 --warmup 10 --streams 1 --no-cpu-baseline > $out/bench_vga_streams1.json 2> /dev/null
 python $root/bench.py --steps 50 --warmup 10 --log-bucket-size 4 --bucket-limit 3 --no-cpu-baseline > $out/bench_vga_buckets43.json 2> /dev/null
 python $root/bench.py --gpus 2 --dist-backend gloo --steps 20 --warmup 5 --batch 128 --no-cpu-baseline > $out/bench_vga_2ranks_one_gpu_gloo.json 2> $out/bench_2ranks.err
+python $root/bench.py --gpus 8 --dist-backend gloo --steps 20 --warmup 5 --batch 32 --no-cpu-baseline > $out/bench_vga_8ranks_one_gpu_gloo.json 2> /dev/null
 for w in vga 1280x960 720p-build; do
   b=256; [ $w = 720p-build ] && b=64
   rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace_$w -o p -- python $root/bench.py --steps 20 --warmup 5 --no-cpu-baseline --workload $w --batch $b > $out/bench_under_rocprof_$w.json 2>/dev/null
