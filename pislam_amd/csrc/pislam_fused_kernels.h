@@ -469,19 +469,29 @@ __device__ __forceinline__ void strip_body(const StripArgs A, const FusedLevel L
     }
   };
   // plain layout: corners -> shq_h, Harris writes the score tile and queues the non-zero scores in shq_n.
-  // ALIAS layout: ONE queue (shq_h, QH_SHARED entries) whose entries carry their score in the top byte:
-  // FAST appends corners with score 0 and over-classified pixels with 0xff, Harris scores the entries
-  // appended since `h_begin` in place, the strip above leaves its carried entries at the front.
+  // ALIAS layout: ONE queue (shq_h, QH_SHARED entries): FAST appends corners as tile offsets, Harris rewrites the
+  // entries appended since `h_begin` in place as x | row << 16 | score << 24 (0xff for over-classified columns), the
+  // strip above leaves its carried entries (already in that form) at the front.
   auto harris_batch = [&](bool valid, uint32_t e, int at) {
     uint8_t score = 0;
-    const bool todo = valid && (!ALIAS || (e >> 24) == 0);
-    if (todo) {
-      const int x = e & 0xffff, r = (e >> 16) & 0xff;
-      score = (ablate & 32) ? (uint8_t)200 : harris_score_mm(tile + r * tpitch + x - 3, tpitch, hthr);
-      if (ALIAS) shq_h[at] = e | ((uint32_t)score << 24);
-      else sc[r * pitch + x] = score;
+    if (ALIAS) {
+      // the entry is still the corner's tile offset k (see fast_batch): (x, r) by one multiply-high here — a third as
+      // many batches as FAST runs — and the window's top-left corner is tile0 + k - 3
+      if (valid) {
+        const int r = (int)__umulhi(e, L.tp_recip);
+        const int x = (int)e - r * tpitch + xbase;
+        // Fast.h:172: only x < w-B is scored; over-classified columns keep 0xff
+        score = x >= L.xscore ? (uint8_t)0xff : (ablate & 32) ? (uint8_t)200 : harris_score_mm(tile0 + e - 3, tpitch, hthr);
+        shq_h[at] = (uint32_t)x | ((uint32_t)r << 16) | ((uint32_t)score << 24);
+      }
+    } else {
+      if (valid) {
+        const int x = e & 0xffff, r = (e >> 16) & 0xff;
+        score = (ablate & 32) ? (uint8_t)200 : harris_score_mm(tile + r * tpitch + x - 3, tpitch, hthr);
+        sc[r * pitch + x] = score;
+      }
+      push_nonzero(score != 0, e);
     }
-    if (!ALIAS) push_nonzero(score != 0, e);
   };
   // Candidates travel through the per-wave queues as TILE OFFSETS k = r * tpitch + (x - xbase) (the pixel's byte
   // offset from the first classified row's tile row): the prefilter scans the tile linearly, the pretest and FAST
@@ -493,12 +503,15 @@ __device__ __forceinline__ void strip_body(const StripArgs A, const FusedLevel L
     // (a one-sided test keyed on which compass side fired was measured: 16 % of the candidates fire on
     //  both sides, so nearly every 64-lane batch needed the second pass and it was slower)
     if (valid) corner = fast9_mm(tile3 + k, tpitch, thr);
-    const int r = (int)__umulhi(k, tp_recip);
-    const int x = (int)k - r * tpitch + xbase;
-    const uint32_t e = (uint32_t)x | ((uint32_t)r << 16);
-    // Fast.h:172: only x < w-B is scored; over-classified columns keep 0xff
-    const bool toh = corner && x < L.xscore;
+    // ALIAS: the corner is queued as its tile offset; the Harris phase turns it into (x, r, score).  Plain layout:
+    // (x, r) is needed here (score tile, NMS queue, over-classified columns: Fast.h:172).
+    uint32_t e = k;
+    bool toh = corner;
     if (!ALIAS) {
+      const int r = (int)__umulhi(k, tp_recip);
+      const int x = (int)k - r * tpitch + xbase;
+      e = (uint32_t)x | ((uint32_t)r << 16);
+      toh = corner && x < L.xscore;
       if (corner && !toh) sc[r * pitch + x] = 0xff;
       push_nonzero(corner && !toh, e);
     }
@@ -510,7 +523,7 @@ __device__ __forceinline__ void strip_body(const StripArgs A, const FusedLevel L
       if (lane == 0) base = (int)lds_add_rtn(&sh_ctr[0], (uint32_t)cnt);
       base = __builtin_amdgcn_readfirstlane(base);
       if (base + cnt <= qcap) {
-        if (q) shq_h[base + ballot_rank(m)] = (ALIAS && !toh) ? e | 0xff000000u : e;
+        if (q) shq_h[base + ballot_rank(m)] = e;
       } else {                                     // queue full
         if (lane == 0) {
           atomicMin(&sh_ctr[1], (uint32_t)base);   // entries below `base` stay valid
