@@ -6,13 +6,14 @@
 // from HBM once and the reference's score map (`out`, Fast.h:54 / Fast.h:166) is never materialised
 // in HBM:
 //
-//   phase A0 SAD prefilter on every 4-pixel group (necessary condition of the compass test)
+//   phase A0 SAD prefilter on every 4-pixel group (necessary condition of the compass test): the classified
+//            rows are scanned as one linear run of tile bytes, 256 per wave step
 //   phase A1 exact "two adjacent compass points" test on the surviving groups, 4 pixels per lane on
 //            packed u16; survivors are compacted per wave (ballot + mbcnt) into a wave-private LDS queue
 //   phase B  whenever a queue holds >= 64 entries the wave pops 64 and runs the full FAST-9 arc test
 //            on densely packed lanes (result-identical to Fast.h:63-147); corners go to ONE queue per
-//            workgroup
-//   phase C  all waves score that queue: 6x6 Harris (Harris.h:80-248)
+//            workgroup.  (Candidates travel through A0 / A1 / B as tile byte offsets.)
+//   phase C  all waves score that queue: 6x6 Harris (Harris.h:80-248); entries become x | row << 16 | score << 24
 //   phase D  2x2-block NMS (Fast.h:228-312), driven by the queue of non-zero scores; survivors are
 //            ranked into block-raster order and written to the strip's slots of a staging buffer
 //
