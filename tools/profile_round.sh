@@ -51,3 +51,6 @@ P
 # per-phase instruction counts of the strip kernel (cumulative ablations of the profiling build)
 (cd $root && bash tools/pmc_ablate.sh --streams 1) > $out/phase_ablation.txt 2>&1
 rm -rf $root/gpurun_out/abl_*
+# workgroup wall-clock share of the strip kernel's phases (clock64 around the phases of every strip, profiling build):
+# cycles per strip of one eager launch (the first lines: the later ones come from bench.py's 16-launch bracket)
+python $root/bench.py --steps 3 --warmup 1 --streams 1 --graph 0 --no-cpu-baseline --ablate 8192 2>&1 | grep "cycles/strip" | head -3 > $out/phase_cycles.txt
