@@ -382,7 +382,8 @@ __device__ __forceinline__ void strip_body(const StripArgs A, const FusedLevel L
   auto mark = [&](int phase) {
     if (HOOKS && prof && tid == 0) {
       const long long t = clock64();
-      prof[phase] += (unsigned long long)(t - t_last);
+      // (a no-return atomic: a read-modify-write would stall wave 0 for a memory round trip at every mark)
+      (void)__hip_atomic_fetch_add(&prof[phase], (unsigned long long)(t - t_last), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       t_last = t;
     }
   };
@@ -900,12 +901,34 @@ __device__ __forceinline__ void strip_body(const StripArgs A, const FusedLevel L
       };
       if (A.lbs == 0) {
         uint32_t my_rank = 0;
-        for (int i = tid; i < ns; i += NT) {
-          const uint32_t key = shq_k[i];
-          int rank = 0;
-          for (int j = 0; j < ns; j++) rank += shq_k[j] < key;
-          stage_kp[strip_slot + rank] = shq_s[i] + add_xy;
-          my_rank = (uint32_t)rank;
+        if (ns <= 64) {
+          // (the usual case, ~17 survivors: one wave, the keys in its lanes, v_readlane instead of an LDS read per
+          //  comparison — the loop is a chain of LDS latencies otherwise, on the workgroup's critical path: the
+          //  other waves wait for wave 0 at the next strip's first barrier)
+          if (wave == 0) {
+            const uint32_t key = lane < ns ? shq_k[lane] : 0xffffffffu;
+            int rank = 0;
+            // four independent comparisons per trip (lanes >= ns hold 0xffffffff: never smaller): a single wave issues
+            // about one instruction per five cycles, the loop is this phase's critical path
+            int r1 = 0, r2 = 0, r3 = 0;
+            for (int j = 0; j < ns; j += 4) {
+              rank += (uint32_t)__builtin_amdgcn_readlane((int)key, j) < key;
+              r1 += (uint32_t)__builtin_amdgcn_readlane((int)key, j + 1) < key;
+              r2 += (uint32_t)__builtin_amdgcn_readlane((int)key, j + 2) < key;
+              r3 += (uint32_t)__builtin_amdgcn_readlane((int)key, j + 3) < key;
+            }
+            rank += r1 + r2 + r3;
+            if (lane < ns) stage_kp[strip_slot + rank] = shq_s[lane] + add_xy;
+            my_rank = (uint32_t)rank;
+          }
+        } else {
+          for (int i = tid; i < ns; i += NT) {
+            const uint32_t key = shq_k[i];
+            int rank = 0;
+            for (int j = 0; j < ns; j++) rank += shq_k[j] < key;
+            stage_kp[strip_slot + rank] = shq_s[i] + add_xy;
+            my_rank = (uint32_t)rank;
+          }
         }
         if (tid == 0)
           strip_count[(size_t)pyr * A.strips_per_pyr + L.strip0 + s] = (uint32_t)ns | (orb ? STRIP_DESCRIBED : 0u);
