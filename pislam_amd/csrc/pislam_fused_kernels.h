@@ -633,9 +633,24 @@ __device__ __forceinline__ void strip_body(const StripArgs A, const FusedLevel L
         lds_u4 *dstv = (lds_u4 *)(tile0 + r_st0 * tpitch);
         const bool tail = (uint32_t)((y_lo + nrows - 1) * A.vstep + xbase + tpitch) > (uint32_t)lim;
         if (!tail) {
-          for (int i = tid; i < nvec; i += NT) {
-            const int row = (int)__umulhi((uint32_t)i, L.vpr_recip);
-            dstv[i] = *(const u32x4 *)(src0 + (uint32_t)(16 * i + row * gap));   // (a pyramid is < 2 GiB)
+          // All of a thread's loads are issued before the first LDS store (ST_MAX in flight per pass; a strip's
+          // R + 10 rows are ~5.3 vectors per thread: one pass).  Written as "load; store" per iteration the compiler
+          // waits for every load before its store — 5 memory round trips in a row on the FIRST strip of each run,
+          // whose rows no strip above could prefetch: 7.8 k of such a strip's cycles, on the workgroup's critical path.
+          constexpr int ST_MAX = 6;
+          for (int i0 = tid; i0 < nvec; i0 += NT * ST_MAX) {
+            u32x4 st[ST_MAX];
+#pragma unroll
+            for (int k = 0; k < ST_MAX; k++) {
+              const int i = i0 + NT * k;
+              if (i < nvec) {
+                const int row = (int)__umulhi((uint32_t)i, L.vpr_recip);
+                st[k] = *(const u32x4 *)(src0 + (uint32_t)(16 * i + row * gap));   // (a pyramid is < 2 GiB)
+              }
+            }
+#pragma unroll
+            for (int k = 0; k < ST_MAX; k++)
+              if (i0 + NT * k < nvec) dstv[i0 + NT * k] = st[k];
           }
         } else {
           for (int i = tid; i < nvec; i += NT) {
