@@ -1413,6 +1413,9 @@ __device__ __forceinline__ void orb_role(const FusedParams &P, const uint8_t *__
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int S = P.strips_per_pyr;
+  // (the lane's mask-table row is loaded FIRST: its memory round trip then runs under the strip-count loads of the
+  //  scan instead of standing between the gather part and the first patch fetch)
+  const OrbLane G = orb_lane(lane, P.vstep);
   // LDS carve: patches (4 waves x 2 x 1.5 KiB) | strip offsets (S+1) | this round's keypoints still to describe |
   // their final positions
   uint8_t *patches = osm;
@@ -1491,7 +1494,6 @@ __device__ __forceinline__ void orb_role(const FusedParams &P, const uint8_t *__
     const uint32_t nt = sh->ntodo;
     if (nt != 0 && !(P.ablate & 64)) {
       // ---- describe the rest: two keypoints per wave iteration ----
-      const OrbLane G = orb_lane(lane, vstep);
       const uint32_t npairs = (nt + 1) >> 1;
       // the two keypoints of pair `it`: packed words (0 when absent) and their final positions
       auto pair_of = [&](uint32_t it, uint32_t &p0, uint32_t &p1, uint32_t &q0, uint32_t &q1) {
