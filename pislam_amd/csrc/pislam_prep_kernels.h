@@ -72,16 +72,32 @@ __global__ __launch_bounds__(256) void k_gaussian5x5(const uint8_t *__restrict__
     return w;
   };
   if (vec_ok) {
-    for (int i = tid; i < (G_TH + 4) * 8; i += 256) {          // 8 x 16 bytes per row
-      const int r = i >> 3, v = i & 7;
+    // (G_TH + 4) * 8 = 288 vectors of 16 bytes: one per thread, a second one for the first 32 threads, plus the two
+    // halo dwords of every row (72 threads).  ALL of a thread's loads are issued before its first LDS store: written
+    // as "load; store" per loop iteration the compiler waits for each load before its store, and the workgroup's
+    // first barrier then sits behind three memory round trips in a row instead of one.
+    static_assert((G_TH + 4) * 8 <= 2 * 256 && (G_TH + 4) * 2 <= 256, "staging assumes <= 2 vectors and 1 halo dword per thread");
+    g_u32x4 v0, v1 = (g_u32x4)(0u);
+    uint32_t hd = 0;
+    const int i1 = tid + 256;
+    {
+      const int r = tid >> 3, v = tid & 7;
       const int gy = min(max(reflect101(y0 - 2 + r, height), 0), height - 1);
-      *(g_u32x4 *)&in[r * G_DW + 4 + 4 * v] = *(const g_u32x4 *)(s + (ptrdiff_t)gy * vstep_src + x0 + 16 * v);
+      v0 = *(const g_u32x4 *)(s + (ptrdiff_t)gy * vstep_src + x0 + 16 * v);
+    }
+    if (i1 < (G_TH + 4) * 8) {
+      const int r = i1 >> 3, v = i1 & 7;
+      const int gy = min(max(reflect101(y0 - 2 + r, height), 0), height - 1);
+      v1 = *(const g_u32x4 *)(s + (ptrdiff_t)gy * vstep_src + x0 + 16 * v);
     }
     if (tid < (G_TH + 4) * 2) {                                // the two halo dwords of every row
       const int r = tid >> 1, side = tid & 1;
       const int gy = min(max(reflect101(y0 - 2 + r, height), 0), height - 1);
-      in[r * G_DW + (side ? 36 : 3)] = stage_dword(s + (ptrdiff_t)gy * vstep_src, side ? x0 + G_TW : x0 - 4);
+      hd = stage_dword(s + (ptrdiff_t)gy * vstep_src, side ? x0 + G_TW : x0 - 4);
     }
+    *(g_u32x4 *)&in[(tid >> 3) * G_DW + 4 + 4 * (tid & 7)] = v0;
+    if (i1 < (G_TH + 4) * 8) *(g_u32x4 *)&in[(i1 >> 3) * G_DW + 4 + 4 * (i1 & 7)] = v1;
+    if (tid < (G_TH + 4) * 2) in[(tid >> 1) * G_DW + ((tid & 1) ? 36 : 3)] = hd;
   } else {
     for (int i = tid; i < (G_TH + 4) * G_NC; i += 256) {
       const int r = i / G_NC, q = i - r * G_NC;
