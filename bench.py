@@ -158,7 +158,8 @@ def build_parser():
     # ---- supervision of the N>1 run ----
     ap.add_argument("--wall-cap", type=float, default=900.0,
                     help="wall-clock cap in seconds for the whole run incl. every fallback attempt (rc != 0 beyond it)")
-    ap.add_argument("--attempt-timeout", type=float, default=300.0, help="N>1: hard timeout of one worker attempt")
+    ap.add_argument("--attempt-timeout", type=float, default=120.0,
+                    help="N>1: hard timeout of one worker attempt (a healthy attempt takes ~40 s; two retries fit the wall cap)")
     ap.add_argument("--selfcheck-timeout", type=float, default=60.0,
                     help="N>1 worker: hard timeout of the start-up self-check (2 untimed steps per pipeline incl. the exchange)")
     ap.add_argument("--worker", action="store_true", help=argparse.SUPPRESS)            # a supervisor's child
@@ -193,6 +194,30 @@ def _inject(stage: str, attempt: int, rank: int):
         if f[2] == "exit":
             os._exit(7)
         raise RuntimeError(f"injected failure at attempt {attempt}, stage {stage}")
+
+
+def _spin_seconds(spin_s: float, rank: int) -> float:
+    """Test hook: PISLAM_BENCH_SPIN_SKEW="<rank>:<factor>[,...]" multiplies --spin-s on chosen ranks, so that the CPU
+    tests can make the ranks' own clocks disagree about the length of the ramp."""
+    for item in filter(None, os.environ.get("PISLAM_BENCH_SPIN_SKEW", "").split(",")):
+        r, _, f = item.partition(":")
+        if int(r) == rank:
+            spin_s *= float(f)
+    return spin_s
+
+
+def clock_ramp(spin_s: float, group, agree_any) -> int:
+    """Untimed load for about `spin_s` seconds with the SAME number of groups on every rank.
+
+    `group()` may issue collectives (every step of an N>1 run ends with the count all-gather), so the decision to run
+    another group cannot be taken from a rank's own clock: before each group every rank says whether ITS clock wants
+    more, the flags are all-reduced (MAX, control plane), and all ranks run the group or all leave — the ramp lasts
+    until the slowest rank's spin_s has passed.  Returns the number of groups run (equal on every rank)."""
+    t0, groups = time.perf_counter(), 0
+    while agree_any(time.perf_counter() - t0 < spin_s):
+        group()
+        groups += 1
+    return groups
 
 
 def _free_port():
@@ -404,18 +429,31 @@ def worker_main(args):
                 xchg.start(fake)
             xchg.finish()
         _inject("run", args.attempt, rank)
+
+        def fake_group():                                 # what spin_once() x 8 + synchronize is to the real worker
+            for _ in range(8):
+                xchg.before_step()
+                xchg.start(fake)
+            xchg.finish()
+            time.sleep(0.002)
+
+        ramp_groups = clock_ramp(_spin_seconds(args.spin_s, rank), fake_group, agree_any)
         xchg.before_step()
         xchg.start(fake)
         allc = xchg.finish()
         ok = allc.tolist() == [100 * r + i for r in range(world) for i in range(B)]
+        coll_ok, coll = pdist.collectives_agree([xchg], world)
         if world > 1:
             torch.distributed.barrier()
+        if not coll_ok:
+            raise SystemExit(f"ranks issued different numbers of count all-gathers: {coll}")
         if rank == 0:
             print(json.dumps({"metric": METRIC, "value": None, "unit": "kp+desc/s", "n_gpus": world, "selftest": "spawn",
                               "exchange_ok": ok, "count_allgather": xchg.path,
                               "config": {"dist_fallbacks": dropped, "rccl_ranks": None, "attempt": args.attempt,
                                          "graph": args.graph, "streams": args.streams, "exchange": args.exchange,
-                                         "dist_backend": args.dist_backend}}), flush=True)
+                                         "dist_backend": args.dist_backend, "ramp_groups": ramp_groups,
+                                         "count_allgathers_per_rank": coll}}), flush=True)
         if world > 1:
             torch.distributed.destroy_process_group()
         return 0
@@ -653,14 +691,17 @@ def worker_main(args):
 
     # Clock ramp: the GPU idles at a few hundred MHz and needs a fraction of a second of load to reach its
     # sustained clocks — far longer than a handful of 0.4 ms steps.  Spin the same step, untimed, before the W
-    # warm-up steps so that W and K measure the steady state whatever their values.
-    # (No collective in here: the loop is time-based, so ranks run different iteration counts.)
+    # warm-up steps so that W and K measure the steady state whatever their values.  Every step of an N>1 run issues
+    # a count all-gather, so the number of ramp groups is AGREED between the ranks (clock_ramp), never taken from a
+    # rank's own clock: ranks that disagreed by one group would differ by 8*S collectives and deadlock.
     _inject("run", args.attempt, rank)
-    t_spin = time.perf_counter()
-    while time.perf_counter() - t_spin < args.spin_s:
+
+    def ramp_group():
         for _ in range(8):
             spin_once()
         torch.cuda.synchronize()
+
+    ramp_groups = clock_ramp(_spin_seconds(args.spin_s, rank), ramp_group, lambda f: agree_any(f, dev))
     for _ in range(args.warmup):
         step()
     finish_all()
@@ -692,6 +733,9 @@ def worker_main(args):
         pass
     dt_rank = dt
     dts = [dt]
+    coll_ok, coll = pdist.collectives_agree([P.xchg for P in pipes], world, dev)   # outside the timed region
+    if not coll_ok:
+        raise SystemExit(f"ranks issued different numbers of count all-gathers: {coll}")
     if world > 1:
         import torch.distributed as dist
         on_gpu = dist.get_backend() == "nccl"
@@ -874,6 +918,7 @@ def worker_main(args):
                 "strips_redone_by_overflow_pass": f"{deferred} of {nstrips}",
                 "max_keypoints": args.max_keypoints, "pyramids_over_capacity": capped,
                 "count_allgather": xchg.path,
+                "count_allgathers_per_rank": coll, "ramp_groups": ramp_groups,
                 "rccl_ranks": rccl_ranks,
                 "communicators_per_rank": 1 if (hub is not None or (world > 1 and not gloo_mode)) else 0,
                 "dist_fallbacks": fallbacks,

@@ -148,6 +148,7 @@ class CountExchange:
         self.ticket = [None] * sets          # C-ABI path: hub.issued when the set's last all-gather was issued
         self.last = None
         self.i = 0
+        self.collectives = 0                 # all-gathers this exchange has issued (any path): must stay equal across ranks
 
     @property
     def path(self) -> str:
@@ -176,6 +177,7 @@ class CountExchange:
         if self.world == 1 and not self.always:
             self.last = local_counts
             return
+        self.collectives += 1
         if self.ctx is not None:
             n = local_counts.numel()
             if self.outs[slot] is None or self.outs[slot].numel() != n * self.world:
@@ -201,6 +203,21 @@ class CountExchange:
                 p[0].wait()
                 self.pending[k] = None
         return self.last
+
+
+def collectives_agree(exchanges, world: int, device=None):
+    """Every rank must have issued the same number of count all-gathers (a rank that issued more leaves collectives
+    that never complete; one that issued fewer blocks its peers).  One all-gather of the totals on the control plane,
+    OUTSIDE any timed region.  Returns (ok, per-rank totals)."""
+    mine = sum(x.collectives for x in exchanges)
+    if world == 1 or not dist.is_initialized():
+        return True, [mine]
+    on_gpu = dist.get_backend() == "nccl"
+    t = torch.tensor([mine], dtype=torch.int64, device=device if on_gpu else None)
+    allt = [torch.zeros_like(t) for _ in range(world)]
+    dist.all_gather(allt, t)
+    tot = [int(x.item()) for x in allt]
+    return len(set(tot)) == 1, tot
 
 
 def global_offsets(all_counts: torch.Tensor) -> torch.Tensor:

@@ -13,13 +13,15 @@ import pytest
 from conftest import ROOT
 
 BENCH = os.path.join(ROOT, "bench.py")
-CLEAN = ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "PISLAM_BENCH_INJECT")
+CLEAN = ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "PISLAM_BENCH_INJECT", "PISLAM_BENCH_SPIN_SKEW")
 
 
-def run_bench(extra, inject=None, timeout=300):
+def run_bench(extra, inject=None, timeout=300, skew=None):
     env = {k: v for k, v in os.environ.items() if k not in CLEAN and not k.startswith("TORCHELASTIC_")}
     if inject:
         env["PISLAM_BENCH_INJECT"] = inject
+    if skew:
+        env["PISLAM_BENCH_SPIN_SKEW"] = skew
     t0 = time.monotonic()
     r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--selftest-spawn"] + extra, capture_output=True, text=True,
                        timeout=timeout, env=env, cwd=ROOT)
@@ -33,6 +35,37 @@ def test_clean_run_drops_nothing():
     assert d["n_gpus"] == 2 and d["exchange_ok"] is True
     assert d["config"]["dist_fallbacks"] == [] and d["config"]["attempt"] == 0 and "rccl_ranks" in d["config"]
     assert len([ln for ln in r.stdout.splitlines() if ln.startswith("{")]) == 1      # ONE JSON line
+
+
+@pytest.mark.parametrize("skew", ["1:3", "0:4"])
+def test_ranks_whose_clocks_disagree_about_the_ramp_issue_the_same_collectives(skew):
+    """The clock-ramp before the timed region is time-based and every step in it issues a count all-gather: a rank
+    whose own clock ends the ramp one group early would leave its peers with collectives that never complete
+    (round-3 bug: 8*S all-gathers of difference, a 300 s attempt lost).  One rank spins 3x / 4x longer here; the run
+    must complete on attempt 0, drop nothing, and every rank must report the same number of all-gathers."""
+    r, d, dt = run_bench(["--spin-s", "0.4", "--selfcheck-timeout", "10", "--attempt-timeout", "60"], skew=skew)
+    assert r.returncode == 0, r.stderr[-3000:]
+    c = d["config"]
+    assert c["attempt"] == 0 and c["dist_fallbacks"] == [] and d["exchange_ok"] is True
+    per_rank = c["count_allgathers_per_rank"]
+    assert len(per_rank) == 2 and per_rank[0] == per_rank[1]
+    # the ramp lasted as long as the SLOWEST rank wanted (>= 1.2 s of 2 ms groups), not as long as rank 0's clock said
+    assert c["ramp_groups"] >= 20 and per_rank[0] == 2 + 8 * c["ramp_groups"] + 1
+    assert "next rung" not in r.stderr
+
+
+def test_clock_ramp_runs_an_agreed_number_of_groups():
+    """Unit test of bench.clock_ramp: the continue decision comes from agree_any, not from the local clock."""
+    import bench
+    calls, votes = [], []
+
+    def agree(flag):                     # a peer that wants exactly 5 groups, whatever this rank's clock says
+        votes.append(flag)
+        return len(votes) <= 5
+
+    assert bench.clock_ramp(0.0, lambda: calls.append(1), agree) == 5
+    assert len(calls) == 5 and votes[0] is False
+    assert bench._spin_seconds(0.5, 1) == 0.5
 
 
 @pytest.mark.parametrize("inject, rungs, final", [
