@@ -107,6 +107,12 @@ def build_parser():
     ap.add_argument("--batch", type=int, default=256, help="pyramids per GPU")
     ap.add_argument("--distinct", type=int, default=0,
                     help="distinct synthetic pyramids generated per GPU (0 = all of the batch)")
+    ap.add_argument("--shared-input", action="store_true",
+                    help="all pipeline lanes read ONE input buffer (rounds 1-3; batch k+1's strips then stream the bytes batch k's "
+                         "gather+ORB is still reading: cache hits a stream of distinct batches never gets).  Default: every lane "
+                         "owns its batch — different pyramids (seeds), separate device buffers")
+    ap.add_argument("--gen-workers", type=int, default=0,
+                    help="processes generating the synthetic input (0 = the usable host cores, at most 16)")
     ap.add_argument("--max-keypoints", type=int, default=0,
                     help="keypoint / descriptor capacity per pyramid (0 = 4096 for vga, 8192 for the larger workloads)")
     ap.add_argument("--force-exchange", action="store_true",
@@ -504,19 +510,29 @@ def worker_main(args):
             lib_opts.append((key, val))
     lib_opts += extra_opts + [("ablate", args.ablate)]
 
-    # ---- the resident input (shared by every lane; the 720p workload builds its pyramids per lane) ----
-    host = d_frames = d_pyr0 = None
+    # ---- the resident input: every lane owns ITS batch — lane l of rank r holds the pyramids (seeds) number
+    # (r * S + l) * B ... — in a device buffer of its own (--shared-input: rounds 1-3, one buffer read by all lanes).
+    # The 720p workload builds its pyramids per lane from the lane's own frames.
+    nd = min(distinct, B)
+    nlane_in = 1 if args.shared_input else S
+    gen_workers = args.gen_workers or max(1, min(16, int(effective_cores()[1]) // max(1, min(world, 8))))
+    idx = [(rank * S + l) * B + i for l in range(nlane_in) for i in range(nd)]
+    host = d_frames = None
+    lane_in = []                                          # per input lane: device tensor (frames or pyramids)
     if args.workload == "720p-build":
-        fr = np.stack([synth.make_level0(first + i, w0, h0) for i in range(min(distinct, B))])
-        d_frames = torch.from_numpy(fr).to(dev)
-        if distinct < B:
-            d_frames = d_frames[torch.arange(B, device=dev) % distinct].contiguous()
+        fr = synth.make_many(idx, workers=gen_workers, kind="level0", w0=w0, h0=h0)
+        for l in range(nlane_in):
+            t = torch.from_numpy(fr[l * nd:(l + 1) * nd]).to(dev)
+            lane_in.append(t[torch.arange(B, device=dev) % nd].contiguous() if nd < B else t)
+        d_frames = lane_in[0]
     else:
         rows = synth.pyramid_rows(levels)
-        host = synth.make_batch(first, min(distinct, B), w0=w0, h0=h0, vstep=vstep, levels=levels)
-        d_pyr0 = torch.from_numpy(host).to(dev)
-        if distinct < B:
-            d_pyr0 = d_pyr0[torch.arange(B, device=dev) % distinct].contiguous()
+        hp = synth.make_many(idx, workers=gen_workers, w0=w0, h0=h0, vstep=vstep, levels=levels)
+        host = hp[:nd]                                    # lane 0's batch: the cpu_baseline sample
+        for l in range(nlane_in):
+            t = torch.from_numpy(hp[l * nd:(l + 1) * nd]).to(dev)
+            lane_in.append(t[torch.arange(B, device=dev) % nd].contiguous() if nd < B else t)
+        del hp
 
     # ---- batches in flight: the LIBRARY's pipeline object (pislam_pipeline_*, include/pislam_hip.h) — S lanes, each a
     # context (workspace) + non-blocking HIP stream of its own; batch k is submitted to lane k % S, so that the tail of
@@ -539,17 +555,18 @@ def worker_main(args):
         P.stream_handle = pl.stream_of(i)                 # (ticket i runs on lane i)
         P.stream = torch.cuda.ExternalStream(P.stream_handle, device=dev)
         P.builder = None
+        P.src = lane_in[i % nlane_in]                     # this lane's frames (720p-build) or pyramids
         with torch.cuda.stream(P.stream):
             if args.workload == "720p-build":
                 P.builder = PyramidBuilder(w0, h0, ctx=P.ctx)
                 levels, vstep, rows = P.builder.levels, P.builder.vstep, P.builder.rows
                 P.d_pyr = torch.empty((B, rows, vstep), dtype=torch.uint8, device=dev)
-                P.builder(d_frames, P.d_pyr)
+                P.builder(P.src, P.d_pyr)
                 torch.cuda.synchronize()
                 if host is None:
-                    host = P.d_pyr[:min(distinct, B)].cpu().numpy()
+                    host = P.d_pyr[:nd].cpu().numpy()
             else:
-                P.d_pyr = d_pyr0
+                P.d_pyr = P.src
         pipes.append(P)
     fe = OrbFrontend(levels, vstep=vstep, rows=rows, max_keypoints=args.max_keypoints, ctx=pipes[0].ctx,
                      log_bucket_size=args.log_bucket_size, bucket_limit=args.bucket_limit)   # parameter / level structs
@@ -620,7 +637,7 @@ def worker_main(args):
             if P.builder is not None:
                 # steady state of a stream: the same pyramid buffer is refilled every step by the same builder
                 # (its first fill, before the timed region, established the zero margins)
-                P.builder(d_frames, P.d_pyr, margins_clean=bool(args.margins_clean))
+                P.builder(P.src, P.d_pyr, margins_clean=bool(args.margins_clean))
             t = pl.submit(fe.params, fe.levels, P.d_pyr, *o)
             assert t == k, "tickets and steps out of phase"
             if m_out is not None:
@@ -650,10 +667,12 @@ def worker_main(args):
         step()
     finish_all()
     torch.cuda.synchronize()
-    with torch.cuda.stream(stream):
-        launches1(kp, desc, counts)
-    torch.cuda.synchronize()
-    graph_bad = any(not torch.equal(o[2], counts) for P in pipes for o in P.outs)
+    graph_bad = False
+    for P in reversed(pipes):                             # (lane 0 last: `counts` then holds lane 0's, as launches1 would leave them)
+        with torch.cuda.stream(stream):
+            fe1(P.d_pyr, kp, desc, counts)                # plain eager call on the lane's own (already built) pyramids
+        torch.cuda.synchronize()
+        graph_bad = graph_bad or any(not torch.equal(o[2], counts) for o in P.outs)
     st0 = pl.stats()
     use_graphs = bool(args.graph) and st0["replayed_from_graphs"] > 0
     if agree_any(graph_bad, dev):
@@ -710,6 +729,7 @@ def worker_main(args):
         torch.distributed.barrier()
     torch.cuda.synchronize()
     nstep[0] = 0
+    tick_timed = [tick[0]]                                 # ticket of the first timed step
     t0 = time.perf_counter()
     last = None
     for _ in range(args.steps):
@@ -848,9 +868,20 @@ def worker_main(args):
     # counts are the reference's un-clamped totals; keypoints beyond the capacity are neither stored nor
     # described, so only min(count, max_keypoints) per pyramid is credited
     capped = int((allc.to(torch.int64) > args.max_keypoints).sum().item())
-    total_kp_step = int(torch.clamp(allc.to(torch.int64), max=args.max_keypoints).sum().item())   # all ranks, one step
-    local_kp = int(torch.clamp(counts.to(torch.int64), max=args.max_keypoints).sum().item())
-    value = total_kp_step * args.steps / dt
+    local_kp = int(torch.clamp(counts.to(torch.int64), max=args.max_keypoints).sum().item())    # lane 0's batch (side context)
+    # keypoints of the K timed steps: step k ran lane k % S, whose batch (its own pyramids) yields the same counts every
+    # time — every output set of a lane holds them
+    lane_kp = [int(torch.clamp(P.outs[0][2].to(torch.int64), max=args.max_keypoints).sum().item()) for P in pipes]
+    assert all(torch.equal(o[2], P.outs[0][2]) for P in pipes for o in P.outs), "a lane's output sets disagree"
+    k_first = tick_timed[0]
+    timed_kp = sum(lane_kp[k % S] for k in range(k_first, k_first + args.steps))                   # this rank
+    if world > 1:
+        import torch.distributed as dist
+        tk = torch.tensor([timed_kp], dtype=torch.int64, device=dev if dist.get_backend() == "nccl" else None)
+        dist.all_reduce(tk)
+        timed_kp = int(tk.item())
+    total_kp_step = timed_kp / args.steps                  # all ranks, mean over the timed steps
+    value = timed_kp / dt
 
     if rank == 0:
         fused = args.pipeline != 1
@@ -904,7 +935,11 @@ def worker_main(args):
                             ", border=16, FAST threshold=20, Harris threshold=1<<15, " + ("no buckets" if not args.log_bucket_size else f"buckets <{args.log_bucket_size},{args.bucket_limit}>") + ", "
                             f"256-bit descriptors (BASELINE.json configs[{cfg_idx}]" + (f": {world} GPUs" if world > 1 else "") + ")",
                 "baseline_config_index": cfg_idx,
-                "batch_per_gpu": B, "global_batch": B * world, "distinct_pyramids_per_gpu": min(distinct, B),
+                "batch_per_gpu": B, "global_batch": B * world, "distinct_pyramids_per_gpu": nd * nlane_in,
+                "input_buffers_per_lane": "shared (one buffer read by every lane)" if args.shared_input else "distinct",
+                "input": (f"{nlane_in} device-resident batch(es) of {B} per GPU, {nd} different pyramids each "
+                          f"(seeds 0x5eed0000 + (rank*{S} + lane)*{B} + i); lane l submits batch l"),
+                "keypoints_per_step_by_lane": lane_kp,
                 "keypoints_per_pyramid": total_kp_step / (B * world),
                 "pyramids_per_s": B * world * args.steps / dt,
                 "parallelism": f"pyramid-shard x{world}, all-gather of counts" if world > 1 else "single GPU",

@@ -9,6 +9,11 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 LIBDIR = os.path.join(PKG, "lib")
 LIB = os.path.join(LIBDIR, "libpislam_hip.so")
+# Development only (A/B runs of kernel variants on the GPU box): PISLAM_HIP_LIB names another in-tree build of the same
+# sources (tools/ab_build.sh); it is loaded as it is, never rebuilt.
+_LIB_OVERRIDE = os.environ.get("PISLAM_HIP_LIB")
+if _LIB_OVERRIDE:
+    LIB = os.path.abspath(_LIB_OVERRIDE)
 SOURCES = ["pislam_hip.hip"]
 
 
@@ -44,6 +49,8 @@ def hipcc() -> str:
 
 
 def _stale() -> bool:
+    if _LIB_OVERRIDE:
+        return False
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
@@ -56,7 +63,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     Safe under concurrent callers (one process per GPU under torchrun): an exclusive file lock
     serialises builders, the compiler writes to a temporary name and the result is renamed into
     place atomically, and late arrivals re-check staleness after taking the lock."""
-    if not force and not _stale():
+    if _LIB_OVERRIDE or (not force and not _stale()):
         return LIB
     import fcntl
     os.makedirs(LIBDIR, exist_ok=True)

@@ -58,6 +58,7 @@ namespace {
 struct DevBuf {
   void *p = nullptr;
   size_t cap = 0;
+  unsigned long long reallocs = 0;   // times the buffer moved: a captured hipGraph holds the OLD address
   // returns true if (re)allocated
   int ensure(size_t bytes, bool *grew = nullptr) {
     if (grew) *grew = false;
@@ -71,6 +72,7 @@ struct DevBuf {
       return PISLAM_ERR_NOMEM;
     }
     cap = want;
+    reallocs++;
     if (grew) *grew = true;
     return PISLAM_OK;
   }
@@ -78,6 +80,7 @@ struct DevBuf {
     if (p) (void)hipFree(p);
     p = nullptr;
     cap = 0;
+    reallocs++;
   }
   template <class T>
   T *as() const { return (T *)p; }
@@ -138,6 +141,17 @@ struct pislam_ctx {
   hipEvent_t ev_join = nullptr;        // aux stream -> context stream at the end of the call
   int ovf_nsub = 0;                    // layout of w_ovf the last call / reserve established: lists, dwords per list
   size_t ovf_stride = 0;
+  unsigned long long ovf_layouts = 0;  // times that layout changed (a replayed graph would read another layout's headers)
+  // Everything a captured batch call bakes into its kernel arguments besides the caller's own pointers: the
+  // addresses of the workspace buffers and the overflow-list layout.  pislam_pipeline_submit replays a hipGraph
+  // only while this number is what it was at capture time.
+  unsigned long long workspace_generation() const {
+    unsigned long long g = ovf_layouts;
+    for (const DevBuf *b : {&w_cnt, &w_off, &w_total, &w_cellkp, &w_score, &w_stage, &w_stripcnt, &w_work, &w_prof,
+                            &w_ovf, &w_stagedesc})
+      g += b->reallocs;
+    return g;
+  }
 };
 
 namespace {
@@ -1260,10 +1274,13 @@ int prepare_ovf(pislam_ctx *c, int nsub, size_t stride) {
   bool grew = false;
   if (c->w_ovf.ensure(sizeof(uint32_t) * stride * nsub, &grew) != PISLAM_OK)
     return fail(c, PISLAM_ERR_NOMEM, "hipMalloc(overflow list)");
-  if (grew || c->ovf_nsub != nsub || c->ovf_stride != stride) {
+  // (one list: its header is at offset 0 whatever the stride — calls of different batch sizes share the layout)
+  const size_t lay = nsub == 1 ? 0 : stride;
+  if (grew || c->ovf_nsub != nsub || c->ovf_stride != lay) {
     HIPCHK(c, hipMemsetAsync(c->w_ovf.p, 0, c->w_ovf.cap, c->stream));
     c->ovf_nsub = nsub;
-    c->ovf_stride = stride;
+    c->ovf_stride = lay;
+    c->ovf_layouts++;
   }
   return PISLAM_OK;
 }
@@ -1314,7 +1331,11 @@ int run_fused(pislam_ctx *c, const pislam_frontend_params *p, const pf::FusedPar
       pf::k_fused_strips<true, true, false>,   pf::k_fused_strips<true, true, true>};
   // strips describing their own keypoints (option "orb_in_strip"): separate instantiations of the aligned ALIAS kernels
   static const KernT kerns_orb[2] = {pf::k_fused_strips<true, false, true, true>, pf::k_fused_strips<true, true, true, true>};
+  // the default mode's kernels (aligned ALIAS layout, no buckets, gather+ORB describes): compiled without the bucket code
+  static const KernT kerns_nb[2] = {pf::k_fused_strips<true, false, true, false, false>,
+                                    pf::k_fused_strips<true, true, true, false, false>};
   const KernT kern = (Fplan.orb_in_strip && vec && alias) ? kerns_orb[hooks ? 1 : 0]
+                     : (vec && alias && Fplan.lbs == 0)   ? kerns_nb[hooks ? 1 : 0]
                                                           : kerns[(vec ? 4 : 0) | (hooks ? 2 : 0) | (alias ? 1 : 0)];
   const size_t klds = alias ? lds_alias : lds;
   if (klds > 150 * 1024) return fail(c, PISLAM_ERR_INVALID, "level too wide for the strip kernel's LDS tiles");
@@ -1770,6 +1791,8 @@ struct LaneCall {
   uint32_t *kp, *desc, *counts;
   hipGraphExec_t exec = nullptr;       // nullptr: seen once, not captured yet
   bool failed = false;                 // capture / instantiation failed: stay eager
+  unsigned long long ws_gen = 0;       // the lane context's workspace_generation() the graph was captured against
+  bool recapture = false;              // the graph was dropped because the workspace moved: next occurrence eager, then capture
   unsigned long long last_use = 0;
   bool same(const pislam_frontend_params *q, const pislam_level *l, const uint8_t *py, size_t st, int b, uint32_t *k,
             uint32_t *d, uint32_t *c) const {
@@ -1787,16 +1810,23 @@ struct pislam_pipeline {
   std::vector<hipEvent_t> done;        // completion of the lane's last batch
   hipEvent_t in_ready = nullptr;       // producer stream -> lane stream
   unsigned long long submitted = 0;
-  unsigned long long n_replayed = 0, n_captured = 0, n_capture_failed = 0;
+  unsigned long long n_replayed = 0, n_captured = 0, n_capture_failed = 0, n_invalidated = 0;
   std::string err;
 };
 
 namespace {
+// An exec may still be in flight on its lane: the lane's stream is drained before one is destroyed (rare events:
+// an option change, an eviction, a workspace that moved).
+void destroy_exec(pislam_ctx *c, LaneCall &lc) {
+  if (!lc.exec) return;
+  (void)hipStreamSynchronize(c->stream);
+  (void)hipGraphExecDestroy(lc.exec);
+  lc.exec = nullptr;
+}
 void drop_lane_calls(pislam_pipeline *q) {
-  for (auto &v : q->calls) {
-    for (auto &lc : v)
-      if (lc.exec) (void)hipGraphExecDestroy(lc.exec);
-    v.clear();
+  for (size_t li = 0; li < q->calls.size(); li++) {
+    for (auto &lc : q->calls[li]) destroy_exec(q->lane[li], lc);
+    q->calls[li].clear();
   }
 }
 }  // namespace
@@ -1911,12 +1941,23 @@ PISLAM_EXPORT int pislam_pipeline_submit(pislam_pipeline *q, const pislam_fronte
     auto &v = q->calls[li];
     for (auto &lc : v)
       if (lc.same(p, lv, pyramids, stride, batch, kp, desc, counts)) hit = &lc;
-    if (!hit) {                        // first occurrence: remember it, run it eagerly
+    if (hit && hit->exec && hit->ws_gen != c->workspace_generation()) {
+      // a larger call on this lane (or pislam_pipeline_reserve, or a direct call on pislam_pipeline_lane()) moved a
+      // workspace buffer or re-laid the overflow lists since the capture: the graph holds stale addresses.  This
+      // occurrence runs eagerly (it re-establishes the layout, as a first occurrence would), the next one captures.
+      destroy_exec(c, *hit);
+      hit->recapture = true;
+      q->n_invalidated++;
+    }
+    if (hit && hit->recapture) {
+      hit->recapture = false;
+      hit->last_use = q->submitted;
+    } else if (!hit) {                 // first occurrence: remember it, run it eagerly
       if (v.size() >= 4) {
         size_t old = 0;
         for (size_t i = 1; i < v.size(); i++)
           if (v[i].last_use < v[old].last_use) old = i;
-        if (v[old].exec) (void)hipGraphExecDestroy(v[old].exec);
+        destroy_exec(c, v[old]);
         v.erase(v.begin() + old);
       }
       LaneCall lc;
@@ -1946,6 +1987,7 @@ PISLAM_EXPORT int pislam_pipeline_submit(pislam_pipeline *q, const pislam_fronte
         rc = PISLAM_OK;
         q->n_capture_failed++;
       } else {
+        hit->ws_gen = c->workspace_generation();
         q->n_captured++;
       }
     }

@@ -165,3 +165,45 @@ def make_pyramid(index: int, w0: int = 640, h0: int = 480, nlevels: int = 8,
 def make_batch(first: int, count: int, **kw) -> np.ndarray:
     """uint8 [count][rows][vstep]."""
     return np.stack([make_pyramid(first + i, **kw) for i in range(count)])
+
+
+def make_many(indices, workers: int = 0, kind: str = "pyramid", **kw) -> np.ndarray:
+    """The pyramids (kind="pyramid") or level-0 frames (kind="level0") numbered `indices`, generated by `workers` child
+    processes (0 / 1: in this process).  The children are plain `python -m pislam_amd.synth` processes — numpy only, no
+    fork of a process that holds a GPU runtime, no re-import of the parent's __main__ — that write their share to a
+    temporary directory.  Same bytes as make_pyramid / make_level0 for every index."""
+    indices = [int(i) for i in indices]
+    one = (lambda i: make_level0(i, **kw)) if kind == "level0" else (lambda i: make_pyramid(i, **kw))
+    if workers <= 1 or len(indices) < 2 * workers:
+        return np.stack([one(i) for i in indices])
+    import json
+    import os
+    import subprocess
+    import sys
+    import tempfile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    parts = [indices[k::workers] for k in range(workers)]
+    with tempfile.TemporaryDirectory(prefix="pislam_synth_") as tmp:
+        procs = []
+        for k, part in enumerate(parts):
+            spec = json.dumps({"kind": kind, "indices": part, "kw": kw, "out": os.path.join(tmp, f"part{k}.npy")})
+            env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1")
+            procs.append(subprocess.Popen([sys.executable, "-m", "pislam_amd.synth", spec], cwd=root, env=env))
+        for pr in procs:
+            if pr.wait() != 0:
+                raise RuntimeError("a synthetic-input worker failed")
+        out = [None] * len(indices)
+        for k, part in enumerate(parts):
+            arr = np.load(os.path.join(tmp, f"part{k}.npy"))
+            for j in range(len(part)):
+                out[k + j * workers] = arr[j]
+    return np.stack(out)
+
+
+if __name__ == "__main__":                       # a make_many worker
+    import json
+    import sys
+    spec = json.loads(sys.argv[1])
+    kw = {k: ([tuple(t) for t in v] if k == "levels" and v is not None else v) for k, v in spec["kw"].items()}
+    fn = make_level0 if spec["kind"] == "level0" else make_pyramid
+    np.save(spec["out"], np.stack([fn(i, **kw) for i in spec["indices"]]))

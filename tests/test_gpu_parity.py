@@ -683,23 +683,31 @@ def test_batch_call_is_hipgraph_capturable(gpu_ctx, orc):
 
 
 def test_dense_input_takes_the_overflow_pass_and_stays_exact(gpu_ctx, orc):
-    """Uniform noise: nearly every pixel is a corner, the on-chip queues of the fast path overflow, the
-    strips are redone by the overflow pass (plain layout, scan fallbacks).  Results must not change and
-    pislam_frontend_last_stats must report it; a second call must start from an empty overflow list."""
+    """Level 0: isolated bright dots on the lattice spanned by (4, 0) and (2, 1) — no lattice point lies on another's
+    FAST ring, so every dot is a corner: one pixel in four, more than the fast path's on-chip corner queue (at most 4096
+    entries) holds for a 32-row strip — and levels of uniform noise: the strips whose queue overflows are redone by the
+    overflow pass (plain layout, scan fallbacks).  Results must not change and pislam_frontend_last_stats must report
+    it; a second call must start from an empty overflow list."""
     import torch
     from pislam_amd import synth
     from pislam_amd.frontend import OrbFrontend
-    levels = [(160, 120, 0), (133, 100, 120), (111, 83, 220)]
+    levels = [(640, 120, 0), (133, 100, 120), (111, 83, 220)]
     rows = 303
     rng = np.random.default_rng(7)
-    pyr = np.zeros((2, rows, 160), np.uint8)
-    for (w, h, r0) in levels:
+    pyr = np.zeros((2, rows, 640), np.uint8)
+    yy, xx = np.mgrid[0:120, 0:640]
+    dots = np.full((120, 640), 20, np.uint8)
+    lattice = (xx - 2 * yy) % 4 == 0
+    dots[lattice] = rng.integers(120, 256, int(lattice.sum()), dtype=np.uint8)
+    pyr[0, :120, :640] = dots
+    for (w, h, r0) in levels[1:]:
         pyr[0, r0:r0 + h, :w] = rng.integers(0, 256, (h, w), dtype=np.uint8)
-    pyr[1] = synth.make_batch(5, 1, w0=160, h0=120, vstep=160, levels=levels)[0]   # a sparse one in the same batch
+    pyr[1] = synth.make_batch(5, 1, w0=640, h0=120, vstep=640, levels=levels)[0]   # a sparse one in the same batch
     dev = torch.device("cuda:0")
     gpu_ctx.set_option("pipeline", 2)
+    gpu_ctx.set_option("strip_rows", 32)
     try:
-        fe = OrbFrontend(levels, vstep=160, rows=rows, max_keypoints=8192, ctx=gpu_ctx)
+        fe = OrbFrontend(levels, vstep=640, rows=rows, max_keypoints=8192, ctx=gpu_ctx)
         kp, desc, counts = fe.alloc_outputs(2, dev)
         for rep in range(2):
             fe(torch.from_numpy(pyr).to(dev), kp, desc, counts)
@@ -716,6 +724,7 @@ def test_dense_input_takes_the_overflow_pass_and_stays_exact(gpu_ctx, orc):
                 assert (k[b, :n] == okp[:n]).all() and (d[b, :n] == odesc[:n]).all()
     finally:
         gpu_ctx.set_option("pipeline", 0)
+        gpu_ctx.set_option("strip_rows", 0)
 
 
 def test_count_exchange_on_rccl_single_rank_group():
@@ -1065,3 +1074,57 @@ def test_pipeline_replays_repeated_calls_from_graphs_and_says_so(orc):
         assert torch.equal(c2, outs[0][2]) and torch.equal(k2, outs[0][0])
         pipe.close()
 
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sub_batches", [1, 2])
+def test_pipeline_graph_survives_a_workspace_that_moved(orc, sub_batches):
+    """A captured call bakes the lane's workspace addresses (and, with sub-batches, the overflow-list layout) into its
+    graph.  A LARGER call on the same lane reallocates them: the small call's graph must not be replayed against the
+    freed buffers (round-3 advisor finding) — the library notices the moved workspace, runs the call eagerly once and
+    captures it again.  Every result equals the oracle."""
+    import torch
+    from pislam_amd import capi, synth
+    from pislam_amd.frontend import OrbFrontend
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    levels = synth.level_table(320, 240, 4)
+    rows = synth.pyramid_rows(levels)
+    dev = torch.device("cuda:0")
+    small, big = 2, 24
+    host = synth.make_batch(7700, big, w0=320, h0=240, nlevels=4, levels=levels, nshapes=30)
+    d_big = torch.from_numpy(host).to(dev)
+    d_small = d_big[:small]
+    fe = OrbFrontend(levels, vstep=320, rows=rows, max_keypoints=2048)
+    want = [orc.pyramid(host[b], levels) for b in range(big)]
+    pipe = capi.Pipeline(device=0, depth=1)
+    pipe.set_option("sub_batches", sub_batches)
+    o_small, o_big = fe.alloc_outputs(small, dev), fe.alloc_outputs(big, dev)
+
+    def run(d_in, outs, n):
+        for t in outs:
+            t.zero_()
+        pipe.submit(fe.params, fe.levels, d_in, *outs, input_stream=torch.cuda.current_stream().cuda_stream)
+        pipe.synchronize()
+        c, kk, dd = (t.cpu().numpy().view(np.uint32) for t in (outs[2], outs[0], outs[1]))
+        for b in range(n):
+            okp, odesc, _ = want[b]
+            assert c[b] == len(okp) and (kk[b, :len(okp)] == okp).all() and (dd[b, :len(okp)] == odesc).all(), b
+
+    for _ in range(3):                       # eager, captured (+ launched), replayed
+        run(d_small, o_small, small)
+    st = pipe.stats()
+    assert st["captured"] == 1 and st["replayed_from_graphs"] == 2, st
+    run(d_big, o_big, big)                   # first occurrence of a larger call: eager, the workspace moves
+    run(d_small, o_small, small)             # the old graph is stale: eager, NOT a replay
+    st = pipe.stats()
+    assert st["captured"] == 1 and st["replayed_from_graphs"] == 2, st
+    run(d_small, o_small, small)             # captured again, against the new workspace
+    run(d_small, o_small, small)
+    run(d_big, o_big, big)                   # the big call's second occurrence: captured (workspace large enough: no move)
+    run(d_small, o_small, small)
+    run(d_big, o_big, big)
+    st = pipe.stats()
+    if sub_batches == 1:
+        assert st["captured"] == 3 and st["capture_failed"] == 0 and st["replayed_from_graphs"] == 7, st
+    pipe.close()
