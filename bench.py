@@ -30,8 +30,10 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+VALU_CYCLES_PER_WAVE_INST = 4.0 # what roofline.valu.issue_frac assumes (see its note)
+VALU_SUSTAINED_PER_S = 533e9    # tools/probes/valu_rate.hip on MI355X: 528-538 G wave64 integer instructions/s chip-wide
 METRIC = "ORB keypoints+descriptors/sec, 640x480 8-level pyramid"
-PROFILE_TAG = "r03"             # profiles/<tag>_counters_<workload>.json holds the PMC passes bench lines quote
+PROFILE_TAG = "r04"             # profiles/<tag>_counters_<workload>.json holds the PMC passes bench lines quote
 
 
 # ---------------------------------------------------------------------------------------------------------
@@ -381,14 +383,15 @@ class Watchdog:
         return False
 
 
-def load_counters(workload: str, batch: int, buckets: bool):
+def load_counters(workload: str, batch: int, suffix: str = ""):
     """PMC passes cannot run inside this process: HBM bytes and instruction counts per step come from the
-    committed profile of this workload (tools/profile_round.sh -> profiles/<tag>_counters_<workload>.json) and are
+    committed profile of this workload (tools/profile_round.sh -> profiles/<tag>_counters_<workload><suffix>.json;
+    suffix "_buckets43" = the README bucket mode, "_streams3" = the pass taken with three batches in flight) and are
     used ONLY when that profile was taken on exactly these kernel sources and this shape."""
     from pislam_amd import build as pbuild
-    path = os.path.join(ROOT, "profiles", f"{PROFILE_TAG}_counters_{workload}.json")
+    path = os.path.join(ROOT, "profiles", f"{PROFILE_TAG}_counters_{workload}{suffix}.json")
     rel = os.path.relpath(path, ROOT)
-    if buckets or not os.path.exists(path):
+    if not os.path.exists(path):
         return None, f"null: no PMC profile for this workload / configuration ({rel})"
     try:
         tj = json.load(open(path))
@@ -896,8 +899,12 @@ def worker_main(args):
         launch_ms = (strip_ms if strip_ms else ev_stage_ms[0]) if fused else ev_total_ms
         achieved = b_alg_launch / (launch_ms * 1e-3) / 1e9
         step_ms = dt / args.steps * 1e3
-        prof, prof_source = load_counters(args.workload, B, bool(args.log_bucket_size)) if fused else (None, "null: staged pipeline")
-        traffic = traffic_step = valu = None
+        bsfx = f"_buckets{args.log_bucket_size}{args.bucket_limit}" if args.log_bucket_size else ""
+        prof, prof_source = load_counters(args.workload, B, bsfx) if fused else (None, "null: staged pipeline")
+        prof3, prof3_source = load_counters(args.workload, B, bsfx + "_streams3") if fused else (None, "null: staged pipeline")
+        traffic = traffic_step = traffic_step3 = valu = None
+        if prof3:
+            traffic_step3 = sum(k.get("hbm_bytes_per_launch", 0) * k.get("launches_per_step", 1) for k in prof3["kernels"].values()) or None
         if prof:
             ks = prof["kernels"]
             dom = ks.get("k_fused_strips", {})
@@ -906,12 +913,20 @@ def worker_main(args):
             if dom.get("SQ_INSTS_VALU") and clock_ghz:
                 nsimd = 4 * 256
                 insts = dom["SQ_INSTS_VALU"]
+                rate = insts / (launch_ms * 1e-3)                 # wave64 VALU instructions per second, chip-wide
                 valu = {"insts": insts, "salu_insts": dom.get("SQ_INSTS_SALU"),
-                        "issue_frac": insts * 4.0 / (nsimd * clock_ghz * 1e9 * launch_ms * 1e-3),
+                        "issue_frac": insts * VALU_CYCLES_PER_WAVE_INST / (nsimd * clock_ghz * 1e9 * launch_ms * 1e-3),
+                        "issue_frac_of_sustained": rate / VALU_SUSTAINED_PER_S,
+                        "wave_insts_per_s": rate, "sustained_wave_insts_per_s": VALU_SUSTAINED_PER_S,
+                        "cycles_per_wave_inst_assumed": VALU_CYCLES_PER_WAVE_INST,
                         "clock_ghz": clock_ghz,
-                        "note": "wave64 VALU instructions of one strip-kernel launch x 4 cycles / (1024 SIMDs x shader clock x "
-                                "launch_ms): the share of the integer issue slots in use — the binding resource of this kernel; "
-                                "clock measured in this run (s_memtime vs s_memrealtime under the steps' load)",
+                        "note": "wave64 VALU instructions of one strip-kernel launch / launch_ms.  issue_frac prices an instruction "
+                                "at 4 cycles of its SIMD (1024 SIMDs x shader clock / 4): the rate tools/probes/valu_rate.hip "
+                                "MEASURED on this part for dependent-free 32-bit integer ops is 528-538 G wave-instructions/s "
+                                "chip-wide = 4.5 cycles — /opt/skills/guides/MI355X_MICROARCH.md quotes 2 cycles per wave64 op, which "
+                                "the probe does not reach for this instruction mix.  issue_frac_of_sustained = the rate over that "
+                                "measured 533 G/s: the share of the ACHIEVABLE integer issue rate this kernel uses — the binding "
+                                "resource.  Clock measured in this run (s_memtime vs s_memrealtime under the steps' load)",
                         "source": prof_source}
         cfg_idx = {"vga": 2 if world > 1 else 1, "1280x960": 3, "720p-build": 4}[args.workload]
         out = {
@@ -968,6 +983,7 @@ def worker_main(args):
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": prof_source,
                 "traffic_whole_step": traffic_step,
+                "traffic_whole_step_3_lanes": traffic_step3, "traffic_3_lanes_source": prof3_source,
                 "kernel": "pf::k_fused_strips (hipEvents on the launch stream around 16 back-to-back launches, / 16, measured after "
                           "the timed region with the other pipelines idle)" if fused
                           else "whole staged step (all launches)",

@@ -369,7 +369,7 @@ __device__ __forceinline__ void strip_body(const StripArgs A, const FusedLevel L
                                            const uint32_t img_bytes32) {
   const int B = A.border;
   // BUCK = false: the instantiation knows logBucketSize == 0 (the product kernel of the default mode carries no
-  // bucket code and, with it, no in-LDS ranking at all)
+  // bucket code)
   const int Albs = BUCK ? A.lbs : 0;
   // Phase E exists in the ORBK instantiations of the ALIAS kernels on 16-byte aligned layouts (vstep % 16 == 0
   // makes a patch's byte shift row-independent; option "orb_in_strip"); elsewhere k_gather_orb describes the
@@ -834,15 +834,6 @@ __device__ __forceinline__ void strip_body(const StripArgs A, const FusedLevel L
     const lds_u32 *nq = ALIAS ? shq_h : shq_n;      // ALIAS: the one queue; entries with score 0 are skipped
     const int own_rows = ye - ys;                   // owned score rows r = 1 .. own_rows
     const int ex0q = L.ex0, ex1q = L.ex1;             // block origins this entry owns
-    // Without buckets a survivor goes STRAIGHT to the strip's staging slots, in the (arbitrary) order the waves
-    // append: k_gather_orb ranks a strip's handful of keypoints into the reference's block-raster order by counting
-    // smaller keys (final_position), one thread per keypoint — here that ranking was a single-wave section on the
-    // workgroup's critical path behind one more barrier.  A strip has one slot per 2x2 block and a block emits at
-    // most one keypoint, so the list cannot overflow.  (Buckets and strips that describe their own keypoints still
-    // rank in LDS: their per-cell top-`limit` / descriptor slots need the ranks here.)
-    const bool direct = Albs == 0 && !(ALIAS && VEC16 && ORBK && A.orb != 0);
-    const size_t strip_slot_d = (size_t)pyr * A.slots_per_pyr + L.slot0 + (size_t)s * (L.R >> 1) * L.nbx;
-    const uint32_t add_xy_d = ((uint32_t)L.col0 << 12) | (uint32_t)L.row0;      // README.md:78
     for (int c0 = wave * 64; c0 < tn; c0 += WAVES * 64) {
       const uint32_t e = nq[min(c0 + lane, tn - 1)];
       const bool valid = c0 + lane < tn && (!ALIAS || (e >> 24) != 0);
@@ -880,9 +871,7 @@ __device__ __forceinline__ void strip_body(const StripArgs A, const FusedLevel L
         int base = 0;
         if (lane == 0) base = (int)lds_add_rtn(&sh_ctr[4], (uint32_t)cnt);
         base = __builtin_amdgcn_readfirstlane(base);
-        if (direct) {
-          if (res) stage_kp[strip_slot_d + base + ballot_rank(m)] = res + add_xy_d;
-        } else if (base + cnt <= QS_SHARED) {
+        if (base + cnt <= QS_SHARED) {
           if (res) {
             const int slot_i = base + ballot_rank(m);
             shq_s[slot_i] = res;
@@ -896,11 +885,6 @@ __device__ __forceinline__ void strip_body(const StripArgs A, const FusedLevel L
     }
     lds_barrier();
     mark(3);
-    if (direct) {                                   // (direct emits never set sh_ctr[3])
-      if (tid == 0 && !(ablate & 128)) strip_count[(size_t)pyr * A.strips_per_pyr + L.strip0 + s] = sh_ctr[4];
-      mark(4);
-      return;
-    }
     if (sh_ctr[3] == 0) {
       if (ablate & 128) return;
       const int ns = (int)sh_ctr[4];
@@ -976,6 +960,38 @@ __device__ __forceinline__ void strip_body(const StripArgs A, const FusedLevel L
       // straddle strips.  Pass 1 marks the survivors that make their cell's top-`limit`, pass 2 ranks
       // the kept ones by (cell, value).
       const int lbs = Albs, limit = A.limit;
+      if (ns <= 64) {
+        // (the usual case: one wave, the survivors in its lanes, v_readlane instead of two LDS reads per comparison —
+        //  written as per-thread loops over LDS the two passes below are chains of ~2 ns LDS round trips on the
+        //  workgroup's critical path)
+        uint32_t my_rank = 0xffffffffu;
+        uint32_t kept = 0;
+        if (wave == 0) {
+          const uint32_t v = lane < ns ? shq_s[lane] : 0u;
+          const uint32_t cell = lane < ns ? ((((uint32_t)(decode_y(v) - B) >> lbs) << 12) | ((uint32_t)(decode_x(v) - B) >> lbs)) : 0xffffffffu;
+          int greater = 0;
+          for (int j = 0; j < ns; j++) {
+            const uint32_t cj = (uint32_t)__builtin_amdgcn_readlane((int)cell, j), vj = (uint32_t)__builtin_amdgcn_readlane((int)v, j);
+            greater += (cj == cell) & (vj > v);
+          }
+          const bool keep = lane < ns && greater < limit;
+          const uint64_t km = __ballot(keep);
+          int rank = 0;
+          for (int j = 0; j < ns; j++) {
+            if (!((km >> j) & 1)) continue;             // (wave-uniform)
+            const uint32_t cj = (uint32_t)__builtin_amdgcn_readlane((int)cell, j), vj = (uint32_t)__builtin_amdgcn_readlane((int)v, j);
+            rank += (cj < cell) | ((cj == cell) & (vj < v));
+          }
+          if (keep) {
+            stage_kp[strip_slot + rank] = v + add_xy;
+            my_rank = (uint32_t)rank;
+          }
+          kept = (uint32_t)__popcll(km);
+        }
+        if (tid == 0) strip_count[(size_t)pyr * A.strips_per_pyr + L.strip0 + s] = kept | (orb ? STRIP_DESCRIBED : 0u);
+        if (orb && ns > 0) describe_strip(ns, my_rank);
+        return;
+      }
       for (int i = tid; i < ns; i += NT) {
         const uint32_t v = shq_s[i];
         const uint32_t cell = (((uint32_t)(decode_y(v) - B) >> lbs) << 12) | ((uint32_t)(decode_x(v) - B) >> lbs);
@@ -1305,8 +1321,7 @@ __global__ __launch_bounds__(NT) void k_fused_overflow(
 // block-raster inside a level, Fast.h:228-320).  A level cut into x-tiles (FusedLevel::gn > 1) emits, per
 // strip, one list per tile, each in block-raster order of its own columns; the level's order interleaves them
 // by block row (bucket mode: by cell row, Fast.h:211-226): tile t's keypoint of row-key r comes after every
-// keypoint of tiles < t with key <= r and of tiles > t with key < r.  Without buckets the strips' lists are unordered
-// and the gather ranks them (final_position).
+// keypoint of tiles < t with key <= r and of tiles > t with key < r.
 // ---------------------------------------------------------------------------
 struct PlanStrip {
   int li;            // plan entry
@@ -1320,62 +1335,32 @@ __device__ __forceinline__ PlanStrip plan_strip(const FusedParams &P, int i) {
 __device__ __forceinline__ uint32_t strip_slot_of(const FusedParams &P, int li, int s) {
   return (uint32_t)(P.lv[li].slot0 + s * (P.lv[li].R >> 1) * P.lv[li].nbx);
 }
-// ONE WAVE puts plan strip `a` of a pyramid into the reference's order: emit(v, pos, k) is called by the lane holding
-// entry k of the strip's staged list (packed keypoint v) with its final index `pos` within the pyramid.
-//   no buckets: a strip's list arrives in NO particular order (the strip kernel's waves append their NMS survivors as
-//     they find them).  The reference's push_back order inside a level is block-raster (Fast.h:228-320): block row, then
-//     x — one keypoint per 2x2 block, so ((y - row0 - B) >> 1, x) in stacked coordinates is a strict total order over
-//     the level's keypoints, tiles included;
-//   buckets: the strips rank their own lists (per-cell top-`limit`, cells in (cell row, bucket) order, Fast.h:314-352), a
-//     level's tiles interleave by cell row: (cell row, tile, index in the tile's list).
-// Either way the keypoint's place among those of its strip row = the number of smaller keys in the lists of all the
-// level's tiles for that strip: the lists (a dozen or two entries each) are loaded one entry per lane and compared
-// through v_readlane — no per-keypoint search, no memory access inside the counting loop.  soff: exclusive prefix of
-// the strip counts (LDS); stage: this pyramid's staging slots.
-template <class OFF, class EMIT>
-__device__ __forceinline__ void rank_strip(const FusedParams &P, const OFF *soff, const uint32_t *__restrict__ stage, const int a,
-                                           const int lane, EMIT emit) {
-  const PlanStrip ps = plan_strip(P, a);              // (wave-uniform)
-  const int li = ps.li, s = ps.s;
-  const int gn = P.lv[li].gn, g0 = P.lv[li].gfirst;
-  const uint32_t n = soff[a + 1] - soff[a];
-  const int row0 = P.lv[li].row0 + P.border;          // (the tiles of a level share row0)
-  const int lbs = P.lbs;
-  auto key_of = [&](uint32_t v, int t, uint32_t k) -> uint32_t {
-    const uint32_t yr = (uint32_t)(decode_y(v) - row0);
-    return lbs == 0 ? ((yr >> 1) << 12 | (uint32_t)decode_x(v)) : ((yr >> lbs) << 22 | (uint32_t)t << 16 | k);
-  };
-  uint32_t base = soff[P.lv[g0].strip0];              // everything before this level ...
-  for (int t = 0; t < gn; t++) base += soff[P.lv[g0 + t].strip0 + s] - soff[P.lv[g0 + t].strip0];   // ... + its strips above (all tiles)
-  const uint32_t *mine = stage + strip_slot_of(P, li, s);
-  for (uint32_t k0 = 0; k0 < n; k0 += 64) {
-    const uint32_t k = k0 + (uint32_t)lane;
-    const bool have = k < n;
-    const uint32_t v = have ? mine[k] : 0u;
-    const uint32_t key = have ? key_of(v, li - g0, k) : 0u;
-    uint32_t pos = base;
-    for (int t = 0; t < gn; t++) {
-      const int e = g0 + t, j = P.lv[e].strip0 + s;
-      const uint32_t nt = soff[j + 1] - soff[j];
-      const uint32_t *list = stage + strip_slot_of(P, e, s);
-      for (uint32_t q0 = 0; q0 < nt; q0 += 64) {
-        const uint32_t q = q0 + (uint32_t)lane;
-        const uint32_t kw = q < nt ? key_of(list[q], t, q) : 0xffffffffu;     // (absent lanes: never smaller)
-        const int m = (int)min(64u, nt - q0);
-        // four independent comparisons per trip (i is a multiple of 4 below 64: lanes i .. i+3 exist; lanes at and beyond
-        // nt - q0 hold 0xffffffff, never smaller)
-        uint32_t r0 = 0, r1 = 0, r2 = 0, r3 = 0;
-        for (int i = 0; i < m; i += 4) {
-          r0 += (uint32_t)__builtin_amdgcn_readlane((int)kw, i) < key;
-          r1 += (uint32_t)__builtin_amdgcn_readlane((int)kw, i + 1) < key;
-          r2 += (uint32_t)__builtin_amdgcn_readlane((int)kw, i + 2) < key;
-          r3 += (uint32_t)__builtin_amdgcn_readlane((int)kw, i + 3) < key;
-        }
-        pos += r0 + r1 + r2 + r3;
-      }
+// final index (within the pyramid) of the k-th keypoint `v` of plan strip (li, s); soff in LDS or global,
+// stage = this pyramid's staging slots
+template <class OFF>
+__device__ __forceinline__ uint32_t final_position(const FusedParams &P, const OFF *soff, const uint32_t *__restrict__ stage,
+                                                   int li, int s, uint32_t k, uint32_t v) {
+  const int gn = P.lv[li].gn;
+  if (gn == 1) return soff[P.lv[li].strip0 + s] + k;
+  const int g0 = P.lv[li].gfirst;
+  const int shift = P.lbs ? P.lbs : 1;
+  const int r = (decode_y(v) - P.lv[li].row0 - P.border) >> shift;      // block row (cell row) inside the level
+  uint32_t pos = soff[P.lv[g0].strip0] + k;       // everything before this level ...
+  for (int t = 0; t < gn; t++) {
+    const int e = g0 + t, j = P.lv[e].strip0 + s;
+    pos += soff[j] - soff[P.lv[e].strip0];          // ... + the level's strips above this one (all tiles)
+    if (e == li) continue;
+    // keypoints of tile t's list that precede: row key < r, or == r when the tile lies to the left
+    const int lim = r + (e < li ? 1 : 0);
+    const uint32_t *list = stage + strip_slot_of(P, e, s);
+    uint32_t lo = 0, hi = soff[j + 1] - soff[j];
+    while (lo < hi) {
+      const uint32_t m = (lo + hi) >> 1;
+      if (((decode_y(list[m]) - P.lv[e].row0 - P.border) >> shift) < lim) lo = m + 1; else hi = m;
     }
-    if (have) emit(v, pos, k);
+    pos += lo;
   }
+  return pos;
 }
 
 // One workgroup per pyramid: exclusive scan of the strip counts, copy staged keypoints to their final
@@ -1425,10 +1410,15 @@ __global__ __launch_bounds__(256) void k_gather(const FusedParams P,
   const uint32_t *stage = stage_kp + (size_t)pyr * P.slots_per_pyr;
   // one wave per strip
   for (int st = wv; st < S; st += 4) {
-    if (soff[st + 1] == soff[st]) continue;
-    rank_strip(P, soff, stage, st, lane, [&](uint32_t v, uint32_t pos, uint32_t) {
+    const uint32_t n = soff[st + 1] - soff[st];
+    if (n == 0) continue;
+    const PlanStrip ps = plan_strip(P, st);
+    const uint32_t *list = stage + strip_slot_of(P, ps.li, ps.s);
+    for (uint32_t k = lane; k < n; k += 64) {
+      const uint32_t v = list[k];
+      const uint32_t pos = final_position(P, soff, stage, ps.li, ps.s, k, v);
       if (pos < cap) kp[(size_t)pyr * kp_stride + pos] = v;
-    });
+    }
   }
 }
 
@@ -1436,7 +1426,7 @@ __global__ __launch_bounds__(256) void k_gather(const FusedParams P,
 // role's 5-workgroups-per-CU budget has no room for another 300 static bytes).
 struct OrbShared {
   uint32_t wsum[4];
-  uint32_t carry, ntodo, a_lo, a_hi;             // a_lo .. a_hi: plan strips holding this chunk's staged keypoints
+  uint32_t carry, ntodo, flag, pad;
   uint8_t rtab[256];                                // vrecpe estimate table (256 threads: one entry each)
 };
 __host__ __device__ constexpr size_t orb_lds_bytes(int strips_per_pyr, size_t per_max) {
@@ -1499,11 +1489,6 @@ __device__ __forceinline__ void orb_role(const FusedParams &P, const uint8_t *__
   const uint32_t per = (total + nch - 1) / nch;
   const uint32_t lo = min((uint32_t)ch * per, total), hi = min(lo + per, total);
   if (lo >= hi) return;
-  for (int i = tid; i < S; i += 256) {                 // the (non-empty) strips that hold entries lo and hi - 1
-    if (soff[i] <= lo && lo < soff[i + 1]) sh->a_lo = (uint32_t)i;
-    if (soff[i] < hi && hi <= soff[i + 1]) sh->a_hi = (uint32_t)i;
-  }
-  __syncthreads();
 
   const uint32_t *stage = stage_kp + (size_t)pyr * P.slots_per_pyr;
   const uint32_t *sd = stage_desc + (size_t)pyr * S * QS_SHARED * words;
@@ -1518,26 +1503,27 @@ __device__ __forceinline__ void orb_role(const FusedParams &P, const uint8_t *__
     const uint32_t c1 = min(c0 + per_max, hi);
     if (tid == 0) sh->ntodo = 0;
     __syncthreads();
-    // ---- one wave per plan strip that holds staged keypoints of [c0, c1): the strip's list ranked into the reference's
-    // order (rank_strip), keypoints written to their final positions and queued for the describe loop.  (A strip that
-    // straddles the range's ends is ranked by both neighbours; each takes the entries inside its own range.)
-    for (int a = (int)sh->a_lo + wv; a <= (int)sh->a_hi; a += OWAVES) {
-      const uint32_t s0 = soff[a];
-      if (soff[a + 1] == s0 || soff[a + 1] <= c0 || s0 >= c1) continue;
-      const bool described = (cnt[a] & STRIP_DESCRIBED) != 0;
-      rank_strip(P, soff, stage, a, lane, [&](uint32_t v, uint32_t pos, uint32_t k) {
-        const uint32_t e = s0 + k;
-        if (e < c0 || e >= c1 || pos >= cap) return;   // other chunk / beyond the caller's capacity: counted, not stored
-        kp[(size_t)pyr * kp_stride + pos] = v;
-        if (described) {
-          const uint32_t *src = sd + ((size_t)a * QS_SHARED + k) * words;
-          for (int w = 0; w < words; w++) dsc[(size_t)pos * words + w] = src[w];
-        } else {
-          const uint32_t slot = atomicAdd(&sh->ntodo, 1u);   // (order irrelevant: results are positional)
-          kpl[slot] = v;
-          kpos[slot] = pos;
-        }
-      });
+    // ---- one thread per staged keypoint: strip by binary search, final position, keypoint + descriptor ----
+    for (uint32_t e = c0 + tid; e < c1; e += 256) {
+      int a = 0, b = S;                                // largest strip index with soff[a] <= e
+      while (b - a > 1) {
+        const int m = (a + b) >> 1;
+        if (soff[m] <= e) a = m; else b = m;
+      }
+      const uint32_t k = e - soff[a];
+      const PlanStrip ps = plan_strip(P, a);
+      const uint32_t v = stage[strip_slot_of(P, ps.li, ps.s) + k];
+      const uint32_t pos = final_position(P, soff, stage, ps.li, ps.s, k, v);
+      if (pos >= cap) continue;                        // beyond the caller's capacity: counted, not stored
+      kp[(size_t)pyr * kp_stride + pos] = v;
+      if (cnt[a] & STRIP_DESCRIBED) {
+        const uint32_t *src = sd + ((size_t)a * QS_SHARED + k) * words;
+        for (int w = 0; w < words; w++) dsc[(size_t)pos * words + w] = src[w];
+      } else {
+        const uint32_t slot = atomicAdd(&sh->ntodo, 1u);   // (order irrelevant: results are positional)
+        kpl[slot] = v;
+        kpos[slot] = pos;
+      }
     }
     __syncthreads();
     const uint32_t nt = sh->ntodo;
@@ -1584,7 +1570,11 @@ __device__ __forceinline__ void orb_role(const FusedParams &P, const uint8_t *__
 //   - otherwise queued and described here: orb_fetch / orb_describe, two keypoints per wave iteration, the
 //     next pair's loads in flight while the current pair is processed.
 // ===========================================================================
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7))) void k_gather_orb(
+// (waves_per_eu(6): the kernel takes 72 VGPRs either way — 7 waves per SIMD — but asking for 7 also caps its SGPRs and
+//  cost 13 SGPR spills (v_writelane / v_readlane in the describe loop); with 6 there are none: the same kernel time alone,
+//  1.5 % off the step with three batches in flight, where the strips' workgroups compete for the same issue slots.  A third
+//  register set (the loads of TWO pairs in flight) was measured too: 80 VGPRs, 6 waves, no gain.)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) void k_gather_orb(
     const FusedParams P, const uint8_t *__restrict__ pyramids, size_t pyr_stride,
     const uint32_t *__restrict__ stage_kp, const uint32_t *__restrict__ strip_count,
     const uint32_t *__restrict__ stage_desc,

@@ -504,6 +504,7 @@ PISLAM_EXPORT int pislam_ctx_set_option(pislam_ctx *c, const char *key, int valu
     c->opt_tile_cols = value;
   } else if (!strcmp(key, "orb_in_strip")) {
     c->opt_orb_in_strip = value != 0;
+
   } else if (!strcmp(key, "dist_rccl_single")) {
     c->opt_dist_rccl_single = value != 0;
   } else if (!strcmp(key, "bucket_round_up")) {

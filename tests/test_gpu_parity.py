@@ -815,9 +815,13 @@ def test_bench_step_with_the_c_abi_exchange_on_one_rank():
     assert "none" in res[0]["config"]["count_allgather"] and "none" in res[4]["config"]["count_allgather"]
     for r, s in zip(res[1:4], (1, 2, 3)):
         assert "C ABI" in r["config"]["count_allgather"] and r["config"]["streams"] == s
-        assert r["config"]["keypoints_per_pyramid"] == res[0]["config"]["keypoints_per_pyramid"] > 100
+        # every lane owns its own batch of pyramids (seeds): lane 0's batch is the same in every run
+        lanes = r["config"]["keypoints_per_step_by_lane"]
+        assert len(lanes) == s and lanes[0] == res[0]["config"]["keypoints_per_step_by_lane"][0] > 1600
+        assert len(set(lanes)) == s and r["config"]["input_buffers_per_lane"] == "distinct"
         assert r["config"]["launch"] == res[0]["config"]["launch"] == "hipGraph replay"
-    assert res[4]["config"]["keypoints_per_pyramid"] == res[0]["config"]["keypoints_per_pyramid"]
+    assert res[4]["config"]["keypoints_per_step_by_lane"][0] == res[0]["config"]["keypoints_per_step_by_lane"][0]
+    assert len(res[4]["config"]["keypoints_per_step_by_lane"]) == 3
 
 
 def test_bench_self_launch_two_ranks_sharing_this_gpu():

@@ -4,28 +4,37 @@
 # (separate --pmc passes: FETCH_SIZE | WRITE_SIZE | TCC | SQ), the bench lines (which quote those counters when the
 # kernel sources match), rocprofv3 --kernel-trace --stats of the same commands — and copies the counter JSONs to
 # profiles/ so that the bench lines of THIS run can already quote them.
-tag=${1:-r03}
+tag=${1:-r04}
 root=${GRAFT_REPO_ROOT:-$(pwd)}
 out=$root/gpurun_out/$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
-for w in vga 1280x960 720p-build; do
-  b=256; [ $w = 720p-build ] && b=64
-  args="--steps 3 --warmup 1 --streams 1 --graph 0 --no-cpu-baseline --spin-s 0.2 --workload $w --batch $b"
+pmc_passes() {   # <name> <workload> <batch> <bench args...>: four separate --pmc passes -> counters_<name>.json (+ profiles/)
+  name=$1; w=$2; b=$3; shift 3
+  args="--steps 3 --warmup 1 --graph 0 --no-cpu-baseline --spin-s 0.2 --workload $w --batch $b $*"
   i=0
   for pmc in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_BUSY_CYCLES"; do
-    rocprofv3 --kernel-trace --pmc $pmc --output-format csv -d $out/pmc_${w}_$i -o p -- python $root/bench.py $args > /dev/null 2>&1
+    rocprofv3 --kernel-trace --pmc $pmc --output-format csv -d $out/pmc_${name}_$i -o p -- python $root/bench.py $args > /dev/null 2>&1
     i=$((i+1))
   done
-  (cd $root && python tools/counters_json.py $out/counters_$w.json $w $b "bench.py $args" $out/pmc_${w}_0 $out/pmc_${w}_1 $out/pmc_${w}_2 $out/pmc_${w}_3)
-  cp $out/counters_$w.json $root/profiles/${tag}_counters_$w.json
-  rm -rf $out/pmc_${w}_*
+  (cd $root && python tools/counters_json.py $out/counters_$name.json $w $b "bench.py $args" $out/pmc_${name}_0 $out/pmc_${name}_1 $out/pmc_${name}_2 $out/pmc_${name}_3)
+  cp $out/counters_$name.json $root/profiles/${tag}_counters_$name.json
+  rm -rf $out/pmc_${name}_*
+}
+for w in vga 1280x960 720p-build; do
+  b=256; [ $w = 720p-build ] && b=64
+  pmc_passes $w $w $b --streams 1
 done
+# the headline configuration itself: three batches in flight, every lane its own input (HBM bytes / L2 hits per step then)
+pmc_passes vga_streams3 vga 256 --streams 3
+# the README bucket mode <4,3>
+pmc_passes vga_buckets43 vga 256 --streams 1 --log-bucket-size 4 --bucket-limit 3
 cd /tmp
 python $root/bench.py --steps 50 --warmup 10 > $out/bench_vga.json 2> $out/bench_vga.err
 python $root/bench.py --steps 50 --warmup 10 --workload 1280x960 --batch 256 --cpu-seconds 5 > $out/bench_1280x960.json 2> $out/bench_1280x960.err
 python $root/bench.py --steps 50 --warmup 10 --workload 720p-build --batch 64 --cpu-seconds 5 > $out/bench_720p-build.json 2> $out/bench_720p-build.err
 python $root/bench.py --steps 50 --warmup 10 --streams 1 --no-cpu-baseline > $out/bench_vga_streams1.json 2> /dev/null
+python $root/bench.py --steps 50 --warmup 10 --shared-input --no-cpu-baseline > $out/bench_vga_shared_input.json 2> /dev/null
 python $root/bench.py --steps 50 --warmup 10 --log-bucket-size 4 --bucket-limit 3 --no-cpu-baseline > $out/bench_vga_buckets43.json 2> /dev/null
 python $root/bench.py --gpus 2 --dist-backend gloo --steps 20 --warmup 5 --batch 128 --no-cpu-baseline > $out/bench_vga_2ranks_one_gpu_gloo.json 2> $out/bench_2ranks.err
 python $root/bench.py --gpus 8 --dist-backend gloo --steps 20 --warmup 5 --batch 32 --no-cpu-baseline > $out/bench_vga_8ranks_one_gpu_gloo.json 2> /dev/null
@@ -50,7 +59,9 @@ P
 (cd $root && make -s -C tools pislam_demo > /dev/null 2>&1; for s in 3 1; do tools/pislam_demo /tmp/demo_pyramid.raw --batch 256 --steps 100 --streams $s; done) > $out/cpp_tool_demo_photo_x256.txt 2>&1
 # per-phase instruction counts of the strip kernel (cumulative ablations of the profiling build)
 (cd $root && bash tools/pmc_ablate.sh --streams 1) > $out/phase_ablation.txt 2>&1
+(cd $root && bash tools/pmc_ablate.sh --streams 1 --log-bucket-size 4 --bucket-limit 3) > $out/phase_ablation_buckets43.txt 2>&1
 rm -rf $root/gpurun_out/abl_*
 # workgroup wall-clock share of the strip kernel's phases (clock64 around the phases of every strip, profiling build):
 # cycles per strip of one eager launch (the first lines: the later ones come from bench.py's 16-launch bracket)
 python $root/bench.py --steps 3 --warmup 1 --streams 1 --graph 0 --no-cpu-baseline --ablate 8192 2>&1 | grep "cycles/strip" | head -3 > $out/phase_cycles.txt
+python $root/bench.py --steps 3 --warmup 1 --streams 1 --graph 0 --no-cpu-baseline --ablate 8192 --log-bucket-size 4 --bucket-limit 3 2>&1 | grep "cycles/strip" | head -3 > $out/phase_cycles_buckets43.txt
