@@ -989,6 +989,7 @@ __device__ __forceinline__ void strip_body(const StripArgs A, const FusedLevel L
           kept = (uint32_t)__popcll(km);
         }
         if (tid == 0) strip_count[(size_t)pyr * A.strips_per_pyr + L.strip0 + s] = kept | (orb ? STRIP_DESCRIBED : 0u);
+        mark(4);
         if (orb && ns > 0) describe_strip(ns, my_rank);
         return;
       }

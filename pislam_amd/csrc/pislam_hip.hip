@@ -505,6 +505,8 @@ PISLAM_EXPORT int pislam_ctx_set_option(pislam_ctx *c, const char *key, int valu
   } else if (!strcmp(key, "orb_in_strip")) {
     c->opt_orb_in_strip = value != 0;
 
+
+
   } else if (!strcmp(key, "dist_rccl_single")) {
     c->opt_dist_rccl_single = value != 0;
   } else if (!strcmp(key, "bucket_round_up")) {
@@ -948,6 +950,10 @@ PISLAM_EXPORT int pislam_pyramid_build_batch(pislam_ctx *c, int nlevels, const i
   //  level k+1 kept in LDS — was built and measured: 184 vs 167 us per 64 frames, 667 vs 584 us per 256.  The
   //  64-frame pyramid set fits the 256 MiB Infinity Cache, so the re-read the fusion saves never reaches HBM,
   //  and the LDS round trips cost more than k_bilinear4's register-only path.)
+  // (The small levels in ONE launch — one 1024-thread workgroup per pyramid walking levels 3 .. 7 through k_bilinear4's
+  //  work items, a device-scope fence + barrier between levels — was built in round 4, bit-exact, and measured: the step of
+  //  64 720p frames 0.375 -> 0.53 ms from level 3 on, 0.59 ms from level 2 on: 64 workgroups with a handful of dependent
+  //  load -> compute -> store round trips each are far slower than five launches that fill the chip, launch floors included.)
   for (int l = 0; l + 1 < nlevels; l++) {
     const uint8_t *src = pyramids + (size_t)levels[l].row0 * vstep;
     uint8_t *dst = pyramids + (size_t)levels[l + 1].row0 * vstep;
@@ -1015,8 +1021,15 @@ bool build_fused_plan_rows(const pislam_ctx *c, const pislam_frontend_params *p,
   // ~16k pixels per strip, 16..28 rows, capped so that queues + tile + the minimum shared queue fit
   // 160 KiB / wgs where 16 rows allow it (VGA at 5 per CU: 24 rows at level 0, 28 below; measured 0.293 ms
   // vs 0.311 ms with 16-row strips).
+  // LDS pitch of an image tile row that stages columns [xbase, xend + 8): a multiple of 16 bytes.  (An ODD number of
+  // 16-byte vectors — consecutive rows 4 banks apart instead of column x of every row in one bank at VGA level 0's 640
+  // bytes — was measured in round 4: bit-exact, the strip kernel within 0.5 % either way: the per-candidate reads'
+  // bank conflicts, 45 % of its LDS cycles, come from the candidates' random columns, not from the row pitch.)
+  auto tile_pitch = [&](int xend_l) -> int {
+    return (xend_l - p->border + ((p->border - 4) & 15) + 4 + 8 + 15) & ~15;
+  };
   auto alias_rows = [&](int xend_l, int w, int wgs) -> int {
-    const int tpitch_l = (xend_l - p->border + ((p->border - 4) & 15) + 4 + 8 + 15) & ~15;
+    const int tpitch_l = tile_pitch(xend_l);
     const long budget = 160 * 1024 / wgs - (long)(pf::WAVES * pf::QCAP + pf::QH_SHARED) * 4;
     const int rcap = (int)(budget / tpitch_l - 10) & ~1;
     if (wgs != 5 && rcap < 10) return 0;              // (an explicit residency request falls back to the generic rule)
@@ -1124,7 +1137,7 @@ bool build_fused_plan_rows(const pislam_ctx *c, const pislam_frontend_params *p,
         // vs 0.371 ms with 16-row strips) where that still fits the residency budget, DOWN on the levels where it
         // does not: the launch has ONE LDS size, a single level over the budget costs every level its fifth workgroup
         const int up = std::min(std::max(bs, 32), ((R + bs - 1) / bs) * bs), down = std::max(bs, (R / bs) * bs);
-        const int tp = (xend_l - p->border + ((p->border - 4) & 15) + 4 + 8 + 15) & ~15;
+        const int tp = tile_pitch(xend_l);
         const long need = (long)(pf::WAVES * pf::QCAP + pf::QH_SHARED) * 4 + (long)(up + 10) * tp;
         R = (c->opt_bucket_round_up || need <= 160 * 1024 / alias_wgs - 1280) ? up : down;
       } else
@@ -1137,9 +1150,7 @@ bool build_fused_plan_rows(const pislam_ctx *c, const pislam_frontend_params *p,
     L.pitch = (L.xend + 4 + 15) & ~15;
     {
       // staged columns [xbase, xbase+tpitch) with xbase = (border-4) & ~15 must reach column xend+8
-      const int ncols = L.xend - p->border;
-      const int lead = ((p->border - 4) & 15) + 4;            // border - xbase
-      L.tpitch = (ncols + lead + 8 + 15) & ~15;
+      L.tpitch = tile_pitch(L.xend);
     }
     L.vpr_recip = (uint32_t)(((1ull << 32) + (L.tpitch / 16) - 1) / (L.tpitch / 16));
     L.tp_recip = (uint32_t)(((1ull << 32) + L.tpitch - 1) / L.tpitch);
