@@ -969,18 +969,28 @@ __device__ __forceinline__ void strip_body(const StripArgs A, const FusedLevel L
         if (wave == 0) {
           const uint32_t v = lane < ns ? shq_s[lane] : 0u;
           const uint32_t cell = lane < ns ? ((((uint32_t)(decode_y(v) - B) >> lbs) << 12) | ((uint32_t)(decode_x(v) - B) >> lbs)) : 0xffffffffu;
-          int greater = 0;
-          for (int j = 0; j < ns; j++) {
-            const uint32_t cj = (uint32_t)__builtin_amdgcn_readlane((int)cell, j), vj = (uint32_t)__builtin_amdgcn_readlane((int)v, j);
-            greater += (cj == cell) & (vj > v);
+          // ONE pass over the survivors: how many of the same cell are larger (-> kept iff fewer than `limit`), and how
+          // many precede this one in (cell, value) order; then the few DROPPED ones (each cell's smallest) that precede
+          // it are taken off again — a loop over the set bits of their ballot, usually none to three.
+          int greater = 0, g1 = 0, less = 0, l1 = 0;
+          for (int j = 0; j < ns; j += 2) {               // (lanes >= ns hold cell 0xffffffff: never equal, never smaller)
+            const uint32_t c0 = (uint32_t)__builtin_amdgcn_readlane((int)cell, j), v0 = (uint32_t)__builtin_amdgcn_readlane((int)v, j);
+            const uint32_t c1 = (uint32_t)__builtin_amdgcn_readlane((int)cell, j + 1), v1 = (uint32_t)__builtin_amdgcn_readlane((int)v, j + 1);
+            greater += (c0 == cell) & (v0 > v);
+            g1 += (c1 == cell) & (v1 > v);
+            less += (c0 < cell) | ((c0 == cell) & (v0 < v));
+            l1 += (c1 < cell) | ((c1 == cell) & (v1 < v));
           }
+          greater += g1;
+          int rank = less + l1;
           const bool keep = lane < ns && greater < limit;
           const uint64_t km = __ballot(keep);
-          int rank = 0;
-          for (int j = 0; j < ns; j++) {
-            if (!((km >> j) & 1)) continue;             // (wave-uniform)
+          uint64_t dm = __ballot(lane < ns && !keep);
+          while (dm) {
+            const int j = __builtin_ctzll(dm);
+            dm &= dm - 1;
             const uint32_t cj = (uint32_t)__builtin_amdgcn_readlane((int)cell, j), vj = (uint32_t)__builtin_amdgcn_readlane((int)v, j);
-            rank += (cj < cell) | ((cj == cell) & (vj < v));
+            rank -= (cj < cell) | ((cj == cell) & (vj < v));
           }
           if (keep) {
             stage_kp[strip_slot + rank] = v + add_xy;

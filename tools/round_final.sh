@@ -1,0 +1,18 @@
+#!/bin/bash
+# usage (GPU box): bash tools/round_final.sh <tag> — the round's closing run: GPU suite, fuzz campaign on the final sources
+# (hash recorded), then tools/profile_round.sh
+tag=${1:-r04}
+root=${GRAFT_REPO_ROOT:-$(pwd)}
+out=$root/gpurun_out/$tag; mkdir -p $out
+cd $root
+(time timeout 1500 python -m pytest tests -m gpu -q --durations=5) > $out/pytest_gpu.log 2>&1
+grep -n "passed\|failed" $out/pytest_gpu.log | tail -3
+h=$(python -c "from pislam_amd import build; print(build.source_hash())")
+{
+  echo "# python tests/fuzz_campaign.py --seeds 20000 --wide --start 2500000; --seeds 60000 --start 2700000 (kernel sources $h)"
+  timeout 1200 python tests/fuzz_campaign.py --seeds 20000 --wide --start 2500000 | tail -3
+  timeout 1200 python tests/fuzz_campaign.py --seeds 60000 --start 2700000 | tail -3
+} > $out/fuzz.txt 2>&1
+tail -2 $out/fuzz.txt
+bash tools/profile_round.sh $tag > $out/profile_round.log 2>&1
+tail -5 $out/profile_round.log
