@@ -68,6 +68,10 @@ int pislam_ctx_set_stream(pislam_ctx *ctx, void *hip_stream);
  *   "run_order"  1 (default) a pyramid's runs are launched longest first, 0 in level order
  *   "tile_cols"  levels with more classified columns are cut into x-tiles run by separate workgroups (0 = 704, < 0 never)
  *   "orb_in_strip" 1 strips describe their own keypoints right after their NMS, 0 (default) one gather+ORB pass describes all
+ *   "bucket_select" fused batch path with log_bucket_size != 0: 1 (default) the strips run as without buckets and a selection
+ *                pass between strip kernel and gather keeps each bucket's bucket_limit largest keypoints (log_bucket_size 1..8);
+ *                0 the selection happens inside the strips (strips cut on bucket rows; log_bucket_size 2..5, others take the
+ *                staged pipeline)
  *   "wgs_per_cu", "strip_px", "strip_rows_max", "lds_pad", "bucket_round_up", "repeat_strips", "ablate"  profiling only (ablate != 0 gives INVALID results by design)
  *   "match_mfma" 1 (default) pislam_match_hamming* run on the int8 matrix cores, 0 the VALU popcount kernel (same results)
  *   "dist_rccl_single" test hook: pislam_dist_init(world = 1) still creates a 1-rank RCCL communicator */

@@ -1433,6 +1433,199 @@ __global__ __launch_bounds__(256) void k_gather(const FusedParams P,
   }
 }
 
+// ===========================================================================
+// k_bucket_select — fastExtract's buckets (Fast.h:200-226, 314-352) as a pass of their own between the strip kernel
+// and the gather: the strips run exactly as without buckets (plain block-raster lists per strip, any strip height),
+// and ONE WAVE per unit = (pyramid, level, cell row = 2^lbs rows of block origins) collects the unit's NMS survivors
+// from the lists of the strips that overlap its rows (all x-tiles of the level), keeps each bucket's `limit` largest
+// packed words, and writes them in the reference's flush order — bucket index, then ascending word (Fast.h:321-352) —
+// to the unit's slots of a second staging area.  k_gather_orb / k_gather then run on a UNIT plan (one "strip" per
+// unit, lists already final, no tiles), i.e. concatenate.  A cell row never depends on another: no state is carried.
+//   bucket of a survivor = (x - B) >> lbs and cell row = (y - B) >> lbs of the WINNER pixel (level-relative): the
+//   reference uses the block origin (Fast.h:316), which differs by at most one in each coordinate and never across a
+//   bucket boundary (origins are even offsets from B, 2^lbs is even).  Packed words compare alike in stacked and
+//   level-relative coordinates (the same offsets are added to every word of a level).
+// ===========================================================================
+struct SelectPlan {
+  int nlevels, lbs, limit, border;
+  int units_per_pyr, uslots_per_pyr;
+  int row0[16], col0[16], h[16];      // the level (not its tiles)
+  int g0[16], gn[16];                 // its plan entries in the strip plan
+  int unit0[16], nunits[16];          // its units (cell rows)
+  int cap[16], uslot0[16];            // slots per unit (buckets x limit), first slot of the level
+  int nb_max;                         // most buckets of any level (the dense path's LDS counters: 2 x nb_max dwords per wave)
+};
+constexpr int SEL_WAVES = 4;
+constexpr int SEL_NB = 1024;                         // buckets per cell row the dense path's LDS counters hold (the host checks)
+__global__ __launch_bounds__(64 * SEL_WAVES) void k_bucket_select(const FusedParams F, const SelectPlan Q,
+                                                                   const uint32_t *__restrict__ stage_kp,
+                                                                   const uint32_t *__restrict__ strip_count,
+                                                                   uint32_t *__restrict__ ustage, uint32_t *__restrict__ ucount) {
+  // dynamic LDS, per wave: [64 survivors of the fast path][nb_max per-bucket counts][nb_max kept entries before the bucket]
+  // (sized by the host from the level table: static arrays for the worst case cost the kernel its occupancy — it is a
+  //  chain of dependent loads per wave, its duration is the number of rounds of resident waves)
+  extern __shared__ uint32_t sel_lds[];
+  const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  uint32_t *sbuf = sel_lds + (size_t)wv * (64 + 2 * Q.nb_max);
+  uint32_t *bcnt = sbuf + 64, *bpre = bcnt + Q.nb_max;
+  const int pyr = blockIdx.y, u = (int)blockIdx.x * SEL_WAVES + wv;
+  if (u >= Q.units_per_pyr) return;
+  int l = 0;
+  while (l + 1 < Q.nlevels && u >= Q.unit0[l + 1]) l++;
+  const int cr = u - Q.unit0[l], lbs = Q.lbs, limit = Q.limit, B = Q.border;
+  const int y0 = B + (cr << lbs), y1 = min(y0 + (1 << lbs), Q.h[l] - B);        // level-relative rows of the unit
+  const int yrow0 = Q.row0[l], xcol0 = Q.col0[l] + B;
+  const uint32_t *stage = stage_kp + (size_t)pyr * F.slots_per_pyr;
+  const uint32_t *cnt = strip_count + (size_t)pyr * F.strips_per_pyr;
+  uint32_t *out = ustage + (size_t)pyr * Q.uslots_per_pyr + Q.uslot0[l] + (size_t)cr * Q.cap[l];
+  // every chunk of 64 staged entries of the strips that overlap the unit's rows: f(v, in) with in = the lane holds a
+  // survivor of this unit
+  auto for_each_chunk = [&](auto f) {
+    for (int t = 0; t < Q.gn[l]; t++) {
+      const int e = Q.g0[l] + t, R = F.lv[e].R;
+      const int s_lo = (y0 - B) / R, s_hi = min((y1 - 1 - B) / R, F.lv[e].nstrips - 1);
+      for (int sidx = s_lo; sidx <= s_hi; sidx++) {
+        const uint32_t n = cnt[F.lv[e].strip0 + sidx] & ~STRIP_DESCRIBED;
+        const uint32_t *list = stage + F.lv[e].slot0 + (size_t)sidx * (R >> 1) * F.lv[e].nbx;
+        for (uint32_t q0 = 0; q0 < n; q0 += 64) {
+          const uint32_t q = q0 + (uint32_t)lane;
+          const uint32_t v = q < n ? list[q] : 0u;
+          // (cell row of the winner pixel = cell row of its block origin: see above)
+          f(v, q < n && (int)((uint32_t)(decode_y(v) - yrow0 - B) >> lbs) == cr);
+        }
+      }
+    }
+  };
+  auto bucket_of = [&](uint32_t v) -> uint32_t { return (uint32_t)(decode_x(v) - xcol0) >> lbs; };
+  // ---- collect (at most 64: the fast path keeps them in the wave's lanes) ----
+  int n_unit = 0;
+  auto collect = [&](uint32_t v, bool in) {
+    const uint64_t m = __ballot(in);
+    if (in) {
+      const int at = n_unit + ballot_rank(m);
+      if (at < 64) sbuf[at] = v;
+    }
+    n_unit += __popcll(m);
+  };
+  // The lists that overlap the unit (one to three strips of one to three tiles): lane j notes list j's place, the counts
+  // come in with ONE load, and the first 64 entries of every list are requested before any of them is looked at (a
+  // strip's slots exist whatever its count — the staging buffer carries 64 dwords of slack past its last strip): two
+  // memory round trips per unit instead of one or two per list.
+  constexpr int ML = 6;
+  uint32_t loff = 0, lcidx = 0;
+  int nl = 0;
+  for (int t = 0; t < Q.gn[l]; t++) {
+    const int e = Q.g0[l] + t, R = F.lv[e].R;
+    const int s_lo = (y0 - B) / R, s_hi = min((y1 - 1 - B) / R, F.lv[e].nstrips - 1);
+    for (int sidx = s_lo; sidx <= s_hi; sidx++) {
+      if (lane == nl) {
+        loff = (uint32_t)(F.lv[e].slot0 + sidx * (R >> 1) * F.lv[e].nbx);
+        lcidx = (uint32_t)(F.lv[e].strip0 + sidx);
+      }
+      nl++;
+    }
+  }
+  if (nl <= ML) {
+    const uint32_t mycnt = lane < nl ? (cnt[lcidx] & ~STRIP_DESCRIBED) : 0u;
+    uint32_t vj[ML];
+#pragma unroll
+    for (int j = 0; j < ML; j++)
+      if (j < nl) vj[j] = stage[(uint32_t)__builtin_amdgcn_readlane((int)loff, j) + (uint32_t)lane];
+#pragma unroll
+    for (int j = 0; j < ML; j++)
+      if (j < nl) {
+        const uint32_t n = (uint32_t)__builtin_amdgcn_readlane((int)mycnt, j);
+        collect(vj[j], (uint32_t)lane < n && (int)((uint32_t)(decode_y(vj[j]) - yrow0 - B) >> lbs) == cr);
+        const uint32_t *list = stage + (uint32_t)__builtin_amdgcn_readlane((int)loff, j);
+        for (uint32_t q0 = 64; q0 < n; q0 += 64) {                               // (a list of more than 64 entries: dense input)
+          const uint32_t q = q0 + (uint32_t)lane;
+          const uint32_t v = q < n ? list[q] : 0u;
+          collect(v, q < n && (int)((uint32_t)(decode_y(v) - yrow0 - B) >> lbs) == cr);
+        }
+      }
+  } else {
+    for_each_chunk(collect);
+  }
+  if (n_unit == 0) {
+    if (lane == 0) ucount[(size_t)pyr * Q.units_per_pyr + u] = 0;
+    return;
+  }
+  if (n_unit <= 64) {
+    const uint32_t v = lane < n_unit ? sbuf[lane] : 0u;                    // (same wave wrote them: no barrier)
+    const uint32_t b = lane < n_unit ? bucket_of(v) : 0xffffffffu;
+    // one pass: larger words of the same bucket (kept iff fewer than `limit`), entries that precede in (bucket, word)
+    // order; then the dropped ones (each bucket's smallest) that precede are taken off again
+    int greater = 0, g1 = 0, less = 0, l1 = 0;
+    for (int j = 0; j < n_unit; j += 2) {                                        // (lanes >= n_unit: bucket 0xffffffff)
+      const uint32_t b0 = (uint32_t)__builtin_amdgcn_readlane((int)b, j), v0 = (uint32_t)__builtin_amdgcn_readlane((int)v, j);
+      const uint32_t b1 = (uint32_t)__builtin_amdgcn_readlane((int)b, j + 1), v1 = (uint32_t)__builtin_amdgcn_readlane((int)v, j + 1);
+      greater += (b0 == b) & (v0 > v);
+      g1 += (b1 == b) & (v1 > v);
+      less += (b0 < b) | ((b0 == b) & (v0 < v));
+      l1 += (b1 < b) | ((b1 == b) & (v1 < v));
+    }
+    greater += g1;
+    int rank = less + l1;
+    const bool keep = lane < n_unit && greater < limit;
+    const uint64_t km = __ballot(keep);
+    uint64_t dm = __ballot(lane < n_unit && !keep);
+    while (dm) {
+      const int j = __builtin_ctzll(dm);
+      dm &= dm - 1;
+      const uint32_t bj = (uint32_t)__builtin_amdgcn_readlane((int)b, j), vj = (uint32_t)__builtin_amdgcn_readlane((int)v, j);
+      rank -= (bj < b) | ((bj == b) & (vj < v));
+    }
+    if (keep) out[rank] = v;
+    if (lane == 0) ucount[(size_t)pyr * Q.units_per_pyr + u] = (uint32_t)__popcll(km);
+    return;
+  }
+  // ---- dense unit (more than 64 survivors): per-bucket counts in LDS, then every survivor against all others ----
+  const int ncx = Q.cap[l] / limit;                                             // buckets of this level (<= SEL_NB: the host checks)
+  for (int i = lane; i < ncx; i += 64) bcnt[i] = 0;
+  for_each_chunk([&](uint32_t v, bool in) {
+    if (in) atomicAdd(&bcnt[bucket_of(v)], 1u);
+  });
+  // kept entries of the buckets before bucket i: exclusive prefix of min(count, limit) — SEL_NB / 64 buckets per lane
+  constexpr int PER = SEL_NB / 64;
+  uint32_t sum = 0;
+  for (int k = 0; k < PER; k++) {
+    const int i = PER * lane + k;
+    sum += i < ncx ? min(bcnt[i], (uint32_t)limit) : 0u;
+  }
+  uint32_t incl = sum;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t t = (uint32_t)__shfl_up((int)incl, d, 64);
+    if (lane >= d) incl += t;
+  }
+  const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+  uint32_t run = incl - sum;
+  for (int k = 0; k < PER; k++) {
+    const int i = PER * lane + k;
+    if (i < ncx) {
+      bpre[i] = run;
+      run += min(bcnt[i], (uint32_t)limit);
+    }
+  }
+  for_each_chunk([&](uint32_t v, bool in) {
+    const uint32_t b = in ? bucket_of(v) : 0xffffffffu;
+    int greater = 0, smaller = 0;
+    for_each_chunk([&](uint32_t w, bool win) {
+      const uint32_t bw = win ? bucket_of(w) : 0xfffffffeu;
+      for (int j = 0; j < 64; j++) {
+        const uint32_t bj = (uint32_t)__builtin_amdgcn_readlane((int)bw, j), wj = (uint32_t)__builtin_amdgcn_readlane((int)w, j);
+        greater += (bj == b) & (wj > v);
+        smaller += (bj == b) & (wj < v);
+      }
+    });
+    if (in && greater < limit) {
+      const uint32_t c = bcnt[b];
+      out[bpre[b] + (uint32_t)smaller - (c - min(c, (uint32_t)limit))] = v;
+    }
+  });
+  if (lane == 0) ucount[(size_t)pyr * Q.units_per_pyr + u] = total;
+}
+
 // Small shared state of the gather + ORB role, carved from the FRONT of the dynamic LDS (not static: the strip
 // role's 5-workgroups-per-CU budget has no room for another 300 static bytes).
 struct OrbShared {

@@ -102,6 +102,7 @@ struct pislam_ctx {
   DevBuf w_cnt, w_off, w_total, w_cellkp;
   // batch pipeline workspace
   DevBuf w_score, w_stage, w_stripcnt, w_work, w_prof, w_ovf, w_stagedesc;
+  DevBuf w_ustage, w_ucount;         // bucket selection pass (pf::k_bucket_select): per-unit lists and counts
   int num_cus = 0;
   int opt_pipeline = 0;      // 0 auto, 1 staged (one launch group per level), 2 fused strips
   int opt_dump_score = 0;    // fused pipeline: also materialise the score map (parity hook)
@@ -119,6 +120,7 @@ struct pislam_ctx {
   int opt_strip_rows_max = 0;    // profiling: upper bound of the heuristic strip height (0 = rule in build_fused_plan)
   int opt_run_order = 1;     // fused pipeline: launch a pyramid's runs longest first (0: in entry order)
   int opt_tile_cols = 0;     // fused pipeline: levels with more classified columns are cut into x-tiles (0 = 704, < 0 = never)
+  int opt_bucket_select = 1; // fused pipeline, buckets: 1 = strips as without buckets + pf::k_bucket_select (default), 0 = the strips select (round 1-3)
   int opt_orb_in_strip = 0;  // fused pipeline: 1 = strips describe their own keypoints (measured slower: DESIGN.md §8), 0 = k_gather_orb describes all
   int opt_match_mfma = 1;         // matcher on the matrix cores (0: the VALU popcount kernel)
   int opt_dist_rccl_single = 0;   // test hook: pislam_dist_init(world = 1) still creates a (1-rank) RCCL communicator
@@ -148,7 +150,7 @@ struct pislam_ctx {
   unsigned long long workspace_generation() const {
     unsigned long long g = ovf_layouts;
     for (const DevBuf *b : {&w_cnt, &w_off, &w_total, &w_cellkp, &w_score, &w_stage, &w_stripcnt, &w_work, &w_prof,
-                            &w_ovf, &w_stagedesc})
+                            &w_ovf, &w_stagedesc, &w_ustage, &w_ucount})
       g += b->reallocs;
     return g;
   }
@@ -421,7 +423,7 @@ PISLAM_EXPORT int pislam_ctx_destroy(pislam_ctx *c) {
   (void)hipStreamSynchronize(c->stream);
   for (DevBuf *b : {&c->s_img, &c->s_out, &c->s_pts, &c->s_desc, &c->s_misc, &c->s_rots, &c->s_tmp, &c->w_cnt,
                     &c->w_off, &c->w_total, &c->w_cellkp, &c->w_score, &c->w_stage, &c->w_stripcnt, &c->w_work, &c->w_prof, &c->w_ovf,
-                    &c->w_stagedesc})
+                    &c->w_stagedesc, &c->w_ustage, &c->w_ucount})
     b->release();
   for (auto &e : c->ev)
     if (e) (void)hipEventDestroy(e);
@@ -504,6 +506,8 @@ PISLAM_EXPORT int pislam_ctx_set_option(pislam_ctx *c, const char *key, int valu
     c->opt_tile_cols = value;
   } else if (!strcmp(key, "orb_in_strip")) {
     c->opt_orb_in_strip = value != 0;
+  } else if (!strcmp(key, "bucket_select")) {
+    c->opt_bucket_select = value != 0;
 
 
 
@@ -1012,8 +1016,19 @@ bool build_fused_plan_rows(const pislam_ctx *c, const pislam_frontend_params *p,
   F->limit = p->bucket_limit;
   F->words = p->words;
   F->orb_in_strip = c->opt_orb_in_strip;
-  // fused bucket mode: cells of 4..32 px (they must fit a strip and the per-wave scratch)
-  if (p->log_bucket_size != 0 && (p->log_bucket_size < 2 || p->log_bucket_size > 5)) return false;
+  // Buckets (fastExtract<.., logBucketSize, bucketLimit>): by default the strips run exactly as without buckets (F->lbs = 0:
+  // any strip height, the plain kernels) and pf::k_bucket_select applies the per-cell top-`limit` between the strip kernel and
+  // the gather (run_fused); option "bucket_select" 0 keeps the selection inside the strips (rounds 1-3: strips cut on bucket
+  // rows, cells of 4..32 px).
+  bool select = p->log_bucket_size != 0 && c->opt_bucket_select;
+  for (int l = 0; l < p->nlevels && select; l++)
+    if (lv[l].width - 2 * p->border > 0 && ((lv[l].width - 2 * p->border - 1) >> p->log_bucket_size) + 1 > pf::SEL_NB) select = false;
+  if (select) {
+    F->lbs = 0;
+    F->orb_in_strip = 0;
+  }
+  // fused bucket mode inside the strips: cells of 4..32 px (they must fit a strip and the per-wave scratch)
+  if (F->lbs != 0 && (p->log_bucket_size < 2 || p->log_bucket_size > 5)) return false;
   F->ablate = c->opt_ablate;
   int strips = 0, slots = 0, runs = 0;
   size_t lds = 0, lds_alias = 0;
@@ -1130,7 +1145,7 @@ bool build_fused_plan_rows(const pislam_ctx *c, const pislam_frontend_params *p,
         }
       }
     }
-    if (p->log_bucket_size) {            // strips hold whole bucket rows
+    if (F->lbs) {                        // (selection inside the strips:) strips hold whole bucket rows
       const int bs = 1 << p->log_bucket_size;
       if (c->opt_strip_rows == 0 && c->opt_alias) {
         // heuristic height: round UP to whole bucket rows (16-px buckets: 32-row strips — measured 0.315 ms
@@ -1310,10 +1325,74 @@ int run_fused(pislam_ctx *c, const pislam_frontend_params *p, const pf::FusedPar
               const uint8_t *pyramids, size_t stride, int batch, int nsub, uint32_t *kp, uint32_t *desc, uint32_t *counts) {
   const int S = Fplan.strips_per_pyr;
   const int submax = sub_max(batch, nsub);
+  // Buckets with the strips run as without (build_fused_plan_rows): the selection pass and the UNIT plan the gather runs on —
+  // one "strip" per (level, cell row), `buckets x limit` slots each, lists final (lbs != 0, no tiles: the gather concatenates).
+  const bool sel = p->log_bucket_size != 0 && Fplan.lbs == 0;
+  pf::SelectPlan Q;
+  pf::FusedParams U;
+  memset(&Q, 0, sizeof(Q));
+  memset(&U, 0, sizeof(U));
+  if (sel) {
+    const int lbs = p->log_bucket_size, bs = 1 << lbs, B = p->border;
+    Q.lbs = lbs;
+    Q.limit = p->bucket_limit;
+    Q.border = B;
+    int nreal = 0;
+    for (int e = 0; e < Fplan.nlevels; e++) {
+      if (Fplan.lv[e].gfirst != e) continue;           // (the tiles of a level follow its first entry)
+      if (nreal >= 16) return fail(c, PISLAM_ERR_INVALID, "too many levels for the bucket selection pass");
+      const int l = nreal++;
+      const int gn = std::max(1, Fplan.lv[e].gn);
+      const pf::FusedLevel &last = Fplan.lv[e + gn - 1];
+      const int wl = last.col0 + last.w - Fplan.lv[e].col0, hl = Fplan.lv[e].h;       // the level's own size
+      const int nx = wl - 2 * B, ny = hl - 2 * B;
+      Q.row0[l] = Fplan.lv[e].row0;
+      Q.col0[l] = Fplan.lv[e].col0;
+      Q.h[l] = hl;
+      Q.g0[l] = e;
+      Q.gn[l] = gn;
+      Q.unit0[l] = Q.units_per_pyr;
+      Q.nunits[l] = (nx > 0 && ny > 0) ? cdiv(ny, bs) : 0;
+      Q.cap[l] = (nx > 0 ? ((nx - 1) >> lbs) + 1 : 1) * p->bucket_limit;             // Fast.h:201 numBuckets x bucketLimit
+      Q.uslot0[l] = Q.uslots_per_pyr;
+      Q.nb_max = std::max(Q.nb_max, Q.cap[l] / p->bucket_limit);
+      Q.units_per_pyr += Q.nunits[l];
+      Q.uslots_per_pyr += Q.nunits[l] * Q.cap[l];
+      pf::FusedLevel &ul = U.lv[l];
+      ul.w = wl;
+      ul.h = hl;
+      ul.row0 = Q.row0[l];
+      ul.col0 = Q.col0[l];
+      ul.R = 2;                                        // strip_slot_of: slot0 + s * (R >> 1) * nbx
+      ul.nbx = Q.cap[l];
+      ul.nstrips = Q.nunits[l];
+      ul.strip0 = Q.unit0[l];
+      ul.slot0 = Q.uslot0[l];
+      ul.gfirst = l;
+      ul.gn = 1;
+    }
+    Q.nlevels = nreal;
+    U.nlevels = nreal;
+    U.strips_per_pyr = Q.units_per_pyr;
+    U.slots_per_pyr = Q.uslots_per_pyr;
+    U.vstep = p->vstep;
+    U.rows = p->rows;
+    U.border = B;
+    U.lbs = lbs;
+    U.limit = p->bucket_limit;
+    U.words = p->words;
+    U.ablate = Fplan.ablate;
+    if (Q.units_per_pyr == 0) return fail(c, PISLAM_ERR_INVALID, "no extractable level");
+    if (c->w_ustage.ensure(sizeof(uint32_t) * (size_t)Q.uslots_per_pyr * batch) != PISLAM_OK ||
+        c->w_ucount.ensure(sizeof(uint32_t) * (size_t)Q.units_per_pyr * batch) != PISLAM_OK)
+      return fail(c, PISLAM_ERR_NOMEM, "hipMalloc(bucket selection staging)");
+  }
+  const int Sg = sel ? Q.units_per_pyr : S;            // "strips" of the plan the gather runs on
   // descriptor staging: QS_SHARED slots of `words` dwords per strip (ALIAS strips hold at most QS_SHARED survivors)
   // (only strips that describe their own keypoints write there: option "orb_in_strip")
   const size_t sdesc_per_pyr = Fplan.orb_in_strip ? (size_t)S * pf::QS_SHARED * (size_t)p->words : 0;
-  if (c->w_stage.ensure(sizeof(uint32_t) * (size_t)Fplan.slots_per_pyr * batch) != PISLAM_OK ||
+  // (+ 64 dwords: pf::k_bucket_select requests the first 64 slots of a strip's list whatever its count)
+  if (c->w_stage.ensure(sizeof(uint32_t) * ((size_t)Fplan.slots_per_pyr * batch + 64)) != PISLAM_OK ||
       c->w_stripcnt.ensure(sizeof(uint32_t) * (size_t)S * batch) != PISLAM_OK ||
       c->w_stagedesc.ensure(sizeof(uint32_t) * sdesc_per_pyr * batch) != PISLAM_OK)
     return fail(c, PISLAM_ERR_NOMEM, "hipMalloc(fused staging)");
@@ -1396,7 +1475,7 @@ int run_fused(pislam_ctx *c, const pislam_frontend_params *p, const pf::FusedPar
     }
     if (c->opt_orb_chunks > 0) nch = c->opt_orb_chunks;
     per_max = ((size_t)p->max_keypoints + nch - 1) / nch;
-    olds = pf::orb_lds_bytes(S, per_max);
+    olds = pf::orb_lds_bytes(Sg, per_max);
     if (olds > 150 * 1024) return fail(c, PISLAM_ERR_INVALID, "max_keypoints too large for the fused ORB kernel");
     if (olds > 64 * 1024)
       HIPCHK(c, hipFuncSetAttribute((const void *)pf::k_gather_orb, hipFuncAttributeMaxDynamicSharedMemorySize, (int)olds));
@@ -1473,8 +1552,23 @@ int run_fused(pislam_ctx *c, const pislam_frontend_params *p, const pf::FusedPar
       PCHK(launch_ok(c, "k_fused_overflow"));
     }
     if (nsub == 1) HIPCHK(c, hipEventRecord(c->ev[2], M));   // stage 1 = the overflow pass (normally empty)
+    // the plan, lists and counts the gather runs on: the strips' own, or the units of the bucket selection pass
+    pf::FusedParams G = F;
+    const uint32_t *g_stage = s_stage, *g_cnt = s_cnt;
+    if (sel) {
+      uint32_t *u_stage = c->w_ustage.as<uint32_t>() + (size_t)first * Q.uslots_per_pyr;
+      uint32_t *u_cnt = c->w_ucount.as<uint32_t>() + (size_t)first * Q.units_per_pyr;
+      const size_t sel_lds = sizeof(uint32_t) * pf::SEL_WAVES * (64 + 2 * (size_t)Q.nb_max);
+      hipLaunchKernelGGL(pf::k_bucket_select, dim3(cdiv(Q.units_per_pyr, pf::SEL_WAVES), n), dim3(64 * pf::SEL_WAVES), sel_lds, X, F, Q,
+                         (const uint32_t *)s_stage, (const uint32_t *)s_cnt, u_stage, u_cnt);
+      PCHK(launch_ok(c, "k_bucket_select"));
+      G = U;
+      G.batch = n;
+      g_stage = u_stage;
+      g_cnt = u_cnt;
+    }
     if (generic_orb) {
-      hipLaunchKernelGGL(pf::k_gather, dim3(n), dim3(256), sizeof(uint32_t) * (S + 1), X, F, s_stage, s_cnt, s_kp,
+      hipLaunchKernelGGL(pf::k_gather, dim3(n), dim3(256), sizeof(uint32_t) * (Sg + 1), X, G, g_stage, g_cnt, s_kp,
                          (size_t)p->max_keypoints, (uint32_t)p->max_keypoints, s_counts, ovf);
       PCHK(launch_ok(c, "k_gather"));
       hipLaunchKernelGGL(pk::k_orb<0>, dim3(cdiv(p->max_keypoints, 4), 1, n), dim3(256), 0, X, s_pyr, p->vstep, stride,
@@ -1482,7 +1576,7 @@ int run_fused(pislam_ctx *c, const pislam_frontend_params *p, const pf::FusedPar
                          (size_t)p->max_keypoints * p->words, (int32_t *)nullptr, (const uint8_t *)nullptr);
       PCHK(launch_ok(c, "k_orb<batch>"));
     } else {
-      hipLaunchKernelGGL(pf::k_gather_orb, dim3(nch, n), dim3(256), olds, X, F, s_pyr, stride, s_stage, s_cnt,
+      hipLaunchKernelGGL(pf::k_gather_orb, dim3(nch, n), dim3(256), olds, X, G, s_pyr, stride, g_stage, g_cnt,
                          (const uint32_t *)s_sdesc, s_kp, (size_t)p->max_keypoints, (uint32_t)p->max_keypoints, s_counts,
                          s_desc, (size_t)p->max_keypoints * p->words, p->words, (uint32_t)per_max, ovf);
       PCHK(launch_ok(c, "k_gather_orb"));
@@ -1539,7 +1633,7 @@ PISLAM_EXPORT int pislam_frontend_reserve(pislam_ctx *c, const pislam_frontend_p
     size_t lds = 0, lds_alias = 0;
     const int nsub = choose_sub_batches(c, p, batch), submax = sub_max(batch, nsub);
     if (build_fused_plan(c, p, lv, submax, &F, &lds, &lds_alias) && F.strips_per_pyr > 0) {
-      if (c->w_stage.ensure(sizeof(uint32_t) * (size_t)F.slots_per_pyr * batch) != PISLAM_OK ||
+      if (c->w_stage.ensure(sizeof(uint32_t) * ((size_t)F.slots_per_pyr * batch + 64)) != PISLAM_OK ||
           c->w_stripcnt.ensure(sizeof(uint32_t) * (size_t)F.strips_per_pyr * batch) != PISLAM_OK ||
           (F.orb_in_strip &&
            c->w_stagedesc.ensure(sizeof(uint32_t) * (size_t)F.strips_per_pyr * batch * pf::QS_SHARED * (size_t)p->words) != PISLAM_OK))

@@ -38,7 +38,8 @@ def make_wide(seed):
     opts = dict(pipeline=2, alias=int(rng.choice([1, 1, 0])), run_len=int(rng.choice([0, 1, 2, 3, 5])),
                 strip_rows=int(rng.choice([0, 0, 0, 16, 20])), sub_batches=1 + int(rng.choice([0, 0, 0, 128])) // 48,
                 orb_in_strip=int(rng.choice([0, 0, 1])), tile_cols=int(rng.choice([0, 0, -1, 192, 256, 320, 448])),
-                strip_rows_max=int(rng.choice([0, 28, 36, 44, 56, 64])), run_order=int(rng.integers(0, 2)))
+                strip_rows_max=int(rng.choice([0, 28, 36, 44, 56, 64])), run_order=int(rng.integers(0, 2)),
+                bucket_select=int(rng.choice([1, 1, 0])))
     return levels, vstep, rows, pyr, par, opts
 
 

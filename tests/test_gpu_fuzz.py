@@ -35,7 +35,7 @@ def make_case(seed):
     opts = dict(pipeline=int(rng.choice([0, 1, 2, 2])), alias=int(rng.integers(0, 2)), run_len=int(rng.choice([0, 1, 3, 9])),
                 strip_rows=int(rng.choice([0, 0, 10, 16, 22, 32])), sub_batches=1 + int(rng.choice([0, 0, 0, 64, 96])) // 48,
                 orb_in_strip=int(rng.integers(0, 2)), tile_cols=int(rng.choice([0, -1, 64, 96, 160])),
-                strip_rows_max=int(rng.choice([0, 0, 36, 56, 64])))
+                strip_rows_max=int(rng.choice([0, 0, 36, 56, 64])), bucket_select=int(rng.choice([1, 1, 0])))
     return levels, vstep, rows, pyr, par, opts
 
 
@@ -67,7 +67,7 @@ def test_random_configurations_match_the_oracle(gpu_ctx, orc, chunk):
                 assert (d[b, :m].reshape(m, par["words"]) == odesc[:m]).all(), (seed, b, par, opts, levels)
     finally:
         for k, v in dict(pipeline=0, alias=1, run_len=0, strip_rows=0, sub_batches=1, orb_in_strip=0, tile_cols=0,
-                         strip_rows_max=0).items():
+                         strip_rows_max=0, bucket_select=1).items():
             gpu_ctx.set_option(k, v)
 
 
@@ -180,7 +180,7 @@ def test_random_packed_layouts_match_the_oracle(gpu_ctx, orc):
                 assert (d_[b, :len(exp)] == orc.orb_compute(pyr[b], exp)).all(), (t, b, levels, opts)
     finally:
         for k, v in dict(pipeline=0, alias=1, run_len=0, strip_rows=0, sub_batches=1, orb_in_strip=0, tile_cols=0,
-                         strip_rows_max=0).items():
+                         strip_rows_max=0, bucket_select=1).items():
             gpu_ctx.set_option(k, v)
 
 

@@ -1132,3 +1132,51 @@ def test_pipeline_graph_survives_a_workspace_that_moved(orc, sub_batches):
     if sub_batches == 1:
         assert st["captured"] == 3 and st["capture_failed"] == 0 and st["replayed_from_graphs"] == 7, st
     pipe.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("lbs,limit", [(4, 3), (2, 1), (5, 2), (3, 6), (1, 1), (6, 4)])
+def test_bucket_selection_pass_and_in_strip_selection_agree_with_the_oracle(gpu_ctx, orc, lbs, limit):
+    """fastExtract's buckets on the batch path, both ways: the default — strips exactly as without buckets, then
+    pf::k_bucket_select (one wave per level and cell row: per-bucket top-`limit`, flush order) — and option
+    bucket_select = 0 (the selection inside the strips, strips cut on bucket rows; cells of 4..32 px only).  Inputs: sparse
+    synthetic pyramids, a level of uniform noise (hundreds of survivors per cell row: the selection pass's dense path) and a
+    1280-wide packed level table (x-tiles: a unit collects from several tiles' lists)."""
+    import torch
+    from pislam_amd import synth
+    from pislam_amd.frontend import OrbFrontend
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(100 + lbs)
+    cases = []
+    levels = synth.level_table(320, 240, 4)
+    pyr = synth.make_batch(8100, 3, w0=320, h0=240, nlevels=4, levels=levels, nshapes=30)
+    lv0 = levels[1]
+    pyr[1, lv0[2]:lv0[2] + lv0[1], :lv0[0]] = rng.integers(0, 256, (lv0[1], lv0[0]), dtype=np.uint8)     # a dense level
+    cases.append((levels, 320, synth.pyramid_rows(levels), pyr, 16384))
+    wide = synth.packed_level_table(1280, 960)
+    rows_w = synth.pyramid_rows(wide)
+    cases.append((wide, 1280, rows_w, synth.make_batch(8200, 1, w0=1280, h0=960, vstep=1280, levels=wide), 16384))
+    for levels, vstep, rows, pyr, cap in cases:
+        want = [orc.pyramid4(pyr[b], levels, log_bucket=lbs, bucket_limit=limit, cap=1 << 17) for b in range(len(pyr))]
+        for select in (1, 0):
+            if not select and not 2 <= lbs <= 5:
+                continue                                  # (in-strip selection: bucket sizes 4..32 only — others take the staged pipeline)
+            gpu_ctx.set_option("bucket_select", select)
+            gpu_ctx.set_option("pipeline", 2)
+            try:
+                fe = OrbFrontend(levels, vstep=vstep, rows=rows, max_keypoints=cap, log_bucket_size=lbs, bucket_limit=limit,
+                                 ctx=gpu_ctx)
+                kp, desc, counts = fe.alloc_outputs(len(pyr), dev)
+                for _ in range(2):
+                    fe(torch.from_numpy(pyr).to(dev), kp, desc, counts)
+                torch.cuda.synchronize()
+                assert fe.last_stats()[1] > 0             # (strips of the fused pipeline ran: not the staged fallback)
+            finally:
+                gpu_ctx.set_option("bucket_select", 1)
+                gpu_ctx.set_option("pipeline", 0)
+            c, k, d = (t.cpu().numpy().view(np.uint32) for t in (counts, kp, desc))
+            for b in range(len(pyr)):
+                okp, odesc, _ = want[b]
+                n = min(len(okp), cap)
+                assert c[b] == len(okp), (select, b, int(c[b]), len(okp))
+                assert (k[b, :n] == okp[:n]).all() and (d[b, :n] == odesc[:n]).all(), (select, b)

@@ -36,6 +36,7 @@ python $root/bench.py --steps 50 --warmup 10 --workload 720p-build --batch 64 --
 python $root/bench.py --steps 50 --warmup 10 --streams 1 --no-cpu-baseline > $out/bench_vga_streams1.json 2> /dev/null
 python $root/bench.py --steps 50 --warmup 10 --shared-input --no-cpu-baseline > $out/bench_vga_shared_input.json 2> /dev/null
 python $root/bench.py --steps 50 --warmup 10 --log-bucket-size 4 --bucket-limit 3 --no-cpu-baseline > $out/bench_vga_buckets43.json 2> /dev/null
+python $root/bench.py --steps 50 --warmup 10 --log-bucket-size 4 --bucket-limit 3 --no-cpu-baseline --opt bucket_select=0 > $out/bench_vga_buckets43_in_strip_selection.json 2> /dev/null
 python $root/bench.py --gpus 2 --dist-backend gloo --steps 20 --warmup 5 --batch 128 --no-cpu-baseline > $out/bench_vga_2ranks_one_gpu_gloo.json 2> $out/bench_2ranks.err
 python $root/bench.py --gpus 8 --dist-backend gloo --steps 20 --warmup 5 --batch 32 --no-cpu-baseline > $out/bench_vga_8ranks_one_gpu_gloo.json 2> /dev/null
 for w in vga 1280x960 720p-build; do
@@ -59,9 +60,9 @@ P
 (cd $root && make -s -C tools pislam_demo > /dev/null 2>&1; for s in 3 1; do tools/pislam_demo /tmp/demo_pyramid.raw --batch 256 --steps 100 --streams $s; done) > $out/cpp_tool_demo_photo_x256.txt 2>&1
 # per-phase instruction counts of the strip kernel (cumulative ablations of the profiling build)
 (cd $root && bash tools/pmc_ablate.sh --streams 1) > $out/phase_ablation.txt 2>&1
-(cd $root && bash tools/pmc_ablate.sh --streams 1 --log-bucket-size 4 --bucket-limit 3) > $out/phase_ablation_buckets43.txt 2>&1
+(cd $root && bash tools/pmc_ablate.sh --streams 1 --log-bucket-size 4 --bucket-limit 3 --opt bucket_select=0) > $out/phase_ablation_buckets43_in_strip_selection.txt 2>&1
 rm -rf $root/gpurun_out/abl_*
 # workgroup wall-clock share of the strip kernel's phases (clock64 around the phases of every strip, profiling build):
 # cycles per strip of one eager launch (the first lines: the later ones come from bench.py's 16-launch bracket)
 python $root/bench.py --steps 3 --warmup 1 --streams 1 --graph 0 --no-cpu-baseline --ablate 8192 2>&1 | grep "cycles/strip" | head -3 > $out/phase_cycles.txt
-python $root/bench.py --steps 3 --warmup 1 --streams 1 --graph 0 --no-cpu-baseline --ablate 8192 --log-bucket-size 4 --bucket-limit 3 2>&1 | grep "cycles/strip" | head -3 > $out/phase_cycles_buckets43.txt
+python $root/bench.py --steps 3 --warmup 1 --streams 1 --graph 0 --no-cpu-baseline --ablate 8192 --log-bucket-size 4 --bucket-limit 3 --opt bucket_select=0 2>&1 | grep "cycles/strip" | head -3 > $out/phase_cycles_buckets43_in_strip_selection.txt
