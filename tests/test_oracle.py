@@ -403,3 +403,19 @@ def test_harris_against_a_register_level_numpy_restatement_of_the_neon_code(orc)
         assert len(bad) == 0, (thr, bad[:5], got[bad[:5]], want[bad[:5]])
         if thr == 1 << 15:
             assert (want != 0).sum() > 10000            # the comparison is not vacuous
+
+
+def test_parallel_synthetic_generator_equals_the_serial_one():
+    """bench.py generates its input (one batch per pipeline lane) with worker processes (pislam_amd.synth.make_many):
+    the bytes must be those of make_pyramid / make_level0 for every index, in the order asked for."""
+    from pislam_amd import synth
+    idx = [7, 3, 11, 5, 300, 301, 2, 9, 1000]
+    a = synth.make_many(idx, workers=3, w0=160, h0=120, nlevels=3)
+    b = np.stack([synth.make_pyramid(i, w0=160, h0=120, nlevels=3) for i in idx])
+    assert a.shape == b.shape and (a == b).all()
+    f = synth.make_many(idx, workers=3, kind="level0", w0=96, h0=64)
+    assert (f == np.stack([synth.make_level0(i, 96, 64) for i in idx])).all()
+    lv = synth.packed_level_table(320, 240)
+    p = synth.make_many(idx[:6], workers=2, w0=320, h0=240, vstep=320, levels=lv)
+    assert p.shape == (6, synth.pyramid_rows(lv), 320)
+    assert (p[0] == synth.make_pyramid(idx[0], w0=320, h0=240, vstep=320, levels=lv)).all()
