@@ -176,7 +176,18 @@ def test_random_packed_layouts_match_the_oracle(gpu_ctx, orc):
                     lkp, _, _ = orc.pyramid(view, [(w, h, 0)], border=border, log_bucket=lbs, bucket_limit=lim)
                     exp.append(lkp + np.uint32((c0 << 12) | r0))
                 exp = np.concatenate(exp)
-                assert c[b] == len(exp) and (k_[b, :len(exp)] == exp).all(), (t, b, levels, opts)
+                if not (c[b] == len(exp) and (k_[b, :len(exp)] == exp).all()):
+                    # say WHAT differs: a rerun of the same call tells a nondeterministic launch from a wrong result
+                    bad = np.flatnonzero(k_[b, :min(int(c[b]), len(exp))] != exp[:min(int(c[b]), len(exp))])
+                    kp2, desc2, counts2 = fe.alloc_outputs(batch, dev)
+                    fe(torch.from_numpy(pyr).to(dev), kp2, desc2, counts2)
+                    torch.cuda.synchronize()
+                    again = kp2.cpu().numpy().view(np.uint32)
+                    raise AssertionError((t, b, levels, opts, "lbs", lbs, "count", int(c[b]), len(exp), "first bad", bad[:8].tolist(),
+                                          [hex(int(v)) for v in k_[b, bad[:4]]], [hex(int(v)) for v in exp[bad[:4]]],
+                                          "same set", bool((np.sort(k_[b, :len(exp)]) == np.sort(exp)).all()),
+                                          "rerun equals first run", bool((again[b] == k_[b]).all()),
+                                          "rerun equals oracle", bool((again[b, :len(exp)] == exp).all())))
                 assert (d_[b, :len(exp)] == orc.orb_compute(pyr[b], exp)).all(), (t, b, levels, opts)
     finally:
         for k, v in dict(pipeline=0, alias=1, run_len=0, strip_rows=0, sub_batches=1, orb_in_strip=0, tile_cols=0,
