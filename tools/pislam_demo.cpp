@@ -250,9 +250,13 @@ int run_batch(int batch, int steps, bool buckets, const char *out_path, int rank
   }
   pislam_frontend_params P = {IMG_W, ROWS, NLEVELS, 16, 20, 1 << 15, buckets ? 4 : 0, buckets ? 3 : 5, 8, 4096};
   const size_t pyr_bytes = (size_t)ROWS * IMG_W;
-  uint8_t *d_pyr = nullptr;
-  HIP_OK(hipMalloc(&d_pyr, pyr_bytes * count));
-  for (int b = 0; b < count; b++) HIP_OK(hipMemcpy(d_pyr + b * pyr_bytes, img, pyr_bytes, hipMemcpyHostToDevice));
+  // every lane reads its OWN copy of the batch (the photo x count): batches in flight never share input cache lines,
+  // as a stream of different frames would not either
+  std::vector<uint8_t *> d_in((size_t)streams, nullptr);
+  for (uint8_t *&d : d_in) {
+    HIP_OK(hipMalloc(&d, pyr_bytes * count));
+    for (int b = 0; b < count; b++) HIP_OK(hipMemcpy(d + b * pyr_bytes, img, pyr_bytes, hipMemcpyHostToDevice));
+  }
   std::vector<OutSet> sets((size_t)streams);            // one output set per lane
   for (OutSet &o : sets) {
     HIP_OK(hipMalloc(&o.d_kp, sizeof(uint32_t) * (size_t)P.max_keypoints * count));
@@ -271,7 +275,7 @@ int run_batch(int batch, int steps, bool buckets, const char *out_path, int rank
     // (`streams` exchanges ago) must be done before the batch overwrites it
     void *lane_stream = pislam_pipeline_stream(pipe, (uint64_t)s);       // (lane s % streams)
     if (pislam_dist_fence_on(comm, streams, lane_stream) != PISLAM_OK) return 1;
-    if (pislam_pipeline_submit(pipe, &P, lv, d_pyr, pyr_bytes, count, o.d_kp, o.d_desc, o.d_counts, nullptr, 0, &t) != PISLAM_OK) {
+    if (pislam_pipeline_submit(pipe, &P, lv, d_in[(size_t)(s % streams)], pyr_bytes, count, o.d_kp, o.d_desc, o.d_counts, nullptr, 0, &t) != PISLAM_OK) {
       fprintf(stderr, "pislam_pipeline_submit: %s\n", pislam_pipeline_last_error(pipe));
       return 1;
     }
@@ -327,7 +331,7 @@ int run_batch(int batch, int steps, bool buckets, const char *out_path, int rank
   for (OutSet &o : sets) {
     (void)hipFree(o.d_kp); (void)hipFree(o.d_desc); (void)hipFree(o.d_counts); (void)hipFree(o.d_all);
   }
-  (void)hipFree(d_pyr);
+  for (uint8_t *d : d_in) (void)hipFree(d);
   return bad ? 14 : 0;
 }
 
