@@ -519,6 +519,12 @@ def worker_main(args):
     nd = min(distinct, B)
     nlane_in = 1 if args.shared_input else S
     gen_workers = args.gen_workers or max(1, min(16, int(effective_cores()[1]) // max(1, min(world, 8))))
+    # (the generator takes ~60 ms per VGA pyramid and host thread: on a host with few usable cores per rank the input is
+    #  built from fewer different pyramids, each lane's batch tiling them — the bench must start within its attempt timeout)
+    if not args.distinct:
+        px = w0 * h0 / (640.0 * 480.0)
+        while nd > 16 and nd * nlane_in * 0.06 * px / gen_workers > 40.0:
+            nd //= 2
     idx = [(rank * S + l) * B + i for l in range(nlane_in) for i in range(nd)]
     host = d_frames = None
     lane_in = []                                          # per input lane: device tensor (frames or pyramids)
