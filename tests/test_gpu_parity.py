@@ -1180,3 +1180,59 @@ def test_bucket_selection_pass_and_in_strip_selection_agree_with_the_oracle(gpu_
                 n = min(len(okp), cap)
                 assert c[b] == len(okp), (select, b, int(c[b]), len(okp))
                 assert (k[b, :n] == okp[:n]).all() and (d[b, :n] == odesc[:n]).all(), (select, b)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("workload", ["vga", "1280x960"])
+def test_full_batch_properties_with_readme_buckets(gpu_ctx, orc, workload):
+    """The README's recommended mode fastExtract<.., 4, 3> at the bench's batch size (256): repeated runs bit-identical,
+    results independent of the batch slot, a sample of slots equal to the oracle, at most 3 keypoints per 16 x 16 cell,
+    cells in flush order (cell row, bucket, ascending word) inside every level — through the selection pass."""
+    import torch
+    from pislam_amd import synth
+    from pislam_amd.frontend import OrbFrontend
+    dev = torch.device("cuda:0")
+    if workload == "vga":
+        levels4 = [(w, h, r0, 0) for (w, h, r0) in synth.level_table()]
+        vstep, rows, cap = 640, 2210, 4096
+        base = synth.make_batch(40, 8)
+    else:
+        levels4 = [tuple(t) for t in synth.packed_level_table(1280, 960)]
+        vstep, rows, cap = 1280, synth.pyramid_rows(levels4), 8192
+        base = synth.make_batch(40, 8, w0=1280, h0=960, vstep=1280, levels=levels4)
+    batch = 256
+    d_pyr = torch.from_numpy(base).to(dev)[torch.arange(batch, device=dev) % 8].contiguous()
+    fe = OrbFrontend(levels4 if workload != "vga" else [t[:3] for t in levels4], vstep=vstep, rows=rows, max_keypoints=cap,
+                     log_bucket_size=4, bucket_limit=3, ctx=gpu_ctx)
+    kp, desc, counts = fe.alloc_outputs(batch, dev)
+    fe(d_pyr, kp, desc, counts)
+    torch.cuda.synchronize()
+    c1, k1, d1 = (t.cpu().numpy().view(np.uint32).copy() for t in (counts, kp, desc))
+    fe(d_pyr, kp, desc, counts)
+    torch.cuda.synchronize()
+    c2, k2, d2 = (t.cpu().numpy().view(np.uint32) for t in (counts, kp, desc))
+    assert (c1 == c2).all() and (k1 == k2).all() and (d1 == d2).all()
+    assert fe.last_stats()[1] > 0
+    for b in range(8, batch):
+        n = min(int(c1[b]), cap)
+        assert c1[b] == c1[b % 8] and (k1[b, :n] == k1[b % 8, :n]).all() and (d1[b, :n] == d1[b % 8, :n]).all()
+    for b in (1, 6):
+        okp, odesc, _ = orc.pyramid4(base[b], levels4, log_bucket=4, bucket_limit=3)
+        m = min(len(okp), cap)
+        assert c1[b] == len(okp) and (k1[b, :m] == okp[:m]).all() and (d1[b, :m] == odesc[:m]).all()
+    for b in range(0, batch, 37):
+        n = min(int(c1[b]), cap)
+        x, y = (k1[b, :n] >> 12) & 0xFFF, k1[b, :n] & 0xFFF
+        pos = 0
+        for (w, h, r0, c0) in levels4:
+            m = (y >= r0) & (y < r0 + h) & (x >= c0) & (x < c0 + w)
+            idx = np.flatnonzero(m)
+            assert len(idx) == 0 or (idx[0] == pos and (np.diff(idx) == 1).all())       # levels are contiguous, in order
+            pos += len(idx)
+            cell = ((y[m] - r0 - 16) >> 4).astype(np.int64) * 4096 + ((x[m] - c0 - 16) >> 4)
+            assert (np.diff(cell) >= 0).all()
+            words = k1[b, :n][m].astype(np.int64) - ((c0 << 12) | r0)
+            same = np.diff(cell) == 0
+            assert (np.diff(words)[same] > 0).all()                                       # ascending inside a cell
+            assert len(cell) == 0 or np.bincount(np.unique(cell, return_inverse=True)[1]).max() <= 3
+        assert pos == n
