@@ -549,11 +549,15 @@ __device__ __forceinline__ void strip_body(const StripArgs A, const FusedLevel L
   // (the linear prefilter also passes groups of the halo columns: they are dropped here, where x is known)
   const uint32_t cspan = (uint32_t)((cxb + 3) & ~3) - (uint32_t)(cxa & ~3);   // dword groups that hold classified columns
   const int xrel = xbase - (cxa & ~3);
-  auto pretest_batch = [&](const bool lane_valid, uint32_t key) {
+  // (a group travels through the prefilter's queue as the LDS ADDRESS of the dword left of it — the pointer the
+  //  prefilter walks with anyway, so that its loop carries no key of its own; the tile offset comes back by one subtract)
+  const uint32_t grp_base = (uint32_t)(uintptr_t)(tile3 - 4);
+  auto pretest_batch = [&](const bool lane_valid, const uint32_t grp) {
+    const uint32_t key = grp - grp_base;
     const int x0r = (int)key - (int)__umulhi(key, tp_recip) * tpitch + xrel;   // x0 - (cxa & ~3)
     const bool valid = lane_valid && (uint32_t)x0r < cspan;
     const int x0 = x0r + (cxa & ~3);
-    const lds_u8 *pb = tile3 + key - 4;                      // (left neighbour first: DS offsets are unsigned)
+    const lds_u8 *pb = (const lds_u8 *)(uintptr_t)grp;       // (left neighbour first: DS offsets are unsigned)
     const uint32_t wl = *(const lds_u32 *)pb;
     const uint32_t wc = *(const lds_u32 *)(pb + 4);
     const uint32_t wr = *(const lds_u32 *)(pb + 8);
@@ -719,7 +723,7 @@ __device__ __forceinline__ void strip_body(const StripArgs A, const FusedLevel L
     // partial.  Nothing is set up per row, the three pointers and the key advance by constants.
     const int lin_lo = r_lo * tpitch, lin_n = max(r_hi - r_lo, 0) * tpitch;
     const int nfull = lin_n >> 8, rem = lin_n & 255;
-    auto prefilter_step = [&](const lds_u8 *pm, const lds_u8 *pu, const lds_u8 *pd, bool lane_ok, uint32_t key) {
+    auto prefilter_step = [&](const lds_u8 *pm, const lds_u8 *pu, const lds_u8 *pd, bool lane_ok) {
       // aligned dword reads; lanes past the tile's columns read harmless bytes of the next tile row
       const uint32_t wl = *(const lds_u32 *)pm;
       const uint32_t wc = *(const lds_u32 *)(pm + 4);
@@ -738,7 +742,7 @@ __device__ __forceinline__ void strip_body(const StripArgs A, const FusedLevel L
       const bool g = lane_ok && (lo > (uint32_t)thr);
       const uint64_t m = __ballot(g);
       if (m == 0) return;
-      if (g) qg[ng + ballot_rank(m)] = key;                               // pack_xy(x0, r)
+      if (g) qg[ng + ballot_rank(m)] = (uint32_t)(uintptr_t)pm;          // the group's address (see pretest_batch)
       ng += __popcll(m);
       if (ng >= 64) {
         ng -= 64;
@@ -751,18 +755,16 @@ __device__ __forceinline__ void strip_body(const StripArgs A, const FusedLevel L
     {
       const lds_u8 *pm = tile3 + lin_lo + 256 * wave + 4 * lane - 4;
       const lds_u8 *pu = pm + 4 - 3 * tpitch, *pd = pm + 4 + 3 * tpitch;
-      uint32_t key = (uint32_t)(lin_lo + 256 * wave + 4 * lane);
       for (int st = wave; st < nfull; st += WAVES) {
-        prefilter_step(pm, pu, pd, true, key);
+        prefilter_step(pm, pu, pd, true);
         pm += 256 * WAVES;
         pu += 256 * WAVES;
         pd += 256 * WAVES;
-        key += 256 * WAVES;
       }
       // (after the loop the pointers stand at the first step >= nfull of this wave: the partial step for one wave)
-      if (rem && (nfull & (WAVES - 1)) == wave) prefilter_step(pm, pu, pd, 4 * lane < rem, key);
+      if (rem && (nfull & (WAVES - 1)) == wave) prefilter_step(pm, pu, pd, 4 * lane < rem);
     }
-    if (ng > 0 && !(ablate & 16)) pretest_batch(lane < ng, lane < ng ? qg[lane] : (uint32_t)lin_lo);
+    if (ng > 0 && !(ablate & 16)) pretest_batch(lane < ng, lane < ng ? qg[lane] : grp_base + (uint32_t)lin_lo);
     ng = 0;
     // left-over candidates (< 64): one partial batch per wave — cheaper than a barrier to merge them
     if (nf > 0 && !(ablate & 2)) fast_batch(lane < nf, qf[min(lane, nf - 1)]);
