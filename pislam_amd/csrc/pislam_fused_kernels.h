@@ -583,9 +583,15 @@ __device__ __forceinline__ void strip_body(const StripArgs A, const FusedLevel L
     }
     if (__ballot((fe | fo) != 0) == 0) return;
     // (bit 15 as the sign of the low half: one 16-bit compare instead of mask + compare)
-    const bool e0 = (int16_t)(uint16_t)fe < 0, o0 = (int16_t)(uint16_t)fo < 0;
-    const uint64_t m0 = __ballot(e0), m1 = __ballot(o0);
-    const uint64_t m2 = __ballot((int32_t)fe < 0), m3 = __ballot((int32_t)fo < 0);
+    // The four pass flags as wave masks, ONE compare each (bit 15 = the sign of the low half, bit 31 the sign of the word),
+    // and the lane predicates taken back from the masks (inverse ballot: no instruction): written as C++ comparisons the
+    // compiler evaluates each low-half flag twice, in two forms — v_and + v_cmp for the branch, v_bfe + v_cmp for the ballot.
+    uint64_t m0, m1, m2, m3;
+    asm volatile("v_cmp_gt_i16_e64 %0, 0, %4\n\tv_cmp_gt_i16_e64 %1, 0, %5\n\tv_cmp_gt_i32_e64 %2, 0, %4\n\tv_cmp_gt_i32_e64 %3, 0, %5\n\ts_nop 1"
+        : "=&s"(m0), "=&s"(m1), "=&s"(m2), "=&s"(m3)
+        : "v"(fe), "v"(fo));
+    const bool e0 = __builtin_amdgcn_inverse_ballot_w64(m0), o0 = __builtin_amdgcn_inverse_ballot_w64(m1);
+    const bool e2 = __builtin_amdgcn_inverse_ballot_w64(m2), o2 = __builtin_amdgcn_inverse_ballot_w64(m3);
     // two half-pushes (<= 128 each) with a pop in between keep the queue below 64 + 128 entries
     {
       lds_u32 *q = qf + nf;
@@ -600,9 +606,9 @@ __device__ __forceinline__ void strip_body(const StripArgs A, const FusedLevel L
     }
     {
       lds_u32 *q = qf + nf;
-      if ((int32_t)fe < 0) q[ballot_rank(m2)] = key + 2;
+      if (e2) q[ballot_rank(m2)] = key + 2;
       q += __popcll(m2);
-      if ((int32_t)fo < 0) q[ballot_rank(m3)] = key + 3;
+      if (o2) q[ballot_rank(m3)] = key + 3;
       nf += __popcll(m2) + __popcll(m3);
     }
     while (nf >= 64) {
