@@ -62,19 +62,24 @@ __device__ __forceinline__ bool fast9(const P *c, int pitch, int thr) {
 }
 
 // The same decision with the multimedia byte instructions: the 16 ring pixels are packed 4 per dword
-// and compared 4 at a time with v_lerp_u8 — lerp(a, ~b, 1) = (a + 255 - b + 1) >> 1 per byte, whose
-// bit 7 is [a >= b].  With hi = min(c + t, 255) and lo = max(c - t, 0) (the reference's saturating
-// forms, Fast.h:63-64):  NOT bright = [hi >= p],  NOT dark = [p >= lo].  The four flag bits of a dword
-// are gathered with v_dot4_u32_u8 (weights = bit positions, flags are 0x80 -> the sum is 128 x the
+// and compared 4 at a time with v_lerp_u8 — lerp(a, b, r) = (a + b + r) >> 1 per byte, whose bit 7 is
+// [a + b + r >= 256]:
+//   bright  p > c + t   <=>  p + max(255 - t - c, 0) >= 256        (r = 0; with c + t >= 255 the addend is 0 and the
+//                                                                    sum never reaches 256: no bright pixel exists)
+//   NOT dark  p >= lo, lo = max(c - t, 0) (the reference's saturating form, Fast.h:63-64)
+//                       <=>  p + (255 - lo) + 1 >= 256              (r = 1), 255 - lo = min(255 + t - c, 255).
+// Three instructions per threshold dword (subtract, clamp, replicate), no special case.  The four flag bits of a
+// dword are gathered with v_dot4_u32_u8 (weights = bit positions, flags are 0x80 -> the sum is 128 x the
 // bits).  ~40 VALU for the two 16-bit masks instead of 64 (one subtract + one v_alignbit per pixel and
 // side in fast9); identical result.
 template <class P>
 __device__ __forceinline__ bool fast9_mm(const P *c, int pitch, int thr) {
   const int v = c[0];
-  // bright: p > c+t  <=>  p >= hi1 with hi1 = c+t+1 (impossible when hi1 > 255);  dark: p < lo  <=>  NOT p >= lo
-  const int hi1 = v + thr + 1;
-  const uint32_t nhi4 = ~((uint32_t)min(hi1, 255) * 0x01010101u);
-  const uint32_t nlo4 = ~((uint32_t)max(v - thr, 0) * 0x01010101u);
+  // (thr is wave-uniform in every caller; the opaque copies keep 255 -/+ thr in scalar registers, one subtract per lane)
+  int k_hi = 255 - thr, k_lo = 255 + thr;
+  asm("" : "+s"(k_hi), "+s"(k_lo));
+  const uint32_t bhi4 = (uint32_t)max(k_hi - v, 0) * 0x01010101u;
+  const uint32_t nlo4 = (uint32_t)min(k_lo - v, 255) * 0x01010101u;
   uint32_t px[16];
 #define PISLAM_F(k, dy, dx) px[k] = c[(dy) * pitch + (dx)];
   PISLAM_RING16(PISLAM_F)
@@ -86,7 +91,7 @@ __device__ __forceinline__ bool fast9_mm(const P *c, int pitch, int thr) {
     const uint32_t t01 = __builtin_amdgcn_perm(px[4 * j + 1], px[4 * j], 0x0c0c0400u);
     const uint32_t t23 = __builtin_amdgcn_perm(px[4 * j + 3], px[4 * j + 2], 0x0c0c0400u);
     const uint32_t w = __builtin_amdgcn_perm(t23, t01, 0x05040100u);
-    const uint32_t gb = __builtin_amdgcn_lerp(w, nhi4, 0x01010101u);      // bit 7 of a byte: p >= hi1 (bright)
+    const uint32_t gb = __builtin_amdgcn_lerp(w, bhi4, 0u);               // bit 7 of a byte: p > c + t (bright)
     const uint32_t nd = __builtin_amdgcn_lerp(w, nlo4, 0x01010101u);      // bit 7 of a byte: p >= lo (not dark)
     const uint32_t wt = (j & 1) ? 0x80402010u : 0x08040201u;
     tb[j >> 1] = __builtin_amdgcn_udot4(gb & 0x80808080u, wt, tb[j >> 1], false);
@@ -97,8 +102,10 @@ __device__ __forceinline__ bool fast9_mm(const P *c, int pitch, int thr) {
   // byte swap (v_perm_b32).  Same decision as has_arc9(dm) || has_arc9(bm) — whose `||` hipcc turned into a branch
   // around the second side that is taken by nearly every batch — in 12 instead of 24 VALU.
   typedef unsigned short us2_t __attribute__((ext_vector_type(2)));
-  uint32_t pm = (td[0] >> 7) | (td[1] << 1) | (tb[0] << 9) | (tb[1] << 17);
-  pm = hi1 > 255 ? (pm & 0xffffu) : pm;
+  // (td / tb = 128 x the mask bytes: low and high byte joined by one shift-add each, then the two sides by a shift and a
+  //  shift-or — four instructions; the four-term OR of shifted sums took six)
+  const uint32_t dsum = td[0] + (td[1] << 8), bsum = tb[0] + (tb[1] << 8);
+  uint32_t pm = (dsum >> 7) | (bsum << 9);
   auto rotr16x2 = [](uint32_t x, int k) -> uint32_t {
     const us2_t v = __builtin_bit_cast(us2_t, x);
     const us2_t a = v >> (us2_t)((unsigned short)k), b = v << (us2_t)((unsigned short)(16 - k));

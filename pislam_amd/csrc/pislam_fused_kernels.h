@@ -8,8 +8,9 @@
 //
 //   phase A0 SAD prefilter on every 4-pixel group (necessary condition of the compass test): the classified
 //            rows are scanned as one linear run of tile bytes, 256 per wave step
-//   phase A1 exact "two adjacent compass points" test on the surviving groups, 4 pixels per lane on
-//            packed u16; survivors are compacted per wave (ballot + mbcnt) into a wave-private LDS queue
+//   phase A1 "two adjacent compass points" test on the surviving groups, 4 pixels per lane in the byte
+//            domain (on halved differences: a necessary condition, one grey level wider than the exact test
+//            on one side); survivors are compacted per wave (ballot + mbcnt) into a wave-private LDS queue
 //   phase B  whenever a queue holds >= 64 entries the wave pops 64 and runs the full FAST-9 arc test
 //            on densely packed lanes (result-identical to Fast.h:63-147); corners go to ONE queue per
 //            workgroup.  (Candidates travel through A0 / A1 / B as tile byte offsets.)
@@ -129,26 +130,9 @@ constexpr int PF_MAX = 4;              // 16-byte vectors a thread can hold for 
 __device__ __forceinline__ uint32_t pack_xy(int x, int r) { return (uint32_t)x | ((uint32_t)r << 16); }
 
 // Necessary condition for a 9-arc: an arc of 9 ring positions contains two ADJACENT compass
-// points (ring indices 1,5,9,13), so both must be dark (or both bright):
-//   exists adjacent pair both > hi  <=>  min(max(p1,p9), max(p5,p13)) > hi
-//   exists adjacent pair both < lo  <=>  max(min(p1,p9), min(p5,p13)) < lo
-// The test for 4 horizontally adjacent pixels held in one dword, evaluated on packed
-// unsigned 16-bit pairs (v_pk_min/max/add/sub_u16): `ce/co` are the even/odd centre pixels
-// zero-extended to 16 bit, etc.  Returns a word whose bit 15 / bit 31 is set when the pixel in
-// the low / high half passes.
-typedef unsigned short us2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ us2 as_us2(uint32_t v) { return __builtin_bit_cast(us2, v); }
-__device__ __forceinline__ uint32_t as_u32(us2 v) { return __builtin_bit_cast(uint32_t, v); }
-__device__ __forceinline__ void pretest_pk(uint32_t c, uint32_t u, uint32_t d, uint32_t l, uint32_t r,
-                                           uint32_t t2, uint32_t &bright, uint32_t &dark) {
-  const us2 C = as_us2(c), U = as_us2(u), D = as_us2(d), Lf = as_us2(l), Rt = as_us2(r), T = as_us2(t2);
-  const us2 a = __builtin_elementwise_min(__builtin_elementwise_max(U, D), __builtin_elementwise_max(Lf, Rt));
-  const us2 b = __builtin_elementwise_max(__builtin_elementwise_min(U, D), __builtin_elementwise_min(Lf, Rt));
-  const us2 hi = C + T, lo = C - T;            // lo may wrap negative: compared as signed 16 bit below
-  // bright: a > hi <=> (hi - a) < 0 ;  dark: b < lo <=> (b - lo) < 0   (all magnitudes < 2^10)
-  bright = as_u32(hi - a);
-  dark = as_u32(b - lo);
-}
+// points (ring indices 1,5,9,13), so both must be dark (or both bright): one of the vertical pair (p1, p9) AND one of
+// the horizontal pair (p5, p13) on the same side of the centre.  strip_body's pretest_batch evaluates it for the 4
+// pixels of a dword at once, in the byte domain.
 
 // Rare path of the plain layout (shared corner queue full): score the flagged lanes right away.  Kept
 // out of line so that the hot loops of the kernel do not carry a second inlined copy of the Harris
@@ -542,7 +526,9 @@ __device__ __forceinline__ void strip_body(const StripArgs A, const FusedLevel L
 
   const int r_lo = carry ? 3 : (ys - 1 < B) ? 1 : 0;              // rows above B are never classified
   const int r_hi = min(ye + 2, Lh - B) - (ys - 1);               // exclusive
-  const uint32_t t2 = (uint32_t)thr * 0x00010001u;
+  // pretest thresholds on h = 128 + floor((N - C) / 2), complemented and replicated (see pretest_batch)
+  const uint32_t nkb4 = ~((uint32_t)min(128 + ((thr + 1) >> 1), 255) * 0x01010101u);   // bright: h >= 128 + floor((t + 1) / 2)
+  const uint32_t nkd4 = ~((uint32_t)(129 - ((thr + 2) >> 1)) * 0x01010101u);            // not dark: h >= 129 - ceil((t + 1) / 2)
   const bool aligned4 = ((B | Lxend) & 3) == 0;    // the classified range's edges fall on dword boundaries
 
   // exact compass pretest of the 4 pixels of one group (x0 % 4 == 0), survivors -> qf
@@ -563,41 +549,52 @@ __device__ __forceinline__ void strip_body(const StripArgs A, const FusedLevel L
     const uint32_t wr = *(const lds_u32 *)(pb + 8);
     const uint32_t wu = *(const lds_u32 *)(pb + 4 - 3 * tpitch);
     const uint32_t wd = *(const lds_u32 *)(pb + 4 + 3 * tpitch);
-    // even pixels (x0, x0+2) and odd pixels (x0+1, x0+3), zero-extended to 16 bit by v_perm_b32
-    uint32_t be, de, bo, dd;
-    pretest_pk(__builtin_amdgcn_perm(0, wc, 0x0c020c00u), __builtin_amdgcn_perm(0, wu, 0x0c020c00u),
-               __builtin_amdgcn_perm(0, wd, 0x0c020c00u),
-               __builtin_amdgcn_perm(wc, wl, 0x0c030c01u),      // x-3: l.b1, l.b3
-               __builtin_amdgcn_perm(wr, wc, 0x0c050c03u), t2, be, de); // x+3: c.b3, r.b1
-    pretest_pk(__builtin_amdgcn_perm(0, wc, 0x0c030c01u), __builtin_amdgcn_perm(0, wu, 0x0c030c01u),
-               __builtin_amdgcn_perm(0, wd, 0x0c030c01u),
-               __builtin_amdgcn_perm(wc, wl, 0x0c040c02u),      // x-3: l.b2, c.b0
-               __builtin_amdgcn_perm(wr, wc, 0x0c060c04u), t2, bo, dd); // x+3: r.b0, r.b2
-    const uint32_t re = be | de, ro = bo | dd;
-    uint32_t fe = valid ? re & 0x80008000u : 0u, fo = valid ? ro & 0x80008000u : 0u;
-    if (!aligned4) {                     // generic border: mask the pixels outside [cxa, cxb)
-      if (x0 + 0 < cxa || x0 + 0 >= cxb) fe &= ~0x00008000u;
-      if (x0 + 1 < cxa || x0 + 1 >= cxb) fo &= ~0x00008000u;
-      if (x0 + 2 < cxa || x0 + 2 >= cxb) fe &= ~0x80000000u;
-      if (x0 + 3 < cxa || x0 + 3 >= cxb) fo &= ~0x80000000u;
-    }
-    if (__ballot((fe | fo) != 0) == 0) return;
-    // (bit 15 as the sign of the low half: one 16-bit compare instead of mask + compare)
-    // The four pass flags as wave masks, ONE compare each (bit 15 = the sign of the low half, bit 31 the sign of the word),
-    // and the lane predicates taken back from the masks (inverse ballot: no instruction): written as C++ comparisons the
-    // compiler evaluates each low-half flag twice, in two forms — v_and + v_cmp for the branch, v_bfe + v_cmp for the ballot.
+    // The compass test in the BYTE domain, 4 pixels per instruction.  h = v_lerp_u8(N, ~C, 1) = 128 + floor((N - C) / 2)
+    // per byte for the neighbour dwords N = up / down / 3 left / 3 right of the group C.  A compass point brighter than
+    // C + t has floor((N - C) / 2) >= floor((t + 1) / 2), a darker one <= -ceil((t + 1) / 2): bit 7 of
+    // v_lerp_u8(h, ~K, 1) is [h >= K], so eight more lerps against two replicated constants give the four "bright" and
+    // the four "not dark" flags, five boolean instructions the pass flag (one vertical AND one horizontal point on the
+    // same side).  Halving the difference makes ONE of the two sides one grey level more permissive than the exact
+    // test (the bright side for even t, the dark side for odd t): still a necessary condition of the segment test —
+    // FAST decides — and 20 instructions where the 16-bit form (two pixels per instruction: ten v_perm_b32 to unpack,
+    // min / max / compare on halves) took 32.
+    const uint32_t nC = ~wc;
+    const uint32_t hU = __builtin_amdgcn_lerp(wu, nC, 0x01010101u), hD = __builtin_amdgcn_lerp(wd, nC, 0x01010101u);
+    const uint32_t hL = __builtin_amdgcn_lerp(__builtin_amdgcn_alignbyte(wc, wl, 1), nC, 0x01010101u);   // x-3: l.b1 .. c.b0
+    const uint32_t hR = __builtin_amdgcn_lerp(__builtin_amdgcn_alignbyte(wr, wc, 3), nC, 0x01010101u);   // x+3: c.b3 .. r.b2
+    const uint32_t bU = __builtin_amdgcn_lerp(hU, nkb4, 0x01010101u), bD = __builtin_amdgcn_lerp(hD, nkb4, 0x01010101u);
+    const uint32_t bL = __builtin_amdgcn_lerp(hL, nkb4, 0x01010101u), bR = __builtin_amdgcn_lerp(hR, nkb4, 0x01010101u);
+    const uint32_t dU = __builtin_amdgcn_lerp(hU, nkd4, 0x01010101u), dD = __builtin_amdgcn_lerp(hD, nkd4, 0x01010101u);
+    const uint32_t dL = __builtin_amdgcn_lerp(hL, nkd4, 0x01010101u), dR = __builtin_amdgcn_lerp(hR, nkd4, 0x01010101u);
+    const uint32_t bright = (bU | bD) & (bL | bR);
+    const uint32_t notdark = (dU & dD) | (dL & dR);        // bit 7: no dark vertical point OR no dark horizontal point
+    const uint32_t pass = bright | ~notdark;               // bit 7 of byte k: pixel x0 + k goes on to the segment test
+    // The four pass flags as wave masks, ONE compare each (SDWA: the sign of byte k; groups outside the classified
+    // columns cleared first), the early exit decided on the masks, and the lane predicates taken back from them
+    // (inverse ballot: no instruction).  (Clearing the masks with scalar ANDs instead of the one v_cndmask was measured:
+    // the same VALU count to within 0.1 %, 0.6 M more SALU instructions per launch, not faster.)
     uint64_t m0, m1, m2, m3;
-    asm volatile("v_cmp_gt_i16_e64 %0, 0, %4\n\tv_cmp_gt_i16_e64 %1, 0, %5\n\tv_cmp_gt_i32_e64 %2, 0, %4\n\tv_cmp_gt_i32_e64 %3, 0, %5\n\ts_nop 1"
+    asm volatile("v_cmp_gt_i32_sdwa %0, 0, sext(%4) src0_sel:DWORD src1_sel:BYTE_0\n\t"
+                 "v_cmp_gt_i32_sdwa %1, 0, sext(%4) src0_sel:DWORD src1_sel:BYTE_1\n\t"
+                 "v_cmp_gt_i32_sdwa %2, 0, sext(%4) src0_sel:DWORD src1_sel:BYTE_2\n\t"
+                 "v_cmp_gt_i32_e64 %3, 0, %4\n\ts_nop 1"
         : "=&s"(m0), "=&s"(m1), "=&s"(m2), "=&s"(m3)
-        : "v"(fe), "v"(fo));
-    const bool e0 = __builtin_amdgcn_inverse_ballot_w64(m0), o0 = __builtin_amdgcn_inverse_ballot_w64(m1);
-    const bool e2 = __builtin_amdgcn_inverse_ballot_w64(m2), o2 = __builtin_amdgcn_inverse_ballot_w64(m3);
+        : "v"(valid ? pass : 0u));
+    if (!aligned4) {                     // generic border: drop the pixels outside [cxa, cxb)
+      m0 &= __ballot(x0 + 0 >= cxa && x0 + 0 < cxb);
+      m1 &= __ballot(x0 + 1 >= cxa && x0 + 1 < cxb);
+      m2 &= __ballot(x0 + 2 >= cxa && x0 + 2 < cxb);
+      m3 &= __ballot(x0 + 3 >= cxa && x0 + 3 < cxb);
+    }
+    if ((m0 | m1 | m2 | m3) == 0) return;
+    const bool p0 = __builtin_amdgcn_inverse_ballot_w64(m0), p1 = __builtin_amdgcn_inverse_ballot_w64(m1);
+    const bool p2 = __builtin_amdgcn_inverse_ballot_w64(m2), p3 = __builtin_amdgcn_inverse_ballot_w64(m3);
     // two half-pushes (<= 128 each) with a pop in between keep the queue below 64 + 128 entries
     {
       lds_u32 *q = qf + nf;
-      if (e0) q[ballot_rank(m0)] = key;
+      if (p0) q[ballot_rank(m0)] = key;
       q += __popcll(m0);
-      if (o0) q[ballot_rank(m1)] = key + 1;
+      if (p1) q[ballot_rank(m1)] = key + 1;
       nf += __popcll(m0) + __popcll(m1);
     }
     while (nf >= 64) {
@@ -606,9 +603,9 @@ __device__ __forceinline__ void strip_body(const StripArgs A, const FusedLevel L
     }
     {
       lds_u32 *q = qf + nf;
-      if (e2) q[ballot_rank(m2)] = key + 2;
+      if (p2) q[ballot_rank(m2)] = key + 2;
       q += __popcll(m2);
-      if (o2) q[ballot_rank(m3)] = key + 3;
+      if (p3) q[ballot_rank(m3)] = key + 3;
       nf += __popcll(m2) + __popcll(m3);
     }
     while (nf >= 64) {
@@ -757,7 +754,11 @@ __device__ __forceinline__ void strip_body(const StripArgs A, const FusedLevel L
     };
     // (Unrolling the full steps so that their strides become immediate DS offsets instead of three
     //  pointer increments was tried: every copy of the step inlines the pretest / FAST batch code behind it,
-    //  4859 -> 6481 instructions for 3 VALU per step.)
+    //  4859 -> 6481 instructions for 3 VALU per step.  Round 4, measured and removed: TWO groups per lane and step
+    //  (8-byte centre / up / down reads, 21 VALU + 5 LDS reads per 512 pixels instead of 24 + 10: -1.7 M VALU per
+    //  launch, the kernel 1.5 % SLOWER — half as many steps to deal round-robin to four waves); reading the next
+    //  step's five dwords before evaluating the current one (the register rotation and re-formed addresses cost
+    //  +5.4 M VALU per launch, the kernel +1 us: the latency it hides is worth less than the moves).)
     {
       const lds_u8 *pm = tile3 + lin_lo + 256 * wave + 4 * lane - 4;
       const lds_u8 *pu = pm + 4 - 3 * tpitch, *pd = pm + 4 + 3 * tpitch;

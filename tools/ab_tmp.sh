@@ -1,12 +1,14 @@
 #!/bin/bash
-(timeout 1200 python -m pytest tests -m gpu -x -q 2>&1 | grep "passed\|failed")
+# development A/B of the variant libraries under variants/ (see tools/ab_build.sh); the working tree's library runs the GPU suite
+true
 run() { echo "$1: $(timeout 300 bash tools/bench_quick.sh ${@:2})"; }
 for rep in 1 2 3; do
-for n in prev new; do
-  if [ $n = new ]; then unset PISLAM_HIP_LIB; else export PISLAM_HIP_LIB=variants/libpislam_hip_$n.so; fi
-  run "$n s1" --streams 1
+for n in "$@"; do
+  export PISLAM_HIP_LIB=$PWD/variants/libpislam_hip_$n.so
   run "$n s3"
 done
 done
-unset PISLAM_HIP_LIB
-bash tools/pmc_quick.sh 2>&1 | grep "k_fused_strips "
+for n in "$@"; do
+  export PISLAM_HIP_LIB=$PWD/variants/libpislam_hip_$n.so
+  echo "$n $(bash tools/pmc_quick.sh 2>&1 | grep 'k_fused_strips ')"
+done
