@@ -227,10 +227,10 @@ __device__ __forceinline__ OrbWin orb_fetch(const OrbLane &G, uint32_t p0, uint3
   OrbWin f;
   const int org0 = (decode_y(p0) - 15) * vstep + (decode_x(p0) - 15);
   const int org1 = (decode_y(p1) - 15) * vstep + (decode_x(p1) - 15);
+  const int d01 = org1 - org0;                      // (wave-uniform: the slot's keypoint is picked by one v_and, not by a select)
 #pragma unroll
   for (int j = 0; j < 3; j++) {
-    const int org = G.sl_h[j] ? org1 : org0;
-    const uint32_t a = min((uint32_t)(org + G.sl_rel[j]) & ~15u, img_bytes32 - 16u);
+    const uint32_t a = min((uint32_t)(org0 + G.sl_rel[j] + (d01 & -G.sl_h[j])) & ~15u, img_bytes32 - 16u);
     f.w[j] = *(const uint4 *)(im + a);
   }
   return f;
@@ -304,6 +304,13 @@ __device__ __forceinline__ void orb_describe(const OrbLane &G, const OrbWin &cur
   // write; the s_nop covers the "VALU wrote the SGPR a v_writelane reads" distance for the last of them
   // (tools/probes/writelane.hip: without it the lane can receive the SGPR's previous value; hipcc pads no
   // hazards inside inline asm).
+  // (Round 4, measured and dropped: eight tests per LANE — the sign of a - b shifted into a byte by v_alignbit_b32, four
+  //  lanes' bytes joined by DPP + v_perm_b32, the table transposed so that the loads stay 128 contiguous bytes per
+  //  half — needs 20 VALU where the ballots and v_writelane_b32 below need 24 and no hazard pad: 24.05 -> 23.3 M VALU
+  //  per launch and the kernel ALONE 1.5 us faster, but its waves live 13 % longer (SQ_WAVE_CYCLES 206 -> 232 M,
+  //  SQ_WAIT_INST_ANY 67 -> 88 M) and the pipelined step, where they share the CUs with the next batch's strip
+  //  kernel, is 1.3 % slower (0.2305 against 0.2275 ms).  Byte stores from all lanes or two 16-byte table loads per
+  //  lane instead: the same.)
   uint32_t myword = 0;
   {
     const uint32_t l0 = (uint32_t)m[0], l1 = (uint32_t)m[1], l2 = (uint32_t)m[2], l3 = (uint32_t)m[3], l4 = (uint32_t)m[4],

@@ -10,5 +10,5 @@ done
 done
 for n in "$@"; do
   export PISLAM_HIP_LIB=$PWD/variants/libpislam_hip_$n.so
-  echo "$n $(bash tools/pmc_quick.sh 2>&1 | grep 'k_fused_strips ')"
+  echo "$n $(bash tools/pmc_quick.sh 2>&1 | grep 'k_fused_strips \|k_gather_orb ')"
 done
