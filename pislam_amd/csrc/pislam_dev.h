@@ -217,24 +217,41 @@ __device__ __forceinline__ uint8_t harris_score_mm(const lds_byte *row0, int pit
   // dx * dy stays within [-32512, 32512].  The three sums are therefore plain sums of byte products:
   // v_dot4_i32_i8 on the two's-complement bytes (offset-binary ^ 0x80), 4 positions per instruction.
   int32_t sxx = 0, syy = 0, sxy = 0;
+  // Columns 0..3 of a row fill a dword; columns 4, 5 only half of one.  Rows are therefore taken in PAIRS: the
+  // column-4/5 gradients of rows m and m + 1 share one dword (three v_perm_b32 pick the byte pairs of the two rows'
+  // vertical differences that the dy chain combines, one more joins the two dx results), so that their halving adds,
+  // sign conversion and dot products are paid once per pair — 11 instead of 18 instructions per row pair.
 #pragma unroll
-  for (int m = 0; m < 6; m++) {
-    // dx: (((e_m + e_m+2) >> 1) + e_m+1) >> 1, Harris.h:139-162
-    const uint32_t DX0 = __builtin_amdgcn_lerp(__builtin_amdgcn_lerp(E0[m], E0[m + 2], 0u), E0[m + 1], 0u);
-    const uint32_t DX1 = __builtin_amdgcn_lerp(__builtin_amdgcn_lerp(E1[m], E1[m + 2], 0u), E1[m + 1], 0u);
-    // vertical differences (P[m+2] - P[m]) >> 1 of columns 0..3 and 4..7, then
-    // dy: (d_c+1 + ((d_c + d_c+2) >> 1)) >> 1, Harris.h:123-135
-    const uint32_t V0 = __builtin_amdgcn_lerp(w0[m + 2], n0[m], ONE4);
-    const uint32_t V1 = __builtin_amdgcn_lerp(w1[m + 2], n1[m], ONE4);
-    const uint32_t DY0 = __builtin_amdgcn_lerp(__builtin_amdgcn_lerp(V0, __builtin_amdgcn_alignbyte(V1, V0, 2), 0u),
-                                               __builtin_amdgcn_alignbyte(V1, V0, 1), 0u);
-    const uint32_t DY1 = __builtin_amdgcn_lerp(__builtin_amdgcn_lerp(V1, V1 >> 16, 0u), V1 >> 8, 0u);
-    // signed bytes of columns 0..3 and of columns 4,5 (the unused upper bytes zeroed)
-    const int x0 = (int)(DX0 ^ 0x80808080u), x1 = (int)((DX1 ^ 0x80808080u) & 0x0000ffffu);
-    const int y0 = (int)(DY0 ^ 0x80808080u), y1 = (int)((DY1 ^ 0x80808080u) & 0x0000ffffu);
-    sxx = __builtin_amdgcn_sdot4(x1, x1, __builtin_amdgcn_sdot4(x0, x0, sxx, false), false);
-    syy = __builtin_amdgcn_sdot4(y1, y1, __builtin_amdgcn_sdot4(y0, y0, syy, false), false);
-    sxy = __builtin_amdgcn_sdot4(x1, y1, __builtin_amdgcn_sdot4(x0, y0, sxy, false), false);
+  for (int m = 0; m < 6; m += 2) {
+    uint32_t DX1[2], V1[2];
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+      const int q = m + h;
+      // dx: (((e_q + e_q+2) >> 1) + e_q+1) >> 1, Harris.h:139-162
+      const uint32_t DX0 = __builtin_amdgcn_lerp(__builtin_amdgcn_lerp(E0[q], E0[q + 2], 0u), E0[q + 1], 0u);
+      DX1[h] = __builtin_amdgcn_lerp(__builtin_amdgcn_lerp(E1[q], E1[q + 2], 0u), E1[q + 1], 0u);
+      // vertical differences (P[q+2] - P[q]) >> 1 of columns 0..3 and 4..7, then
+      // dy: (d_c+1 + ((d_c + d_c+2) >> 1)) >> 1, Harris.h:123-135
+      const uint32_t V0 = __builtin_amdgcn_lerp(w0[q + 2], n0[q], ONE4);
+      V1[h] = __builtin_amdgcn_lerp(w1[q + 2], n1[q], ONE4);
+      const uint32_t DY0 = __builtin_amdgcn_lerp(__builtin_amdgcn_lerp(V0, __builtin_amdgcn_alignbyte(V1[h], V0, 2), 0u),
+                                                 __builtin_amdgcn_alignbyte(V1[h], V0, 1), 0u);
+      // signed bytes of columns 0..3
+      const int x0 = (int)(DX0 ^ 0x80808080u), y0 = (int)(DY0 ^ 0x80808080u);
+      sxx = __builtin_amdgcn_sdot4(x0, x0, sxx, false);
+      syy = __builtin_amdgcn_sdot4(y0, y0, syy, false);
+      sxy = __builtin_amdgcn_sdot4(x0, y0, sxy, false);
+    }
+    // columns 4, 5 of both rows: bytes {row m: c4, c5, row m+1: c4, c5}
+    const uint32_t DX1p = __builtin_amdgcn_perm(DX1[1], DX1[0], 0x05040100u);
+    const uint32_t va = __builtin_amdgcn_perm(V1[1], V1[0], 0x05040100u);     // d_c   (columns 4, 5)
+    const uint32_t vb = __builtin_amdgcn_perm(V1[1], V1[0], 0x07060302u);     // d_c+2 (columns 6, 7)
+    const uint32_t vc = __builtin_amdgcn_perm(V1[1], V1[0], 0x06050201u);     // d_c+1 (columns 5, 6)
+    const uint32_t DY1p = __builtin_amdgcn_lerp(__builtin_amdgcn_lerp(va, vb, 0u), vc, 0u);
+    const int x1 = (int)(DX1p ^ 0x80808080u), y1 = (int)(DY1p ^ 0x80808080u);
+    sxx = __builtin_amdgcn_sdot4(x1, x1, sxx, false);
+    syy = __builtin_amdgcn_sdot4(y1, y1, syy, false);
+    sxy = __builtin_amdgcn_sdot4(x1, y1, sxy, false);
   }
   return harris_eval((uint32_t)sxx >> 4, (uint32_t)syy >> 4, sxy >> 4, threshold);
 }
