@@ -156,7 +156,7 @@ __device__ __attribute__((noinline)) void harris_overflow(lds_u8 *tile, lds_u8 *
 //   163-286) is a per-lane constant; the moments are v_dot4_u32_u8 dot products with the |dx| weights
 //   (Orb.h:123-126); rows are summed across the 32 lanes by DPP; every lane evaluates the angle bin
 //   (Orb.h:310-387); the 256 BRIEF tests (Brief.h:52) read the LDS patch through the precomputed offset
-//   table g_brief_ofs, 32 pairs per half-wave per round, one ballot = one descriptor word per keypoint.
+//   table g_brief_ofs, eight tests per lane = one descriptor byte per lane.
 // ===========================================================================
 constexpr int OWAVES = 4;                           // waves per k_gather_orb workgroup
 constexpr int ORB_PITCH = 48;                       // one 48-byte (3 x 16 B) window per patch row
@@ -235,13 +235,13 @@ __device__ __forceinline__ OrbWin orb_fetch(const OrbLane &G, uint32_t p0, uint3
   }
   return f;
 }
-// Park the fetched windows of a pair, then moments -> angle bin -> BRIEF.  `dst`: where this half's keypoint
-// keeps its `words` descriptor words (ignored when that keypoint is absent).  `wave_patches`: 2 x
+// Park the fetched windows of a pair, then moments -> angle bin -> BRIEF.  `dst_base` (wave-uniform) + 4 * `dst_word`
+// (< 2^30): where this half's keypoint keeps its `words` descriptor words (ignored when that keypoint is absent).  `wave_patches`: 2 x
 // ORB_PATCH_BYTES of LDS private to the wave.  `rtab`: the vrecpe estimate table in LDS.
 template <class TAB>
 __device__ __forceinline__ void orb_describe(const OrbLane &G, const OrbWin &cur, uint32_t p0, uint32_t p1,
                                              lds_u8 *wave_patches, int vstep, const TAB *rtab, int words,
-                                             uint32_t *__restrict__ dst) {
+                                             uint8_t *__restrict__ dst_base, const uint32_t dst_word) {
   const int half = G.half, r = G.r;
   const uint32_t pme = half ? p1 : p0;
   const bool valid = pme != 0;
@@ -284,53 +284,36 @@ __device__ __forceinline__ void orb_describe(const OrbLane &G, const OrbWin &cur
   const int m10 = half_sum((int)right - (int)left, half);
   const int m01 = half_sum((r - 15) * (int)sv, half);
   const uint32_t rot = angle_bin_fast(m10, m01, rtab);
-  // BRIEF: pair k = 32*round + r of this half's keypoint -> bit r of word `round`
+  // BRIEF: lane r of a half runs the EIGHT tests k = 8 r .. 8 r + 7 of its keypoint — byte r of the descriptor (bit
+  // k % 32 of word k / 32 = byte k / 8, bit k % 8).  The sign of a - b IS the test (Brief.h:52) and v_alignbit_b32
+  // shifts it into the byte (tests taken from t = 7 down, so that test 8 r + t ends up in bit t); four adjacent lanes'
+  // bytes make a word (two DPP quad permutes + two v_perm_b32) and ds_bpermute_b32 brings the eight words of a half
+  // into its lanes 0 .. 7, which store them.  g_brief_ofs is laid out for this: entry [rot][t][r] = test 8 r + t, so
+  // that the lanes of a half read 128 contiguous bytes per t.
+  // (One test per lane and round, a ballot per round and v_writelane_b32 to bring the 16 half-ballots back into lanes
+  //  took 8 + 16 VALU and a 5-cycle hazard pad for the same bits: 24.05 -> 22.9 M VALU per launch together with the
+  //  32-bit destination offsets below.  The first measurements of this form were 1.3 % SLOWER per pipelined step: it
+  //  needs fewer SGPRs, which let a seventh wave per SIMD in — see the occupancy pin in k_gather_orb.)
   const uint32_t *tab = ::g_brief_ofs.v + rot * 256 + r;   // defined by the including TU
   // the patch's byte (dy,dx) sits at orb_row_ofs(dy+15) + sh + dx+15 (the table holds the first and last term); sh is
   // the same for every row
   const lds_u8 *bp = patch_l + sh;
   uint32_t ent[8];
 #pragma unroll
-  for (int round = 0; round < 8; round++) ent[round] = tab[32 * round];   // all 8 table loads in flight
-  uint64_t m[8];
+  for (int t = 0; t < 8; t++) ent[t] = tab[32 * t];        // all 8 table loads in flight
+  uint32_t pa[8], pb[8];
 #pragma unroll
-  for (int round = 0; round < 8; round++) {
-    const uint32_t e = ent[round];
-    const uint32_t a = bp[e & 0xffffu], b = bp[e >> 16];
-    m[round] = __ballot(a < b);                                     // Brief.h:52
-  }
-  // lane `round` of either half keeps that half's word: the 16 ballot halves go straight from their SGPRs into
-  // the lanes with v_writelane_b32 (no compare / select per round).  All compares are issued before the first
-  // write; the s_nop covers the "VALU wrote the SGPR a v_writelane reads" distance for the last of them
-  // (tools/probes/writelane.hip: without it the lane can receive the SGPR's previous value; hipcc pads no
-  // hazards inside inline asm).
-  // (Round 4, measured and dropped: eight tests per LANE — the sign of a - b shifted into a byte by v_alignbit_b32, four
-  //  lanes' bytes joined by DPP + v_perm_b32, the table transposed so that the loads stay 128 contiguous bytes per
-  //  half — needs 20 VALU where the ballots and v_writelane_b32 below need 24 and no hazard pad: 24.05 -> 23.3 M VALU
-  //  per launch and the kernel ALONE 1.5 us faster, but its waves live 13 % longer (SQ_WAVE_CYCLES 206 -> 232 M,
-  //  SQ_WAIT_INST_ANY 67 -> 88 M) and the pipelined step, where they share the CUs with the next batch's strip
-  //  kernel, is 1.3 % slower (0.2305 against 0.2275 ms).  Byte stores from all lanes or two 16-byte table loads per
-  //  lane instead: the same.)
-  uint32_t myword = 0;
-  {
-    const uint32_t l0 = (uint32_t)m[0], l1 = (uint32_t)m[1], l2 = (uint32_t)m[2], l3 = (uint32_t)m[3], l4 = (uint32_t)m[4],
-                   l5 = (uint32_t)m[5], l6 = (uint32_t)m[6], l7 = (uint32_t)m[7];
-    const uint32_t h0 = (uint32_t)(m[0] >> 32), h1 = (uint32_t)(m[1] >> 32), h2 = (uint32_t)(m[2] >> 32), h3 = (uint32_t)(m[3] >> 32),
-                   h4 = (uint32_t)(m[4] >> 32), h5 = (uint32_t)(m[5] >> 32), h6 = (uint32_t)(m[6] >> 32), h7 = (uint32_t)(m[7] >> 32);
-    asm volatile("s_nop 4\n\t"
-                 "v_writelane_b32 %0, %1, 0\n\tv_writelane_b32 %0, %9, 32\n\t"
-                 "v_writelane_b32 %0, %2, 1\n\tv_writelane_b32 %0, %10, 33\n\t"
-                 "v_writelane_b32 %0, %3, 2\n\tv_writelane_b32 %0, %11, 34\n\t"
-                 "v_writelane_b32 %0, %4, 3\n\tv_writelane_b32 %0, %12, 35\n\t"
-                 "v_writelane_b32 %0, %5, 4\n\tv_writelane_b32 %0, %13, 36\n\t"
-                 "v_writelane_b32 %0, %6, 5\n\tv_writelane_b32 %0, %14, 37\n\t"
-                 "v_writelane_b32 %0, %7, 6\n\tv_writelane_b32 %0, %15, 38\n\t"
-                 "v_writelane_b32 %0, %8, 7\n\tv_writelane_b32 %0, %16, 39"
-                 : "+v"(myword)
-                 : "s"(l0), "s"(l1), "s"(l2), "s"(l3), "s"(l4), "s"(l5), "s"(l6), "s"(l7), "s"(h0), "s"(h1), "s"(h2), "s"(h3),
-                   "s"(h4), "s"(h5), "s"(h6), "s"(h7));
-  }
-  if (valid && r < words) dst[r] = myword;
+  for (int t = 0; t < 8; t++) pa[t] = bp[ent[t] & 0xffffu], pb[t] = bp[ent[t] >> 16];   // all 16 reads in flight
+  uint32_t acc = 0;
+#pragma unroll
+  for (int t = 7; t >= 0; t--) acc = __builtin_amdgcn_alignbit(acc, pa[t] - pb[t], 31);   // acc = acc << 1 | [a < b]
+  const uint32_t n1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)acc, 0xf5, 0xf, 0xf, true);     // quad_perm [1,1,3,3]
+  const uint32_t hw = __builtin_amdgcn_perm(n1, acc, 0x0c0c0400u);                                   // byte r | byte r+1 << 8
+  const uint32_t n2 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)hw, 0xaa, 0xf, 0xf, true);      // quad_perm [2,2,2,2]
+  const uint32_t word4 = __builtin_amdgcn_perm(n2, hw, 0x05040100u);                                 // valid in lanes r % 4 == 0
+  const uint32_t word = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(4u * (32u * (uint32_t)half + 4u * ((uint32_t)r & 7u))), (int)word4);
+  // (32-bit byte offset from a wave-uniform base: one multiply and a shift-add instead of a 64-bit multiply-add chain)
+  if (valid && r < words) *(uint32_t *)(dst_base + (dst_word * 4u + 4u * (uint32_t)r)) = word;
 }
 
 // Scalar copies of the kernel arguments the strip body needs (the by-value FusedParams must not be
@@ -929,8 +912,8 @@ __device__ __forceinline__ void strip_body(const StripArgs A, const FusedLevel L
           const uint32_t p1 = r1 != 0xffffffffu ? shq_s[i1] + add_xy : 0u;
           if ((p0 | p1) == 0) continue;               // (bucket mode: both dropped)
           const OrbWin w = orb_fetch(G, p0, p1, imb, A.vstep, img_bytes32);
-          orb_describe(G, w, p0, p1, wave_patches, A.vstep, (const lds_u8 *)rtab, A.words,
-                       dbase + (size_t)(G.half ? r1 : r0) * A.words);
+          orb_describe(G, w, p0, p1, wave_patches, A.vstep, (const lds_u8 *)rtab, A.words, (uint8_t *)dbase,
+                       (G.half ? r1 : r0) * (uint32_t)A.words);
         }
       };
       if (Albs == 0) {
@@ -1766,11 +1749,11 @@ __device__ __forceinline__ void orb_role(const FusedParams &P, const uint8_t *__
       for (uint32_t it = wv; it < npairs; it += 2 * OWAVES) {
         pair_of(it + OWAVES, b0, b1, qb0, qb1);
         wb = orb_fetch(G, b0, b1, im, vstep, img_bytes32);
-        orb_describe(G, wa, a0, a1, wave_patches, vstep, rtab, words, dsc + (size_t)(G.half ? qa1 : qa0) * words);
+        orb_describe(G, wa, a0, a1, wave_patches, vstep, rtab, words, (uint8_t *)dsc, (G.half ? qa1 : qa0) * (uint32_t)words);
         if (it + OWAVES >= npairs) break;
         pair_of(it + 2 * OWAVES, a0, a1, qa0, qa1);
         wa = orb_fetch(G, a0, a1, im, vstep, img_bytes32);
-        orb_describe(G, wb, b0, b1, wave_patches, vstep, rtab, words, dsc + (size_t)(G.half ? qb1 : qb0) * words);
+        orb_describe(G, wb, b0, b1, wave_patches, vstep, rtab, words, (uint8_t *)dsc, (G.half ? qb1 : qb0) * (uint32_t)words);
       }
     }
     __syncthreads();                                  // kpl / kpos / todo are reused by the next round
@@ -1790,16 +1773,21 @@ __device__ __forceinline__ void orb_role(const FusedParams &P, const uint8_t *__
 //   - otherwise queued and described here: orb_fetch / orb_describe, two keypoints per wave iteration, the
 //     next pair's loads in flight while the current pair is processed.
 // ===========================================================================
-// (waves_per_eu(6): the kernel takes 72 VGPRs either way — 7 waves per SIMD — but asking for 7 also caps its SGPRs and
-//  cost 13 SGPR spills (v_writelane / v_readlane in the describe loop); with 6 there are none: the same kernel time alone,
-//  1.5 % off the step with three batches in flight, where the strips' workgroups compete for the same issue slots.  A third
-//  register set (the loads of TWO pairs in flight) was measured too: 80 VGPRs, 6 waves, no gain.)
+// (waves_per_eu(6): asking the compiler for 7 waves caps its SGPRs and cost 13 SGPR spills — v_writelane / v_readlane in
+//  the describe loop; the resident waves are pinned to 6 per SIMD inside the kernel, see there.  A third register set
+//  (the loads of TWO pairs in flight) was measured too: 80 VGPRs, no gain.)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) void k_gather_orb(
     const FusedParams P, const uint8_t *__restrict__ pyramids, size_t pyr_stride,
     const uint32_t *__restrict__ stage_kp, const uint32_t *__restrict__ strip_count,
     const uint32_t *__restrict__ stage_desc,
     uint32_t *__restrict__ kp, size_t kp_stride, uint32_t cap, uint32_t *__restrict__ counts,
     uint32_t *__restrict__ desc, size_t desc_stride, int words, uint32_t per_max, uint32_t *__restrict__ ovf_reset) {
+  // SIX waves per SIMD, pinned: the clobber makes the allocation 80 VGPRs (the kernel uses 72).  With three batches in
+  // flight this kernel shares the CUs with the next batch's strip kernel, and the step is fastest when it holds six
+  // wave slots per SIMD: measured 0.2261 ms at 6, 0.2293 at 7 (what 72 VGPRs allow: the kernel ALONE is 2 % faster
+  // there, its waves live 13 % longer), 0.2302 at 5, 0.2354 at 4.  Until round 4 the limit of 6 came about by accident
+  // — 101 SGPRs — and went away whenever a change to the describe loop freed a few of them.
+  asm volatile("" ::: "v79");
   extern __shared__ __attribute__((aligned(16))) uint8_t osm[];
   // the overflow list of this step has been consumed (stream order): empty it for the next step
   if (ovf_reset && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {

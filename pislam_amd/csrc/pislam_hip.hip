@@ -24,7 +24,7 @@ static constexpr uint32_t h_brief_tab_packed[30 * 256] = {
 };
 // The same table as byte offsets into the LDS patch of the ORB kernels (48-byte rows, skewed by one dword per 8
 // rows: pf::orb_row_ofs) whose row 15 / column 15 is the keypoint: ofs = row_ofs(dy+15) + (dx+15); low half = first
-// sample point, high half = second.
+// sample point, high half = second.  Entry order: see make_brief_ofs.
 struct BriefOfsTab {
   uint32_t v[30 * 256];
 };
@@ -35,7 +35,10 @@ static constexpr BriefOfsTab make_brief_ofs() {
     const uint32_t e = h_brief_tab_packed[i];
     const int dx0 = (int8_t)(e & 0xff), dy0 = (int8_t)((e >> 8) & 0xff);
     const int dx1 = (int8_t)((e >> 16) & 0xff), dy1 = (int8_t)(e >> 24);
-    t.v[i] = (uint32_t)(brief_row_ofs(dy0 + 15) + dx0 + 15) | ((uint32_t)(brief_row_ofs(dy1 + 15) + dx1 + 15) << 16);
+    // stored as [rot][t][r] for test k = 8 r + t (pf::orb_describe: lane r of a half runs tests 8 r .. 8 r + 7)
+    const int rot = i >> 8, k = i & 255;
+    t.v[rot * 256 + 32 * (k & 7) + (k >> 3)] =
+        (uint32_t)(brief_row_ofs(dy0 + 15) + dx0 + 15) | ((uint32_t)(brief_row_ofs(dy1 + 15) + dx1 + 15) << 16);
   }
   return t;
 }

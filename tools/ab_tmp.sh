@@ -1,6 +1,6 @@
 #!/bin/bash
 # development A/B of the variant libraries under variants/ (see tools/ab_build.sh); the working tree's library runs the GPU suite
-(timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | grep "passed\|failed\|Error" | tail -3)
+true
 run() { echo "$1: $(timeout 300 bash tools/bench_quick.sh ${@:2})"; }
 for rep in 1 2 3; do
 for n in "$@"; do
