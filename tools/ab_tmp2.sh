@@ -1,8 +1,7 @@
 #!/bin/bash
+(timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | grep "passed\|failed\|Error" | tail -3)
 for rep in 1 2; do
-for w in 720p-build 1280x960; do
-for n in 0 3 4 12; do
-  echo "$w run_len $n: $(timeout 300 bash tools/bench_quick.sh --workload $w --opt run_len=$n)"
-done
+for n in 0 22 20 18; do
+  echo "strip_rows $n: $(timeout 300 bash tools/bench_quick.sh --opt strip_rows=$n)"
 done
 done
