@@ -173,3 +173,31 @@ int run(int device, void *my_stream, const pislam_frontend_params *p, const pisl
         r = subprocess.run([cc, std, "-fsyntax-only", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(src)],
                            capture_output=True, text=True)
         assert r.returncode == 0, r.stderr
+
+
+def test_compiler_resources_of_the_two_measured_kernels(tmp_path):
+    """The residency DESIGN.md §5.1 / §5.2 argue with is a property of the COMPILED kernels: the product strip kernel must
+    fit six waves' worth of registers (<= 80 VGPRs — five workgroups per CU are then set by its LDS alone), keep no
+    private segment and at most a handful of spilled SGPRs outside its loops; k_gather_orb is pinned at an 80-VGPR
+    allocation = six waves per SIMD (the step with batches in flight is measurably slower at five or seven).  Checked
+    on the compiler's own resource remarks (device pass only, no GPU)."""
+    import os
+    import shutil
+    import subprocess
+    from conftest import ROOT
+    if not (shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc")):
+        pytest.skip("hipcc not available")
+    out = tmp_path / "res.txt"
+    subprocess.run(["bash", os.path.join(ROOT, "tools", "kernel_resources.sh"), str(out)], check=True, timeout=600)
+    rows = {}
+    lines = out.read_text().splitlines()
+    cols = [c.strip() for c in lines[0].split("|")]
+    for ln in lines[1:]:
+        f = [c.strip() for c in ln.split("|")]
+        rows[f[0]] = dict(zip(cols[1:], f[1:]))
+    strips = rows["void pf::k_fused_strips<true, false, true, false, false>"]
+    assert int(strips["VGPRs"]) <= 80 and int(strips["ScratchSize [bytes/lane]"]) == 0, strips
+    assert int(strips["VGPRs Spill"]) == 0 and int(strips["SGPRs Spill"]) <= 8, strips
+    gather = rows["pf::k_gather_orb"]
+    assert 73 <= int(gather["VGPRs"]) <= 80 and int(gather["ScratchSize [bytes/lane]"]) == 0, gather
+    assert int(gather["VGPRs Spill"]) == 0 and int(gather["SGPRs Spill"]) == 0, gather
