@@ -34,3 +34,10 @@ for f in sorted(glob.glob(os.path.join(dst, f"{tag}_kernel_stats_*streams1.csv")
 sys.path.insert(0, root)
 from pislam_amd import build  # noqa: E402
 print("source_hash now", build.source_hash())
+# the counters files are only used by bench.py when they were measured on the sources of this tree: say so loudly if not
+# (e.g. a file under csrc/ was touched between launching the closing run and its snapshot)
+for f in sorted(glob.glob(os.path.join(dst, f"{tag}_counters_*.json"))):
+    h = json.load(open(f)).get("source_hash")
+    if h != build.source_hash():
+        print(f"WARNING: {os.path.basename(f)} was measured on kernel sources {h}, this tree is {build.source_hash()} — "
+              f"bench.py will report roofline.traffic / roofline.valu as null: re-run tools/round_final.sh")
