@@ -787,6 +787,7 @@ def worker_main(args):
     ev_total_ms = float(np.mean([e[0] for e in ev]))
     ev_stage_ms = [float(np.mean([e[1][i] for e in ev])) for i in range(3)]
     one_ms = None
+    one_pyr_ms = None
     try:
         pl1 = capi.Pipeline(device=local_rank, depth=1)
         pl1.set_option("graphs", 1 if use_graphs else 0)
@@ -819,6 +820,29 @@ def worker_main(args):
                 brackets.append((e0, e1))
         torch.cuda.synchronize()
         one_ms = min(a.elapsed_time(b) for a, b in brackets) / REPS
+        # ... and ONE pyramid per call on the same object (the reference's own use: a frame at a time)
+        if b1 is None and m_out is None:
+            try:
+                o_s = fe.alloc_outputs(1, dev)
+                d_one = d_pyr[:1]
+                brackets = []
+                with torch.cuda.stream(s1):
+                    for _ in range(4):
+                        pl1.submit(fe.params, fe.levels, d_one, *o_s)
+                    for _ in range(3):
+                        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                        e0.record(s1)
+                        for _ in range(200):
+                            pl1.submit(fe.params, fe.levels, d_one, *o_s)
+                        e1.record(s1)
+                        brackets.append((e0, e1))
+                torch.cuda.synchronize()
+                one_pyr_ms = min(a.elapsed_time(b) for a, b in brackets) / 200
+                if int(o_s[2].cpu()[0]) != int(o1[2].cpu()[0]):
+                    raise RuntimeError("a pyramid alone and as the first of its batch gave different keypoint counts")
+            except Exception as e:                       # noqa: BLE001
+                one_pyr_ms = None
+                print(f"[bench] one-pyramid-per-call measurement failed: {e!r}", file=sys.stderr)
         pl1.close()
     except Exception as e:                               # noqa: BLE001
         print(f"[bench] one-call-at-a-time measurement failed: {e!r}", file=sys.stderr)
@@ -941,6 +965,7 @@ def worker_main(args):
             "warmup": args.warmup, "ms_per_step": step_ms, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "one_batch_ms": one_ms,
+            "one_pyramid_ms": one_pyr_ms,
             "one_batch_value": (local_kp / (one_ms * 1e-3)) if one_ms else None,
             "config": {
                 "workload": {"vga": f"batch={B} synthetic 640x480 pyramids per GPU, 8 levels x1.2 stacked (vstep=640, "
@@ -970,7 +995,7 @@ def worker_main(args):
                 "batches_in_flight": (f"{S}: step k is pislam_pipeline_submit to lane k % {S} of ONE library pipeline object (own "
                                       "HIP stream, context/workspace, outputs, hipGraph inside the library); each step is one whole "
                                       "batch, all K steps start and finish inside the timed region; one_batch_ms = the same "
-                                      "through a pipeline of depth 1" if S > 1 else "1"),
+                                      "through a pipeline of depth 1, one_pyramid_ms = ONE pyramid per call through that object" if S > 1 else "1"),
                 "strips_redone_by_overflow_pass": f"{deferred} of {nstrips}",
                 "max_keypoints": args.max_keypoints, "pyramids_over_capacity": capped,
                 "count_allgather": xchg.path,
