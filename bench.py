@@ -125,6 +125,9 @@ def build_parser():
                          "the CPU (no GPU work, value is null)")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="budget of the 1-thread cpu_baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--one-pyramid", action="store_true",
+                    help="also time ONE pyramid per call (one_pyramid_ms): off by default — its 600 small launches would enter "
+                         "the kernel-trace averages and PMC medians of a profiled run of the default command")
     ap.add_argument("--dist-backend", default=None,
                     help="override the torch.distributed backend (default nccl = RCCL); 'gloo' lets the N>1 code "
                          "path be exercised with several ranks sharing one GPU (testing only)")
@@ -821,7 +824,7 @@ def worker_main(args):
         torch.cuda.synchronize()
         one_ms = min(a.elapsed_time(b) for a, b in brackets) / REPS
         # ... and ONE pyramid per call on the same object (the reference's own use: a frame at a time)
-        if b1 is None and m_out is None:
+        if args.one_pyramid and b1 is None and m_out is None:
             try:
                 o_s = fe.alloc_outputs(1, dev)
                 d_one = d_pyr[:1]
@@ -995,7 +998,7 @@ def worker_main(args):
                 "batches_in_flight": (f"{S}: step k is pislam_pipeline_submit to lane k % {S} of ONE library pipeline object (own "
                                       "HIP stream, context/workspace, outputs, hipGraph inside the library); each step is one whole "
                                       "batch, all K steps start and finish inside the timed region; one_batch_ms = the same "
-                                      "through a pipeline of depth 1, one_pyramid_ms = ONE pyramid per call through that object" if S > 1 else "1"),
+                                      "through a pipeline of depth 1, one_pyramid_ms (--one-pyramid) = ONE pyramid per call through that object" if S > 1 else "1"),
                 "strips_redone_by_overflow_pass": f"{deferred} of {nstrips}",
                 "max_keypoints": args.max_keypoints, "pyramids_over_capacity": capped,
                 "count_allgather": xchg.path,

@@ -35,6 +35,7 @@ python $root/bench.py --steps 50 --warmup 10 --workload 1280x960 --batch 256 --c
 python $root/bench.py --steps 50 --warmup 10 --workload 720p-build --batch 64 --cpu-seconds 5 > $out/bench_720p-build.json 2> $out/bench_720p-build.err
 python $root/bench.py --steps 50 --warmup 10 --streams 1 --no-cpu-baseline > $out/bench_vga_streams1.json 2> /dev/null
 python $root/bench.py --steps 50 --warmup 10 --shared-input --no-cpu-baseline > $out/bench_vga_shared_input.json 2> /dev/null
+python $root/bench.py --steps 50 --warmup 10 --no-cpu-baseline --one-pyramid > $out/bench_vga_one_pyramid_per_call.json 2> /dev/null
 python $root/bench.py --steps 50 --warmup 10 --log-bucket-size 4 --bucket-limit 3 --no-cpu-baseline > $out/bench_vga_buckets43.json 2> /dev/null
 python $root/bench.py --steps 50 --warmup 10 --log-bucket-size 4 --bucket-limit 3 --no-cpu-baseline --opt bucket_select=0 > $out/bench_vga_buckets43_in_strip_selection.json 2> /dev/null
 python $root/bench.py --gpus 2 --dist-backend gloo --steps 20 --warmup 5 --batch 128 --no-cpu-baseline > $out/bench_vga_2ranks_one_gpu_gloo.json 2> $out/bench_2ranks.err
