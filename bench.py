@@ -33,7 +33,7 @@ HBM_PEAK_GBPS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 
 VALU_CYCLES_PER_WAVE_INST = 4.0 # what roofline.valu.issue_frac assumes (see its note)
 VALU_SUSTAINED_PER_S = 533e9    # tools/probes/valu_rate.hip on MI355X: 528-538 G wave64 integer instructions/s chip-wide
 METRIC = "ORB keypoints+descriptors/sec, 640x480 8-level pyramid"
-PROFILE_TAG = "r04"             # profiles/<tag>_counters_<workload>.json holds the PMC passes bench lines quote
+PROFILE_TAG = "r05"             # profiles/<tag>_counters_<workload>.json holds the PMC passes bench lines quote
 
 
 # ---------------------------------------------------------------------------------------------------------
@@ -61,22 +61,29 @@ def effective_cores():
     return vis, eff, how
 
 
-def cpu_baseline(pyr_host, levels, budget_s=10.0, mt_s=3.0):
+CPU_CAP = 16384                                           # oracle output capacity per pyramid (keeps allocation out of the timing)
+
+
+def cpu_baseline(pyr_host, levels, budget_s=10.0, mt_s=3.0, log_bucket=0, bucket_limit=5, keep=0, kept=None):
     """The oracle (bit-exact plain-C restatement of the reference path, oracle/pislam_oracle.c) timed
     on ONE host thread — the reference itself is single-threaded — on a bounded sample of the same
     workload; then the same port on every visible host thread (pthreads inside liborc, one pyramid per
-    thread at a time, timed in C) for >= mt_s seconds.  levels: (w, h, row0[, col0])."""
+    thread at a time, timed in C) for >= mt_s seconds.  levels: (w, h, row0[, col0]).
+    `kept` (a list): receives the oracle's (keypoints, descriptors) of the first `keep` pyramids — they are what
+    parity_in_run compares the timed GPU outputs with, computed here anyway."""
     import numpy as np
     from oracle import orc
     orc.lib()
-    CPU_CAP = 16384                                       # output capacity per pyramid (keeps allocation out of the timing)
-    orc.pyramid4(pyr_host[0], levels, cap=CPU_CAP)        # warm caches / lazy table
+    okw = dict(log_bucket=log_bucket, bucket_limit=bucket_limit, cap=CPU_CAP)
+    orc.pyramid4(pyr_host[0], levels, **okw)              # warm caches / lazy table
     n_kp, n_pyr, t0 = 0, 0, time.perf_counter()
     for b in range(64 * len(pyr_host)):                   # ~budget_s of work: the batch, repeated if need be
-        kp, _, _ = orc.pyramid4(pyr_host[b % len(pyr_host)], levels, cap=CPU_CAP)
+        kp, dsc, _ = orc.pyramid4(pyr_host[b % len(pyr_host)], levels, **okw)
+        if kept is not None and b < keep and b < len(pyr_host):
+            kept.append((kp, dsc))
         n_kp += len(kp)
         n_pyr += 1
-        if time.perf_counter() - t0 > budget_s:
+        if time.perf_counter() - t0 > budget_s and (kept is None or len(kept) >= min(keep, len(pyr_host))):
             break
     dt = time.perf_counter() - t0
     vis, eff, how = effective_cores()
@@ -86,7 +93,8 @@ def cpu_baseline(pyr_host, levels, budget_s=10.0, mt_s=3.0):
     # reported beside the single-thread figure, which stays `value`
     try:
         nthr = max(1, vis)
-        tot, done, dt2 = orc.pyramid_mt(np.ascontiguousarray(pyr_host), levels, nthr, mt_s, cap=CPU_CAP)
+        tot, done, dt2 = orc.pyramid_mt(np.ascontiguousarray(pyr_host), levels, nthr, mt_s, log_bucket=log_bucket,
+                                        bucket_limit=bucket_limit, cap=CPU_CAP)
         out["all_threads"] = {"value": tot / dt2, "threads": nthr, "cores_visible": vis, "cores_effective": round(eff, 2),
                               "cores_effective_source": how,
                               "sample": f"{done} pyramids ({tot} keypoints) in {dt2:.2f} s, {nthr} pthreads (orc_pyramid_mt) "
@@ -94,6 +102,59 @@ def cpu_baseline(pyr_host, levels, budget_s=10.0, mt_s=3.0):
     except Exception as e:                                   # never let the extra leg break the bench line
         out["all_threads"] = {"error": repr(e)}
     return out
+
+
+def parity_in_run(snap, kept, lane_hosts, levels, max_kp, log_bucket, bucket_limit, n_other=8, pins=None):
+    """The proof inside the bench line: what the TIMED steps left in the lanes' output sets against the oracle
+    (oracle/pislam_oracle.c) on the same pyramids — demo.cpp:85-113 prints its feature count; here the counts, the packed
+    keypoints (order included) and the descriptor words are compared.
+      snap[l] = (kp [n][max_kp], desc [n][max_kp][words], counts [B]) of lane l, copied to the host right after the timed
+                region (numpy, uint32);
+      kept    = the oracle's (keypoints, descriptors) of lane 0's first pyramids (computed by cpu_baseline's timing loop);
+      lane_hosts[l] = the first pyramids of lane l on the host: lanes >= 1 are checked on `n_other` pyramids each (counts
+                and keypoint words; lane 0 in full);
+      pins    = optional reference counts every checked pyramid must have (the demo photo: 1754 / 1315)."""
+    import numpy as np
+    from oracle import orc
+    full, kps, count_only, bad = 0, 0, 0, None
+
+    def cmp(l, i, okp, odesc, want_desc):
+        nonlocal kps, bad
+        kp, desc, counts = snap[l]
+        n = int(counts[i])
+        if n != len(okp):
+            bad = bad or f"lane {l} pyramid {i}: {n} keypoints, oracle {len(okp)}"
+            return
+        if pins is not None and n != pins:
+            bad = bad or f"lane {l} pyramid {i}: {n} keypoints, the reference's pin is {pins}"
+            return
+        m = min(n, max_kp)
+        if not np.array_equal(kp[i, :m], okp[:m]):
+            bad = bad or f"lane {l} pyramid {i}: keypoint words differ from the oracle's"
+            return
+        if want_desc and not np.array_equal(desc[i, :m], odesc[:m]):
+            bad = bad or f"lane {l} pyramid {i}: descriptor words differ from the oracle's"
+            return
+        kps += m
+
+    for i, (okp, odesc) in enumerate(kept):
+        if i < len(snap[0][0]):
+            cmp(0, i, okp, odesc, True)
+            full += 1
+    for l in range(1, len(snap)):
+        h = lane_hosts[l % len(lane_hosts)]
+        memo = {}
+        for i in range(min(n_other, len(snap[l][0]))):
+            j = i % len(h)                                   # (a lane's batch tiles the pyramids it holds)
+            if j not in memo:
+                memo[j] = orc.pyramid4(h[j], levels, log_bucket=log_bucket, bucket_limit=bucket_limit, cap=CPU_CAP)
+            cmp(l, i, memo[j][0], memo[j][1], True)
+            count_only += 1
+    return {"pyramids": full, "pyramids_other_lanes": count_only, "keypoints": kps, "ok": bad is None and full > 0,
+            "compared": "keypoint count, packed keypoint words in order, descriptor words — oracle/pislam_oracle.c on the host "
+                        "vs the output sets the timed pislam_pipeline_submit steps wrote (copied right after the timed region)",
+            **({"reference_count_pin": pins} if pins is not None else {}),
+            **({"first_mismatch": bad} if bad else {})}
 
 
 # ---------------------------------------------------------------------------------------------------------
@@ -125,18 +186,25 @@ def build_parser():
                          "the CPU (no GPU work, value is null)")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="budget of the 1-thread cpu_baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--one-pyramid", action="store_true",
-                    help="also time ONE pyramid per call (one_pyramid_ms): off by default — its 600 small launches would enter "
-                         "the kernel-trace averages and PMC medians of a profiled run of the default command")
+    ap.add_argument("--one-pyramid", action="store_true", help=argparse.SUPPRESS)      # (rounds 1-4: opt-in; now the default)
+    ap.add_argument("--no-one-pyramid", action="store_true",
+                    help="skip one_pyramid_ms (ONE pyramid per call, the reference's frame-at-a-time use): profiled runs pass this "
+                         "— its small launches would enter the kernel-trace averages and PMC medians of the batch kernels")
     ap.add_argument("--dist-backend", default=None,
                     help="override the torch.distributed backend (default nccl = RCCL); 'gloo' lets the N>1 code "
                          "path be exercised with several ranks sharing one GPU (testing only)")
     ap.add_argument("--exchange", default="cabi", choices=["cabi", "torch"],
                     help="N>1 count all-gather: the C ABI's communicator (pislam_dist_*, default) or torch.distributed's")
-    ap.add_argument("--workload", default="vga", choices=["vga", "1280x960", "720p-build"],
+    ap.add_argument("--workload", default="vga", choices=["vga", "1280x960", "1280x960-dense", "720p-build", "demo-photo"],
                     help="vga = BASELINE configs[1] (default, the headline; configs[2] when N>1); 1280x960 = configs[3] "
-                         "(packed layout, vstep 1280); 720p-build = configs[4] (gaussian5x5 + bilinear pyramid build on "
-                         "the GPU inside the timed step)")
+                         "(packed layout, vstep 1280, ~2000 keypoints per pyramid as BASELINE.json names it); 1280x960-dense = "
+                         "the same layout with the VGA shape density (~4400 keypoints per pyramid: rounds 2-4 measured this); "
+                         "720p-build = configs[4] (gaussian5x5 + bilinear pyramid build on the GPU inside the timed step); "
+                         "demo-photo = the reference's own demo pyramid (tests/golden/demo_pyramid.npz: natural image content, "
+                         "1754 keypoints) x batch, every lane its own copy")
+    ap.add_argument("--parity-pyramids", type=int, default=32,
+                    help="parity_in_run: pyramids of lane 0 whose timed outputs (counts, keypoints, descriptors) are compared with "
+                         "the oracle after the timed region (other lanes: 8 each); 0 = off.  A mismatch ends the run with rc 6")
     ap.add_argument("--pipeline", type=int, default=0, help="0 auto (fused), 1 staged, 2 fused")
     ap.add_argument("--strip-rows", type=int, default=0)
     ap.add_argument("--orb-chunks", type=int, default=0)
@@ -481,17 +549,22 @@ def worker_main(args):
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 
-    if args.workload == "vga":
+    nshapes = None                                          # synth.make_level0's rule: 80 shapes per VGA frame area
+    if args.workload in ("vga", "demo-photo"):
         levels = synth.level_table()                       # demo.cpp:38-47 table, 2210 stacked rows
         vstep, w0, h0 = 640, 640, 480
-    elif args.workload == "1280x960":
+    elif args.workload in ("1280x960", "1280x960-dense"):
         levels = synth.packed_level_table(1280, 960)       # 3768 rows: levels 4|5 and 6|7 side by side
         vstep, w0, h0 = 1280, 1280, 960
+        # BASELINE.json configs[3] / SURVEY 8d name "~2000 kp/frame": 148 shapes per frame give 1990-2060 keypoints per
+        # pyramid at threshold 20 (calibrated with the oracle); the area-scaled density (320 shapes, ~4400 keypoints) that
+        # rounds 2-4 measured stays available as 1280x960-dense
+        nshapes = 148 if args.workload == "1280x960" else None
     else:
         from pislam_amd.frontend import PyramidBuilder
         w0, h0 = 1280, 720
     B = args.batch
-    distinct = args.distinct or (B if args.workload == "vga" else min(B, 16))
+    distinct = args.distinct or (min(B, 16) if args.workload == "720p-build" else 1 if args.workload == "demo-photo" else B)
     first = rank * B
     S = 1 if args.match else (args.streams if args.streams > 0 else 3)
     force = args.force_exchange and world == 1
@@ -530,8 +603,20 @@ def worker_main(args):
             nd //= 2
     idx = [(rank * S + l) * B + i for l in range(nlane_in) for i in range(nd)]
     host = d_frames = None
+    lane_hosts = []                                       # per input lane: its first pyramids on the host (parity_in_run)
     lane_in = []                                          # per input lane: device tensor (frames or pyramids)
-    if args.workload == "720p-build":
+    if args.workload == "demo-photo":
+        # the reference's own demo input (data fixture; the image its README and demo.cpp run on), `B` copies per lane in
+        # a device buffer of the lane's own: natural image content, 1754 keypoints per pyramid (1315 in README mode <4,3>)
+        rows = synth.pyramid_rows(levels)
+        img = np.load(os.path.join(ROOT, "tests", "golden", "demo_pyramid.npz"))["img"]
+        assert img.shape == (rows, vstep)
+        host = np.ascontiguousarray(img[None])
+        nd = 1
+        for l in range(nlane_in):
+            lane_in.append(torch.from_numpy(host).to(dev).expand(B, rows, vstep).contiguous())
+            lane_hosts.append(host)
+    elif args.workload == "720p-build":
         fr = synth.make_many(idx, workers=gen_workers, kind="level0", w0=w0, h0=h0)
         for l in range(nlane_in):
             t = torch.from_numpy(fr[l * nd:(l + 1) * nd]).to(dev)
@@ -539,11 +624,12 @@ def worker_main(args):
         d_frames = lane_in[0]
     else:
         rows = synth.pyramid_rows(levels)
-        hp = synth.make_many(idx, workers=gen_workers, w0=w0, h0=h0, vstep=vstep, levels=levels)
+        hp = synth.make_many(idx, workers=gen_workers, w0=w0, h0=h0, vstep=vstep, levels=levels, nshapes=nshapes)
         host = hp[:nd]                                    # lane 0's batch: the cpu_baseline sample
         for l in range(nlane_in):
             t = torch.from_numpy(hp[l * nd:(l + 1) * nd]).to(dev)
             lane_in.append(t[torch.arange(B, device=dev) % nd].contiguous() if nd < B else t)
+            lane_hosts.append(hp[l * nd:l * nd + min(8, nd)].copy())
         del hp
 
     # ---- batches in flight: the LIBRARY's pipeline object (pislam_pipeline_*, include/pislam_hip.h) — S lanes, each a
@@ -577,6 +663,7 @@ def worker_main(args):
                 torch.cuda.synchronize()
                 if host is None:
                     host = P.d_pyr[:nd].cpu().numpy()
+                lane_hosts.append(P.d_pyr[:8].cpu().numpy())   # (the pyramids the GPU built: the front-end's own input)
             else:
                 P.d_pyr = P.src
         pipes.append(P)
@@ -752,6 +839,18 @@ def worker_main(args):
         torch.distributed.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    # parity_in_run: what the timed steps left in the lanes' output sets (the set the lane's LAST timed step wrote), copied
+    # now — before anything else touches the pipelines
+    snap = None
+    NP = max(0, args.parity_pyramids)
+    if NP:
+        snap = []
+        for li, P in enumerate(pipes):
+            last_k = max((k for k in range(tick_timed[0], tick_timed[0] + args.steps) if k % S == li), default=None)
+            o = P.outs[(last_k // S) % nsets] if last_k is not None else P.outs[0]
+            n = min(B, NP if li == 0 else 8)
+            snap.append((o[0][:n].cpu().numpy().view(np.uint32), o[1][:n].cpu().numpy().view(np.uint32).reshape(n, args.max_keypoints, -1),
+                         o[2].cpu().numpy().view(np.uint32)))
     clock_ghz = None
     try:
         for _ in range(4):
@@ -824,7 +923,7 @@ def worker_main(args):
         torch.cuda.synchronize()
         one_ms = min(a.elapsed_time(b) for a, b in brackets) / REPS
         # ... and ONE pyramid per call on the same object (the reference's own use: a frame at a time)
-        if args.one_pyramid and b1 is None and m_out is None:
+        if not args.no_one_pyramid and b1 is None and m_out is None:
             try:
                 o_s = fe.alloc_outputs(1, dev)
                 d_one = d_pyr[:1]
@@ -919,6 +1018,7 @@ def worker_main(args):
     total_kp_step = timed_kp / args.steps                  # all ranks, mean over the timed steps
     value = timed_kp / dt
 
+    parity_bad = False
     if rank == 0:
         fused = args.pipeline != 1
         valid_px = sum(t[0] * t[1] for t in levels)
@@ -935,7 +1035,7 @@ def worker_main(args):
         bsfx = f"_buckets{args.log_bucket_size}{args.bucket_limit}" if args.log_bucket_size else ""
         prof, prof_source = load_counters(args.workload, B, bsfx) if fused else (None, "null: staged pipeline")
         prof3, prof3_source = load_counters(args.workload, B, bsfx + "_streams3") if fused else (None, "null: staged pipeline")
-        traffic = traffic_step = traffic_step3 = valu = None
+        traffic = traffic_step = traffic_step3 = valu = lds_info = None
         if prof3:
             traffic_step3 = sum(k.get("hbm_bytes_per_launch", 0) * k.get("launches_per_step", 1) for k in prof3["kernels"].values()) or None
         if prof:
@@ -943,6 +1043,13 @@ def worker_main(args):
             dom = ks.get("k_fused_strips", {})
             traffic = dom.get("hbm_bytes_per_launch")
             traffic_step = sum(k.get("hbm_bytes_per_launch", 0) * k.get("launches_per_step", 1) for k in ks.values()) or None
+            if dom.get("SQ_LDS_IDX_ACTIVE") and dom.get("SQ_BUSY_CU_CYCLES"):
+                # the LDS of the dominant kernel: cycles its arrays were active over the CUs' busy cycles, and the share of
+                # those cycles that were bank-conflict replays (MI355X_MICROARCH.md, LDS section)
+                lds_info = {"busy_frac": dom["SQ_LDS_IDX_ACTIVE"] / dom["SQ_BUSY_CU_CYCLES"],
+                            "conflict_frac": dom.get("SQ_LDS_BANK_CONFLICT", 0.0) / dom["SQ_LDS_IDX_ACTIVE"],
+                            "lds_insts": dom.get("SQ_INSTS_LDS"), "wait_inst_lds": dom.get("SQ_WAIT_INST_LDS"),
+                            "per_phase": f"profiles/{PROFILE_TAG}_phase_ablation.txt", "source": prof_source}
             if dom.get("SQ_INSTS_VALU") and clock_ghz:
                 nsimd = 4 * 256
                 insts = dom["SQ_INSTS_VALU"]
@@ -961,20 +1068,27 @@ def worker_main(args):
                                 "measured 533 G/s: the share of the ACHIEVABLE integer issue rate this kernel uses — the binding "
                                 "resource.  Clock measured in this run (s_memtime vs s_memrealtime under the steps' load)",
                         "source": prof_source}
-        cfg_idx = {"vga": 2 if world > 1 else 1, "1280x960": 3, "720p-build": 4}[args.workload]
+        cfg_idx = {"vga": 2 if world > 1 else 1, "1280x960": 3, "1280x960-dense": 3, "720p-build": 4, "demo-photo": 0}[args.workload]
         out = {
             "metric": METRIC,
             "value": value, "unit": "kp+desc/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": step_ms, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": "u8",
+            "data": "the reference's demo photo (fixture), replicated" if args.workload == "demo-photo" else "synthetic",
             "one_batch_ms": one_ms,
             "one_pyramid_ms": one_pyr_ms,
             "one_batch_value": (local_kp / (one_ms * 1e-3)) if one_ms else None,
             "config": {
                 "workload": {"vga": f"batch={B} synthetic 640x480 pyramids per GPU, 8 levels x1.2 stacked (vstep=640, "
                                     "2210 rows)",
-                             "1280x960": f"batch={B} synthetic 1280x960 pyramids per GPU, 8 levels x1.2, packed layout "
-                                         "(vstep=1280, 3768 rows, levels 4|5 and 6|7 side by side)",
+                             "1280x960": f"batch={B} synthetic 1280x960 pyramids per GPU (~2000 keypoints each: 148 shapes per frame), "
+                                         "8 levels x1.2, packed layout (vstep=1280, 3768 rows, levels 4|5 and 6|7 side by side)",
+                             "1280x960-dense": f"batch={B} synthetic 1280x960 pyramids per GPU at the VGA shape density (320 shapes per "
+                                               "frame, ~4400 keypoints each — denser than BASELINE.json's ~2000), 8 levels x1.2, packed "
+                                               "layout (vstep=1280, 3768 rows, levels 4|5 and 6|7 side by side)",
+                             "demo-photo": f"batch={B} copies per lane of the reference's own demo pyramid (tests/golden/demo_pyramid.npz: "
+                                           "the photo demo.cpp runs on, natural image content), 640x480, 8 levels x1.2 stacked "
+                                           "(vstep=640, 2210 rows)",
                              "720p-build": f"batch={B} synthetic 1280x720 frames per GPU; gaussian5x5 + "
                                            "13/16,7/8,13/16,13/16,7/8,13/16,13/16 bilinear pyramid built on the GPU inside "
                                            f"the step (vstep={vstep}, {rows} rows"
@@ -1028,15 +1142,32 @@ def worker_main(args):
                                "note": "per GPU, every kernel of a step over ms_per_step" +
                                        (" (bytes incl. frame read + pyramid write of the build)" if builder is not None else "")},
                 "valu": valu,
+                "lds": lds_info,
                 "shader_clock_ghz": clock_ghz,
                 "step_gpu_ms": ev_total_ms,
                 "stage_ms": {"detect+score+nms": ev_stage_ms[0], "overflow pass" if fused else "extract": ev_stage_ms[1],
                              "gather+orb" if fused else "orb": ev_stage_ms[2]},
             },
         }
+        kept = []
+        lb, bl = args.log_bucket_size, args.bucket_limit
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(host, levels, budget_s=args.cpu_seconds)
+            out["cpu_baseline"] = cpu_baseline(host, levels, budget_s=args.cpu_seconds, log_bucket=lb, bucket_limit=bl,
+                                               keep=NP, kept=kept)
+        if snap is not None and not args.ablate:
+            from oracle import orc
+            for b in range(len(kept), min(NP, len(host))):      # (no CPU leg in this run: the oracle's results are computed here)
+                k_, d_, _ = orc.pyramid4(host[b], levels, log_bucket=lb, bucket_limit=bl, cap=CPU_CAP)
+                kept.append((k_, d_))
+            kept_full = [kept[i % len(kept)] for i in range(min(NP, B))]     # (batch index i holds host pyramid i % nd)
+            pins = None
+            if args.workload == "demo-photo":                 # the reference's own counts on its demo input
+                pins = 1754 if lb == 0 else 1315 if (lb, bl) == (4, 3) else None
+            out["parity_in_run"] = parity_in_run(snap, kept_full, lane_hosts, levels, args.max_keypoints, lb, bl, pins=pins)
+            parity_bad = not out["parity_in_run"]["ok"]
         print(json.dumps(out), flush=True)
+        if parity_bad:
+            print(f"[bench] parity_in_run FAILED: {out['parity_in_run'].get('first_mismatch')}", file=sys.stderr, flush=True)
     if world > 1:
         torch.distributed.barrier()
         try:
@@ -1045,7 +1176,7 @@ def worker_main(args):
             pass
         pl.synchronize()
         torch.distributed.destroy_process_group()
-    return 0
+    return 6 if parity_bad else 0
 
 
 def main():

@@ -14,6 +14,11 @@ LIB = os.path.join(LIBDIR, "libpislam_hip.so")
 _LIB_OVERRIDE = os.environ.get("PISLAM_HIP_LIB")
 if _LIB_OVERRIDE:
     LIB = os.path.abspath(_LIB_OVERRIDE)
+    if not os.path.exists(LIB):
+        raise RuntimeError(f"PISLAM_HIP_LIB={_LIB_OVERRIDE}: no such library (the override is never built; unset it or run "
+                           "tools/ab_build.sh)")
+    import sys as _sys
+    print(f"[pislam_amd] PISLAM_HIP_LIB override: loading {LIB} instead of the in-tree build", file=_sys.stderr)
 SOURCES = ["pislam_hip.hip"]
 
 

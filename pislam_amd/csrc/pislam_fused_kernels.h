@@ -1454,6 +1454,8 @@ struct SelectPlan {
   int cap[16], uslot0[16];            // slots per unit (buckets x limit), first slot of the level
   int nb_max;                         // most buckets of any level (the dense path's LDS counters: 2 x nb_max dwords per wave)
 };
+// (k_bucket_select takes FusedParams + SelectPlan + four pointers by value: the kernel-argument segment holds 4 KiB)
+static_assert(sizeof(FusedParams) + sizeof(SelectPlan) + 4 * sizeof(void *) <= 4096, "k_bucket_select's arguments exceed the 4 KiB kernarg segment");
 constexpr int SEL_WAVES = 4;
 constexpr int SEL_NB = 1024;                         // buckets per cell row the dense path's LDS counters hold (the host checks)
 __global__ __launch_bounds__(64 * SEL_WAVES) void k_bucket_select(const FusedParams F, const SelectPlan Q,

@@ -511,9 +511,6 @@ PISLAM_EXPORT int pislam_ctx_set_option(pislam_ctx *c, const char *key, int valu
     c->opt_orb_in_strip = value != 0;
   } else if (!strcmp(key, "bucket_select")) {
     c->opt_bucket_select = value != 0;
-
-
-
   } else if (!strcmp(key, "dist_rccl_single")) {
     c->opt_dist_rccl_single = value != 0;
   } else if (!strcmp(key, "bucket_round_up")) {
@@ -1323,6 +1320,69 @@ int ensure_aux(pislam_ctx *c, int nsub) {
   return PISLAM_OK;
 }
 
+// The bucket selection pass (pf::k_bucket_select) and the UNIT plan the gather runs on when the strips run as without buckets
+// (build_fused_plan_rows): one "strip" per (level, cell row), `buckets x limit` slots each, lists final (lbs != 0, no tiles:
+// the gather concatenates).  Shared by run_fused and pislam_frontend_reserve (which sizes w_ustage / w_ucount from it, so that
+// the first bucket-mode call after a reserve allocates nothing and can be captured into a hipGraph).
+int build_select_plan(pislam_ctx *c, const pislam_frontend_params *p, const pf::FusedParams &Fplan, pf::SelectPlan *Qp,
+                      pf::FusedParams *Up) {
+  pf::SelectPlan &Q = *Qp;
+  pf::FusedParams &U = *Up;
+  memset(&Q, 0, sizeof(Q));
+  memset(&U, 0, sizeof(U));
+  const int lbs = p->log_bucket_size, bs = 1 << lbs, B = p->border;
+  Q.lbs = lbs;
+  Q.limit = p->bucket_limit;
+  Q.border = B;
+  int nreal = 0;
+  for (int e = 0; e < Fplan.nlevels; e++) {
+    if (Fplan.lv[e].gfirst != e) continue;           // (the tiles of a level follow its first entry)
+    if (nreal >= 16) return fail(c, PISLAM_ERR_INVALID, "too many levels for the bucket selection pass");
+    const int l = nreal++;
+    const int gn = std::max(1, Fplan.lv[e].gn);
+    const pf::FusedLevel &last = Fplan.lv[e + gn - 1];
+    const int wl = last.col0 + last.w - Fplan.lv[e].col0, hl = Fplan.lv[e].h;       // the level's own size
+    const int nx = wl - 2 * B, ny = hl - 2 * B;
+    Q.row0[l] = Fplan.lv[e].row0;
+    Q.col0[l] = Fplan.lv[e].col0;
+    Q.h[l] = hl;
+    Q.g0[l] = e;
+    Q.gn[l] = gn;
+    Q.unit0[l] = Q.units_per_pyr;
+    Q.nunits[l] = (nx > 0 && ny > 0) ? cdiv(ny, bs) : 0;
+    Q.cap[l] = (nx > 0 ? ((nx - 1) >> lbs) + 1 : 1) * p->bucket_limit;             // Fast.h:201 numBuckets x bucketLimit
+    Q.uslot0[l] = Q.uslots_per_pyr;
+    Q.nb_max = std::max(Q.nb_max, Q.cap[l] / p->bucket_limit);
+    Q.units_per_pyr += Q.nunits[l];
+    Q.uslots_per_pyr += Q.nunits[l] * Q.cap[l];
+    pf::FusedLevel &ul = U.lv[l];
+    ul.w = wl;
+    ul.h = hl;
+    ul.row0 = Q.row0[l];
+    ul.col0 = Q.col0[l];
+    ul.R = 2;                                        // strip_slot_of: slot0 + s * (R >> 1) * nbx
+    ul.nbx = Q.cap[l];
+    ul.nstrips = Q.nunits[l];
+    ul.strip0 = Q.unit0[l];
+    ul.slot0 = Q.uslot0[l];
+    ul.gfirst = l;
+    ul.gn = 1;
+  }
+  Q.nlevels = nreal;
+  U.nlevels = nreal;
+  U.strips_per_pyr = Q.units_per_pyr;
+  U.slots_per_pyr = Q.uslots_per_pyr;
+  U.vstep = p->vstep;
+  U.rows = p->rows;
+  U.border = B;
+  U.lbs = lbs;
+  U.limit = p->bucket_limit;
+  U.words = p->words;
+  U.ablate = Fplan.ablate;
+  if (Q.units_per_pyr == 0) return fail(c, PISLAM_ERR_INVALID, "no extractable level");
+  return PISLAM_OK;
+}
+
 // `Fplan`: the strip plan, built for the largest sub-batch (sub_max pyramids).
 int run_fused(pislam_ctx *c, const pislam_frontend_params *p, const pf::FusedParams &Fplan, size_t lds, size_t lds_alias,
               const uint8_t *pyramids, size_t stride, int batch, int nsub, uint32_t *kp, uint32_t *desc, uint32_t *counts) {
@@ -1336,56 +1396,7 @@ int run_fused(pislam_ctx *c, const pislam_frontend_params *p, const pf::FusedPar
   memset(&Q, 0, sizeof(Q));
   memset(&U, 0, sizeof(U));
   if (sel) {
-    const int lbs = p->log_bucket_size, bs = 1 << lbs, B = p->border;
-    Q.lbs = lbs;
-    Q.limit = p->bucket_limit;
-    Q.border = B;
-    int nreal = 0;
-    for (int e = 0; e < Fplan.nlevels; e++) {
-      if (Fplan.lv[e].gfirst != e) continue;           // (the tiles of a level follow its first entry)
-      if (nreal >= 16) return fail(c, PISLAM_ERR_INVALID, "too many levels for the bucket selection pass");
-      const int l = nreal++;
-      const int gn = std::max(1, Fplan.lv[e].gn);
-      const pf::FusedLevel &last = Fplan.lv[e + gn - 1];
-      const int wl = last.col0 + last.w - Fplan.lv[e].col0, hl = Fplan.lv[e].h;       // the level's own size
-      const int nx = wl - 2 * B, ny = hl - 2 * B;
-      Q.row0[l] = Fplan.lv[e].row0;
-      Q.col0[l] = Fplan.lv[e].col0;
-      Q.h[l] = hl;
-      Q.g0[l] = e;
-      Q.gn[l] = gn;
-      Q.unit0[l] = Q.units_per_pyr;
-      Q.nunits[l] = (nx > 0 && ny > 0) ? cdiv(ny, bs) : 0;
-      Q.cap[l] = (nx > 0 ? ((nx - 1) >> lbs) + 1 : 1) * p->bucket_limit;             // Fast.h:201 numBuckets x bucketLimit
-      Q.uslot0[l] = Q.uslots_per_pyr;
-      Q.nb_max = std::max(Q.nb_max, Q.cap[l] / p->bucket_limit);
-      Q.units_per_pyr += Q.nunits[l];
-      Q.uslots_per_pyr += Q.nunits[l] * Q.cap[l];
-      pf::FusedLevel &ul = U.lv[l];
-      ul.w = wl;
-      ul.h = hl;
-      ul.row0 = Q.row0[l];
-      ul.col0 = Q.col0[l];
-      ul.R = 2;                                        // strip_slot_of: slot0 + s * (R >> 1) * nbx
-      ul.nbx = Q.cap[l];
-      ul.nstrips = Q.nunits[l];
-      ul.strip0 = Q.unit0[l];
-      ul.slot0 = Q.uslot0[l];
-      ul.gfirst = l;
-      ul.gn = 1;
-    }
-    Q.nlevels = nreal;
-    U.nlevels = nreal;
-    U.strips_per_pyr = Q.units_per_pyr;
-    U.slots_per_pyr = Q.uslots_per_pyr;
-    U.vstep = p->vstep;
-    U.rows = p->rows;
-    U.border = B;
-    U.lbs = lbs;
-    U.limit = p->bucket_limit;
-    U.words = p->words;
-    U.ablate = Fplan.ablate;
-    if (Q.units_per_pyr == 0) return fail(c, PISLAM_ERR_INVALID, "no extractable level");
+    PCHK(build_select_plan(c, p, Fplan, &Q, &U));
     if (c->w_ustage.ensure(sizeof(uint32_t) * (size_t)Q.uslots_per_pyr * batch) != PISLAM_OK ||
         c->w_ucount.ensure(sizeof(uint32_t) * (size_t)Q.units_per_pyr * batch) != PISLAM_OK)
       return fail(c, PISLAM_ERR_NOMEM, "hipMalloc(bucket selection staging)");
@@ -1644,6 +1655,14 @@ PISLAM_EXPORT int pislam_frontend_reserve(pislam_ctx *c, const pislam_frontend_p
       if (c->opt_alias && submax <= 65535 && F.strips_per_pyr <= 65535)
         PCHK(prepare_ovf(c, nsub, 2 + (size_t)F.strips_per_pyr * submax));
       if (nsub > 1) PCHK(ensure_aux(c, nsub));
+      if (p->log_bucket_size != 0 && F.lbs == 0) {   // the selection pass's staging (run_fused allocates nothing after this)
+        pf::SelectPlan Q;
+        pf::FusedParams U;
+        PCHK(build_select_plan(c, p, F, &Q, &U));
+        if (c->w_ustage.ensure(sizeof(uint32_t) * (size_t)Q.uslots_per_pyr * batch) != PISLAM_OK ||
+            c->w_ucount.ensure(sizeof(uint32_t) * (size_t)Q.units_per_pyr * batch) != PISLAM_OK)
+          return fail(c, PISLAM_ERR_NOMEM, "hipMalloc(bucket selection staging)");
+      }
     }
   }
   return PISLAM_OK;

@@ -682,6 +682,41 @@ def test_batch_call_is_hipgraph_capturable(gpu_ctx, orc):
     assert c[1] == len(okp) and (kp.cpu().numpy().view(np.uint32)[1, :len(okp)] == okp).all()
 
 
+def test_first_bucket_mode_call_after_reserve_is_capturable(gpu_ctx, orc):
+    """pislam_frontend_reserve sizes the bucket selection pass's staging too (round-4 advisor finding: w_ustage / w_ucount were
+    allocated by the first bucket-mode call itself — a synchronising hipMalloc inside a capture): reserve, then capture the
+    VERY FIRST <4,3> call on the context (only a call without buckets ran before: module load), replay, compare with the oracle."""
+    import torch
+    from pislam_amd import synth
+    from pislam_amd.capi import Context
+    from pislam_amd.frontend import OrbFrontend
+    levels = synth.level_table()
+    pyr = synth.make_batch(44, 3)
+    dev = torch.device("cuda:0")
+    d_pyr = torch.from_numpy(pyr).to(dev)
+    side = torch.cuda.Stream(dev)
+    with torch.cuda.stream(side):
+        ctx = Context(device=0, stream=side.cuda_stream)
+        fe0 = OrbFrontend(levels, vstep=640, rows=2210, max_keypoints=4096, ctx=ctx)
+        kp, desc, counts = fe0.alloc_outputs(3, dev)
+        fe0(d_pyr, kp, desc, counts)                    # no buckets: loads the module, touches none of the selection buffers
+        fe = OrbFrontend(levels, vstep=640, rows=2210, max_keypoints=4096, ctx=ctx, log_bucket_size=4, bucket_limit=3)
+        fe.reserve(3)
+        side.synchronize()
+        for t in (kp, desc, counts):
+            t.zero_()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=side):
+            fe(d_pyr, kp, desc, counts)                 # the first bucket-mode call of this context
+        g.replay()
+        side.synchronize()
+    c = counts.cpu().numpy().view(np.uint32)
+    kk, dd = kp.cpu().numpy().view(np.uint32), desc.cpu().numpy().view(np.uint32)
+    for b in range(3):
+        okp, odesc, _ = orc.pyramid(pyr[b], levels, log_bucket=4, bucket_limit=3)
+        assert c[b] == len(okp) and (kk[b, :len(okp)] == okp).all() and (dd[b, :len(okp)] == odesc).all(), b
+
+
 def test_dense_input_takes_the_overflow_pass_and_stays_exact(gpu_ctx, orc):
     """Level 0: isolated bright dots on the lattice spanned by (4, 0) and (2, 1) — no lattice point lies on another's
     FAST ring, so every dot is a corner: one pixel in four, more than the fast path's on-chip corner queue (at most 4096

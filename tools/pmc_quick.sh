@@ -4,7 +4,7 @@
 cd /tmp && export TMPDIR=/tmp
 root=${GRAFT_REPO_ROOT:-/root/repo}
 d=$root/gpurun_out/pmcq_$$
-rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_BUSY_CYCLES --output-format csv -d $d -o p -- python $root/bench.py --steps 2 --warmup 1 --no-cpu-baseline --graph 0 --streams 1 "$@" > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_BUSY_CU_CYCLES --output-format csv -d $d -o p -- python $root/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-one-pyramid --parity-pyramids 0 --graph 0 --streams 1 "$@" > /dev/null 2>&1
 python - <<P
 import csv, collections
 agg = collections.defaultdict(lambda: collections.defaultdict(list))

@@ -1,27 +1,28 @@
 #!/bin/bash
 # usage (on the GPU box, from the repo root): bash tools/profile_round.sh <tag>   e.g. r03
 # Produces under gpurun_out/<tag>/ everything profiles/ keeps for a round — per workload the PMC counters
-# (separate --pmc passes: FETCH_SIZE | WRITE_SIZE | TCC | SQ), the bench lines (which quote those counters when the
+# (separate --pmc passes: FETCH_SIZE | WRITE_SIZE | TCC | SQ instructions | SQ LDS / activity), the bench lines (which quote those counters when the
 # kernel sources match), rocprofv3 --kernel-trace --stats of the same commands — and copies the counter JSONs to
 # profiles/ so that the bench lines of THIS run can already quote them.
-tag=${1:-r04}
+tag=${1:-r05}
 root=${GRAFT_REPO_ROOT:-$(pwd)}
 out=$root/gpurun_out/$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 pmc_passes() {   # <name> <workload> <batch> <bench args...>: four separate --pmc passes -> counters_<name>.json (+ profiles/)
   name=$1; w=$2; b=$3; shift 3
-  args="--steps 3 --warmup 1 --graph 0 --no-cpu-baseline --spin-s 0.2 --workload $w --batch $b $*"
+  args="--steps 3 --warmup 1 --graph 0 --no-cpu-baseline --no-one-pyramid --parity-pyramids 0 --spin-s 0.2 --workload $w --batch $b $*"
   i=0
-  for pmc in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_BUSY_CYCLES"; do
+  for pmc in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_BUSY_CYCLES SQ_THREAD_CYCLES_VALU" \
+             "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_BUSY_CU_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_SMEM SQ_INST_CYCLES_SALU"; do
     rocprofv3 --kernel-trace --pmc $pmc --output-format csv -d $out/pmc_${name}_$i -o p -- python $root/bench.py $args > /dev/null 2>&1
     i=$((i+1))
   done
-  (cd $root && python tools/counters_json.py $out/counters_$name.json $w $b "bench.py $args" $out/pmc_${name}_0 $out/pmc_${name}_1 $out/pmc_${name}_2 $out/pmc_${name}_3)
+  (cd $root && python tools/counters_json.py $out/counters_$name.json $w $b "bench.py $args" $out/pmc_${name}_0 $out/pmc_${name}_1 $out/pmc_${name}_2 $out/pmc_${name}_3 $out/pmc_${name}_4)
   cp $out/counters_$name.json $root/profiles/${tag}_counters_$name.json
   rm -rf $out/pmc_${name}_*
 }
-for w in vga 1280x960 720p-build; do
+for w in vga 1280x960 720p-build demo-photo; do
   b=256; [ $w = 720p-build ] && b=64
   pmc_passes $w $w $b --streams 1
 done
@@ -33,20 +34,22 @@ cd /tmp
 python $root/bench.py --steps 50 --warmup 10 > $out/bench_vga.json 2> $out/bench_vga.err
 python $root/bench.py --steps 50 --warmup 10 --workload 1280x960 --batch 256 --cpu-seconds 5 > $out/bench_1280x960.json 2> $out/bench_1280x960.err
 python $root/bench.py --steps 50 --warmup 10 --workload 720p-build --batch 64 --cpu-seconds 5 > $out/bench_720p-build.json 2> $out/bench_720p-build.err
+python $root/bench.py --steps 50 --warmup 10 --workload demo-photo --cpu-seconds 5 > $out/bench_demo_photo.json 2> $out/bench_demo_photo.err
+python $root/bench.py --steps 50 --warmup 10 --workload 1280x960-dense --batch 256 --no-cpu-baseline > $out/bench_1280x960-dense.json 2> /dev/null
 python $root/bench.py --steps 50 --warmup 10 --streams 1 --no-cpu-baseline > $out/bench_vga_streams1.json 2> /dev/null
 python $root/bench.py --steps 50 --warmup 10 --shared-input --no-cpu-baseline > $out/bench_vga_shared_input.json 2> /dev/null
-python $root/bench.py --steps 50 --warmup 10 --no-cpu-baseline --one-pyramid > $out/bench_vga_one_pyramid_per_call.json 2> /dev/null
+python $root/bench.py --steps 50 --warmup 10 --no-cpu-baseline > $out/bench_vga_one_pyramid_per_call.json 2> /dev/null   # (one_pyramid_ms is part of the default line)
 python $root/bench.py --steps 50 --warmup 10 --log-bucket-size 4 --bucket-limit 3 --no-cpu-baseline > $out/bench_vga_buckets43.json 2> /dev/null
 python $root/bench.py --steps 50 --warmup 10 --log-bucket-size 4 --bucket-limit 3 --no-cpu-baseline --opt bucket_select=0 > $out/bench_vga_buckets43_in_strip_selection.json 2> /dev/null
 python $root/bench.py --gpus 2 --dist-backend gloo --steps 20 --warmup 5 --batch 128 --no-cpu-baseline > $out/bench_vga_2ranks_one_gpu_gloo.json 2> $out/bench_2ranks.err
 python $root/bench.py --gpus 8 --dist-backend gloo --steps 20 --warmup 5 --batch 32 --no-cpu-baseline > $out/bench_vga_8ranks_one_gpu_gloo.json 2> /dev/null
-for w in vga 1280x960 720p-build; do
+for w in vga 1280x960 720p-build demo-photo; do
   b=256; [ $w = 720p-build ] && b=64
-  rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace_$w -o p -- python $root/bench.py --steps 20 --warmup 5 --no-cpu-baseline --workload $w --batch $b > $out/bench_under_rocprof_$w.json 2>/dev/null
+  rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace_$w -o p -- python $root/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-one-pyramid --workload $w --batch $b > $out/bench_under_rocprof_$w.json 2>/dev/null
   cp $out/trace_$w/p_kernel_stats.csv $out/kernel_stats_$w.csv
   # one batch at a time: per-kernel durations without another batch's kernels sharing the GPU (these are the
   # durations roofline.launch_ms has to agree with)
-  rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace1_$w -o p -- python $root/bench.py --steps 20 --warmup 5 --no-cpu-baseline --streams 1 --workload $w --batch $b > /dev/null 2>&1
+  rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace1_$w -o p -- python $root/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-one-pyramid --streams 1 --workload $w --batch $b > /dev/null 2>&1
   cp $out/trace1_$w/p_kernel_stats.csv $out/kernel_stats_${w}_streams1.csv
 done
 python $root/tools/probes/pipeline_api.py 1 2 3 > $out/pipeline_api.txt 2>/dev/null
