@@ -27,6 +27,11 @@
 #pragma once
 #include "pislam_dev.h"
 
+// development switches (tools/ab_build.sh -D...): the defaults are the product
+#ifndef PISLAM_OVL
+#define PISLAM_OVL 1          // strips of a run follow each other without a workgroup barrier (strip_body)
+#endif
+
 namespace pf {
 
 using namespace pdev;
@@ -332,7 +337,8 @@ struct StripArgs {
 template <bool VEC16, bool HOOKS, bool ALIAS, bool ORBK, bool BUCK>
 __device__ __forceinline__ void strip_body(const StripArgs A, const FusedLevel L, const int pyr, const int s,
                                            const int ys, const int ye, lds_u8 *tile0, lds_u8 *sc, lds_u32 *queues,
-                                           lds_u32 *shq, uint32_t *sh_ctr, const uint8_t *__restrict__ im, const ptrdiff_t lim,
+                                           lds_u32 *shq, uint32_t *sh_ctr, uint32_t *sh_ctr_prev, bool &deferred,
+                                           const uint8_t *__restrict__ im, const ptrdiff_t lim,
                                            uint32_t *__restrict__ stage_kp,
                                            uint32_t *__restrict__ strip_count, uint8_t *__restrict__ score_dump,
                                            size_t score_stride, const bool carry, const int tid,
@@ -371,21 +377,41 @@ __device__ __forceinline__ void strip_body(const StripArgs A, const FusedLevel L
   // score rows [ys-1, ys+2) its score rows R..R+2, so they are moved up inside LDS instead of being
   // staged / classified / scored a second time; the NMS candidates queued for those rows move too.
   const bool carry_img = carry;
+  // OVL (the product kernels: ALIAS layout, no in-strip buckets, no in-strip ORB): a run's strips follow each other WITHOUT
+  // a workgroup barrier in between.  After the NMS barrier of strip s wave 0 ranks and emits its survivors while the
+  // other waves already move the halo rows, compact the corner queue (wave 1) and store the prefetched rows of strip
+  // s + 1; everybody meets again at the staging barrier.  What makes that safe:
+  //  * the counters are double-buffered by strip parity (sh_ctr = this strip's block, sh_ctr_prev = the block of the
+  //    strip above): nothing a late wave still reads of strip s is reset before the staging barrier of strip s + 1;
+  //  * the carry copy and the store of the prefetched rows touch the same LDS vector from the same THREAD (the copy loop
+  //    is dealt like the prefetch: vector v of the new rows belongs to thread v % NT), so the copy's reads of the old
+  //    rows R .. R+9 precede the stores over them in one wave's program order — no barrier between copy and store;
+  //  * the survivors' ranking scratch lies in front of the image tile and is rewritten only by the next classification.
+  constexpr bool OVL = PISLAM_OVL && ALIAS && !BUCK && !ORBK;
+  const int cwave = OVL ? 1 : 0;                    // the wave that compacts the carried queue
+  bool need_sync = true;                            // a barrier between the carry copy and the staging stores
   if (carry) {
     const int R = L.R;
     if (carry_img) {
       const int nv = (10 * tpitch) >> 4;            // source rows R.. and destination rows 0..9 are disjoint (R >= 10)
-      for (int i = tid; i < nv; i += NT) ((lds_u4 *)tile0)[i] = ((const lds_u4 *)(tile0 + R * tpitch))[i];
+      if (OVL && VEC16 && pf_have) {
+        // source vector i is new-row vector (R - 10) * vpr + i: copied by the thread that will store over it
+        const int i0 = (tid - (R - 10) * (tpitch >> 4)) & (NT - 1);
+        for (int i = i0; i < nv; i += NT) ((lds_u4 *)tile0)[i] = ((const lds_u4 *)(tile0 + R * tpitch))[i];
+        need_sync = false;
+      } else {
+        for (int i = tid; i < nv; i += NT) ((lds_u4 *)tile0)[i] = ((const lds_u4 *)(tile0 + R * tpitch))[i];
+      }
     }
     if (!ALIAS) {                                   // (ALIAS: the carried scores travel in the queue entries)
       const int nvs = (3 * pitch) >> 4;
       for (int i = tid; i < nvs; i += NT) ((lds_u4 *)sc)[i] = ((const lds_u4 *)(sc + R * pitch))[i];
     }
-    if (wave == 0) {                                // in-place compaction of the candidate queue (front to back)
+    if (wave == cwave) {                            // in-place compaction of the candidate queue (front to back)
       // plain: the queue of non-zero scores; ALIAS: the one queue of corners, whose entries carry their
       // score in the top byte (0 = scored below the threshold: dropped here)
       lds_u32 *qn = ALIAS ? shq : shq + QH_SHARED;
-      const int tn = (int)sh_ctr[ALIAS ? 0 : 2];
+      const int tn = (int)sh_ctr_prev[ALIAS ? 0 : 2];
       int kept = 0;
       for (int c0 = 0; c0 < tn; c0 += 64) {
         const uint32_t e = qn[min(c0 + lane, tn - 1)];
@@ -397,7 +423,7 @@ __device__ __forceinline__ void strip_body(const StripArgs A, const FusedLevel L
       if (lane < 8)
         sh_ctr[lane] = lane == 1 ? (uint32_t)(ALIAS ? L.qh : QH_SHARED) : (lane == 2 || (ALIAS && lane == 0)) ? (uint32_t)kept : 0u;
     }
-    lds_barrier();
+    if (need_sync) lds_barrier();
     if (!ALIAS) {
       const int nz = (L.R * pitch) >> 4;            // fresh score rows 3 .. R+2
       for (int i = tid; i < nz; i += NT) ((lds_u4 *)(sc + 3 * pitch))[i] = (u32x4)(0u);
@@ -716,6 +742,7 @@ __device__ __forceinline__ void strip_body(const StripArgs A, const FusedLevel L
     // partial.  Nothing is set up per row, the three pointers and the key advance by constants.
     const int lin_lo = r_lo * tpitch, lin_n = max(r_hi - r_lo, 0) * tpitch;
     const int nfull = lin_n >> 8, rem = lin_n & 255;
+    const uint32_t thr1x2 = (uint32_t)(thr + 1) * 0x10001u;
     auto prefilter_step = [&](const lds_u8 *pm, const lds_u8 *pu, const lds_u8 *pd, bool lane_ok) {
       // aligned dword reads; lanes past the tile's columns read harmless bytes of the next tile row
       const uint32_t wl = *(const lds_u32 *)pm;
@@ -730,9 +757,10 @@ __device__ __forceinline__ void strip_body(const StripArgs A, const FusedLevel L
       const uint32_t b = __builtin_amdgcn_sad_hi_u8(__builtin_amdgcn_alignbyte(wr, wc, 3), wc, __builtin_amdgcn_sad_u8(wd, wc, 0u));
       typedef unsigned short us2v __attribute__((ext_vector_type(2)));
       const uint32_t mm = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(us2v, a), __builtin_bit_cast(us2v, b)));
-      uint32_t lo;
-      asm("v_min_u32_sdwa %0, %1, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:WORD_1" : "=v"(lo) : "v"(mm));
-      const bool g = lane_ok && (lo > (uint32_t)thr);
+      // both halves > t  <=>  both halves >= t + 1  <=>  v_pk_min_u16(mm, {t+1, t+1}) == {t+1, t+1}: two instructions the
+      // compiler schedules itself (the SDWA min of the two halves was an opaque asm statement: an s_nop on either side)
+      const uint32_t mn = __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(us2v, mm), __builtin_bit_cast(us2v, thr1x2)));
+      const bool g = lane_ok && (mn == thr1x2);
       const uint64_t m = __ballot(g);
       if (m == 0) return;
       if (g) qg[ng + ballot_rank(m)] = (uint32_t)(uintptr_t)pm;          // the group's address (see pretest_batch)
@@ -785,6 +813,7 @@ __device__ __forceinline__ void strip_body(const StripArgs A, const FusedLevel L
   // ALIAS kernels have no dense fallbacks: a strip whose queues overflowed (very dense corners) is put on
   // the overflow list and redone by k_fused_overflow (non-aliased layout, scan fallbacks) afterwards.
   auto defer = [&]() {
+    deferred = true;                                // (every thread: the caller decides on the next strip's carry)
     if (tid == 0) {
       const uint32_t at = atomicAdd(&ovf[0], 1u);
       ovf[2 + at] = ovf_id;                         // [0] count, [1] count of the previous step, [2..] entries
@@ -1248,15 +1277,26 @@ __device__ __forceinline__ void strips_role(const FusedParams &P, const uint8_t 
                  "+s"(A.strips_per_pyr), "+s"(A.hthr), "+s"(A.words), "+s"(A.orb));
     const int ys = A.border + s * L.R;              // first block-row y of the strip
     const int ye = min(ys + L.R, L.h - A.border);   // one past the last row owned
-    strip_body<VEC16, HOOKS, ALIAS, ORBK, BUCK>(A, L, pyr, s, ys, ye, m.tile, m.sc, m.queues, m.shq, sh_ctr, im, lim, stage_kp,
-                                    strip_count, score_dump, score_stride, carry, tid_o, prof, pf, pf_have, s + 1 < s1,
+    // (OVL: the strips of a run follow each other without a barrier — see strip_body; counters double-buffered by parity)
+    constexpr bool OVL = PISLAM_OVL && ALIAS && !BUCK && !ORBK;
+    uint32_t *ctr = sh_ctr + (OVL ? 8 * (s & 1) : 0), *ctr_prev = sh_ctr + (OVL ? 8 * ((s & 1) ^ 1) : 0);
+    bool deferred = false;
+    strip_body<VEC16, HOOKS, ALIAS, ORBK, BUCK>(A, L, pyr, s, ys, ye, m.tile, m.sc, m.queues, m.shq, ctr, ctr_prev, deferred, im, lim,
+                                    stage_kp, strip_count, score_dump, score_stride, carry, tid_o, prof, pf, pf_have, s + 1 < s1,
                                     pf_have, ovf, ((uint32_t)pyr << 16) | (uint32_t)(L.strip0 + s), stage_desc,
                                     pyramids + (size_t)pyr * pyr_stride, (uint32_t)((size_t)P.rows * P.vstep));
     if (s + 1 < s1) {
-      lds_barrier();                                // every read of this strip's LDS state is done
-      // (a scan fallback scribbles over the tiles, a deferred strip leaves no scores: start afresh)
-      carry = sh_ctr[6] == 0 && L.R >= 10 && !(HOOKS && (P.ablate & 1024));
-      lds_barrier();
+      if (OVL && !(HOOKS && (P.ablate & 0xfbf))) {   // (ablations that cut phases keep the barriers)
+        // a deferred strip left the body early (its waves are not aligned on a barrier) and leaves no scores: the next
+        // strip starts afresh, behind a barrier
+        if (deferred) lds_barrier();
+        carry = !deferred && L.R >= 10;
+      } else {
+        lds_barrier();                              // every read of this strip's LDS state is done
+        // (a scan fallback scribbles over the tiles, a deferred strip leaves no scores: start afresh)
+        carry = ctr[6] == 0 && L.R >= 10 && !(HOOKS && (P.ablate & 1024));
+        lds_barrier();
+      }
       if (HOOKS && prof && threadIdx.x == 0) prof[6] += 1ull;
     }
   }
@@ -1270,7 +1310,7 @@ __global__ __launch_bounds__(NT) void k_fused_strips(
     uint8_t *__restrict__ score_dump, size_t score_stride, unsigned long long *__restrict__ prof,
     uint32_t *__restrict__ ovf, uint32_t *__restrict__ stage_desc) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-  __shared__ uint32_t sh_ctr[8];
+  __shared__ uint32_t sh_ctr[16];                   // two blocks of counters: strips of a run alternate (strips_role)
   // XCD-aware mapping: workgroup b runs on XCD b%8; keep all strips of one pyramid on one XCD so
   // the halo rows shared by neighbouring runs are served by that XCD's L2.
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
@@ -1317,7 +1357,8 @@ __global__ __launch_bounds__(NT) void k_fused_overflow(
     const int ys = A.border + s * L.R;
     const int ye = min(ys + L.R, L.h - A.border);
     bool issued = false;
-    strip_body<VEC16, HOOKS, false, false, true>(A, L, pyr_o, s, ys, ye, m.tile, m.sc, m.queues, m.shq, sh_ctr, im, lim, stage_kp,
+    bool deferred = false;
+    strip_body<VEC16, HOOKS, false, false, true>(A, L, pyr_o, s, ys, ye, m.tile, m.sc, m.queues, m.shq, sh_ctr, sh_ctr, deferred, im, lim, stage_kp,
                                     strip_count, score_dump, score_stride, false, tid_o, nullptr, pf, false, false, issued,
                                     nullptr, 0u, nullptr, nullptr, 0u);
     lds_barrier();

@@ -117,6 +117,7 @@ struct pislam_ctx {
   int opt_repeat_strips = 1; // profiling: launch the strip kernel n times inside the stage-0 event bracket
   int opt_alias = 1;         // fused pipeline: score tile laid over the dead image rows (0 = separate tiles)
   int opt_run_len = 0;       // fused pipeline: strips per workgroup run (0 = default, 1 = independent strips)
+  int lanes_in_flight = 1;   // > 1: this context is a lane of a pislam_pipeline of that depth (other batches' kernels share the GPU)
   int opt_lds_pad = 0;       // profiling only: extra dynamic LDS bytes per strip workgroup
   int opt_wgs_per_cu = 0;    // fused pipeline: if > 0, size strip heights for this many workgroups per CU
   int opt_strip_px = 16384;  // profiling: pixels per strip the height heuristic aims at
@@ -1206,8 +1207,13 @@ bool build_fused_plan_rows(const pislam_ctx *c, const pislam_frontend_params *p,
   // 0.232 / 0.222 / 0.220 / 0.224 / 0.222 / 0.233 for run_len 1 / 2 / 3 / 4 / 6 / 8; 1280x960 batch 256 0.920 / 0.898 /
   // 0.899 / 0.889 / 0.889 for 2 / 4 / 6 / 8 / 12; 720p batch 64 0.191 / 0.191 / 0.197 / 0.206 for 1 / 2 / 3 / 4.
   {
+    // Round 5 (strips of a run follow each other without a barrier): one call at a time the rule stands (VGA batch 256: strip
+    // kernel 0.164 / 0.166 / 0.171 ms for run_len 2 / 3 / 4), but as a LANE of a pipeline — other batches' kernels fill the
+    // tail of the launch — longer runs win: whole step 0.2233 / 0.2208 / 0.2203 ms for 2 / 3 / 4 (720p batch 64: 0.2974 /
+    // 0.2954 for 2 / 3; demo photo x 256: 0.3242 / 0.3208 for 2 / 4).  Lanes aim at ~3.25 workgroups per slot.
     const double per_slot = (double)strips * batch / (5.0 * std::max(1, c->num_cus));
-    F->run_len = c->opt_run_len > 0 ? c->opt_run_len : std::max(1, std::min(8, (int)(per_slot / 6.5 + 0.5)));
+    const double per_wg = c->lanes_in_flight > 1 ? 3.25 : 6.5;
+    F->run_len = c->opt_run_len > 0 ? c->opt_run_len : std::max(1, std::min(8, (int)(per_slot / per_wg + 0.5)));
   }
   for (int l = 0; l < F->nlevels; l++) {
     F->lv[l].run0 = runs;
@@ -1984,6 +1990,7 @@ PISLAM_EXPORT int pislam_pipeline_create(int device, int depth, pislam_pipeline 
     pislam_ctx *c = nullptr;
     int rc = pislam_ctx_create(device, &c);
     if (rc == PISLAM_OK) rc = use_own_stream(c, 2);
+    if (rc == PISLAM_OK) c->lanes_in_flight = depth;
     hipEvent_t e = nullptr;
     if (rc == PISLAM_OK && hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) rc = PISLAM_ERR_HIP;
     if (c) {
