@@ -889,7 +889,7 @@ def worker_main(args):
     ev_total_ms = float(np.mean([e[0] for e in ev]))
     ev_stage_ms = [float(np.mean([e[1][i] for e in ev])) for i in range(3)]
     one_ms = None
-    one_pyr_ms = None
+    one_pyr_ms = one_pyr_lat_ms = one_pyr_path = None
     try:
         pl1 = capi.Pipeline(device=local_rank, depth=1)
         pl1.set_option("graphs", 1 if use_graphs else 0)
@@ -942,6 +942,20 @@ def worker_main(args):
                 one_pyr_ms = min(a.elapsed_time(b) for a, b in brackets) / 200
                 if int(o_s[2].cpu()[0]) != int(o1[2].cpu()[0]):
                     raise RuntimeError("a pyramid alone and as the first of its batch gave different keypoint counts")
+                # ... and the latency of ONE isolated call on an idle stream (events right around the submit, a synchronise
+                # between calls): 200 back-to-back submits above are paced by the host's ~30 us per pislam_pipeline_submit
+                # from Python, not by the GPU
+                lat = []
+                with torch.cuda.stream(s1):
+                    for _ in range(60):
+                        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                        e0.record(s1)
+                        pl1.submit(fe.params, fe.levels, d_one, *o_s)
+                        e1.record(s1)
+                        e1.synchronize()
+                        lat.append(e0.elapsed_time(e1))
+                one_pyr_lat_ms = float(np.median(lat[10:]))
+                one_pyr_path = "one launch (pf::k_frame)" if (fe.last_path_of(c1) & 4) else "three launches"
             except Exception as e:                       # noqa: BLE001
                 one_pyr_ms = None
                 print(f"[bench] one-pyramid-per-call measurement failed: {e!r}", file=sys.stderr)
@@ -1077,6 +1091,8 @@ def worker_main(args):
             "data": "the reference's demo photo (fixture), replicated" if args.workload == "demo-photo" else "synthetic",
             "one_batch_ms": one_ms,
             "one_pyramid_ms": one_pyr_ms,
+            "one_pyramid_latency_ms": one_pyr_lat_ms,
+            "one_pyramid_path": one_pyr_path,
             "one_batch_value": (local_kp / (one_ms * 1e-3)) if one_ms else None,
             "config": {
                 "workload": {"vga": f"batch={B} synthetic 640x480 pyramids per GPU, 8 levels x1.2 stacked (vstep=640, "

@@ -256,6 +256,16 @@ int pislam_frontend_last_timing(pislam_ctx *ctx, float *total_ms, float stage_ms
  * than the fast path is sized for.  Synchronises the context stream. */
 int pislam_frontend_last_stats(pislam_ctx *ctx, uint32_t stats[2]);
 
+/* Which path the last pislam_orb_frontend_batch call on this context took (a bit mask; 0 before the first call).
+ * Results are identical on every path; this is for tests, tuning and bug reports.  No synchronisation. */
+#define PISLAM_PATH_STAGED 1u          /* one launch group per level (option "pipeline" 1, or a shape the strips cannot take) */
+#define PISLAM_PATH_FUSED 2u           /* strip kernel -> overflow pass -> gather + ORB */
+#define PISLAM_PATH_ONE_LAUNCH 4u      /* the same work as ONE launch (pf::k_frame): batches of 1 or 2 pyramids by default, option "frame" */
+#define PISLAM_PATH_BUCKET_SELECT 8u   /* buckets applied by the selection pass between strips and gather (option "bucket_select" 1) */
+#define PISLAM_PATH_BUCKETS_IN_STRIPS 16u /* buckets applied inside the strips (option "bucket_select" 0, or more buckets than the pass holds) */
+#define PISLAM_PATH_GENERIC_ORB 32u    /* generic gather + per-keypoint ORB kernels (vstep % 16 != 0) */
+unsigned pislam_frontend_last_path(const pislam_ctx *ctx);
+
 /* ---- batches in flight ---------------------------------------------------
  * A pipeline = `depth` (1..8) contexts behind one object, each with its own workspace and non-blocking stream:
  * batch k runs on lane k % depth, so that the tail of one batch (partly filled CUs, the latency-bound gather+ORB

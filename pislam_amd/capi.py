@@ -63,6 +63,7 @@ SYMBOLS = {
     "pislam_frontend_last_timing": (_i, [_vp, ctypes.POINTER(ctypes.c_float),
                                          ctypes.POINTER(ctypes.c_float * 3)]),
     "pislam_frontend_last_stats": (_i, [_vp, ctypes.POINTER(ctypes.c_uint32 * 2)]),
+    "pislam_frontend_last_path": (ctypes.c_uint, [_vp]),
     "pislam_pipeline_create": (_i, [_i, _i, ctypes.POINTER(_vp)]),
     "pislam_pipeline_destroy": (_i, [_vp]),
     "pislam_pipeline_depth": (_i, [_vp]),

@@ -28,6 +28,9 @@
 #include "pislam_dev.h"
 
 // development switches (tools/ab_build.sh -D...): the defaults are the product
+#ifndef PISLAM_FRAME_SLEEP
+#define PISLAM_FRAME_SLEEP 16 // k_frame: s_sleep argument between polls (x 64 cycles)
+#endif
 #ifndef PISLAM_OVL
 #define PISLAM_OVL 1          // strips of a run follow each other without a workgroup barrier (strip_body)
 #endif
@@ -816,7 +819,8 @@ __device__ __forceinline__ void strip_body(const StripArgs A, const FusedLevel L
     deferred = true;                                // (every thread: the caller decides on the next strip's carry)
     if (tid == 0) {
       const uint32_t at = atomicAdd(&ovf[0], 1u);
-      ovf[2 + at] = ovf_id;                         // [0] count, [1] count of the previous step, [2..] entries
+      if (ovf_id != 0xffffffffu) ovf[2 + at] = ovf_id;   // [0] count, [1] count of the previous step, [2..] entries
+                                                    // (id 0xffffffff: counted only — k_frame redoes the strip itself)
       if (HOOKS && prof) prof[5] += (sh_ctr[7] & 1 ? 1ull : 0ull) + (sh_ctr[7] & 2 ? 1ull << 20 : 0ull) +
                                     (sh_ctr[7] & 4 ? 1ull << 40 : 0ull);
       sh_ctr[6] = 1;                                // the next strip of the run must not carry from this one
@@ -1232,7 +1236,7 @@ __device__ __forceinline__ StripLds strip_lds(uint8_t *smem, const FusedLevel &L
 // on, the 10 halo image rows and the 3 halo score rows it shares with the strip above are carried
 // over inside LDS (strip_body `carry`), so a run behaves like one strip of run_len * R rows at the
 // LDS footprint of R rows: the halo is staged, classified and scored once per run, not per strip.
-template <bool VEC16, bool HOOKS, bool ALIAS, bool ORBK, bool BUCK>
+template <bool VEC16, bool HOOKS, bool ALIAS, bool ORBK, bool BUCK, bool INLINE_OVF = false>
 __device__ __forceinline__ void strips_role(const FusedParams &P, const uint8_t *__restrict__ pyramids, size_t pyr_stride,
                                             uint32_t *__restrict__ stage_kp, uint32_t *__restrict__ strip_count,
                                             uint8_t *__restrict__ score_dump, size_t score_stride,
@@ -1283,8 +1287,18 @@ __device__ __forceinline__ void strips_role(const FusedParams &P, const uint8_t 
     bool deferred = false;
     strip_body<VEC16, HOOKS, ALIAS, ORBK, BUCK>(A, L, pyr, s, ys, ye, m.tile, m.sc, m.queues, m.shq, ctr, ctr_prev, deferred, im, lim,
                                     stage_kp, strip_count, score_dump, score_stride, carry, tid_o, prof, pf, pf_have, s + 1 < s1,
-                                    pf_have, ovf, ((uint32_t)pyr << 16) | (uint32_t)(L.strip0 + s), stage_desc,
+                                    pf_have, ovf, INLINE_OVF ? 0xffffffffu : ((uint32_t)pyr << 16) | (uint32_t)(L.strip0 + s), stage_desc,
                                     pyramids + (size_t)pyr * pyr_stride, (uint32_t)((size_t)P.rows * P.vstep));
+    if (INLINE_OVF && ALIAS && deferred) {
+      // k_frame: a strip whose queues overflowed is redone right here with the plain layout and its scan fallbacks
+      // (what k_fused_overflow does in the three-launch path); the launch's dynamic LDS covers both layouts
+      lds_barrier();
+      const StripLds m2 = strip_lds<false>(smem, L);
+      bool d2 = false, issued = false;
+      strip_body<VEC16, HOOKS, false, false, true>(A, L, pyr, s, ys, ye, m2.tile, m2.sc, m2.queues, m2.shq, sh_ctr, sh_ctr, d2, im, lim,
+                                      stage_kp, strip_count, score_dump, score_stride, false, tid_o, nullptr, pf, false, false,
+                                      issued, nullptr, 0u, nullptr, nullptr, 0u);
+    }
     if (s + 1 < s1) {
       if (OVL && !(HOOKS && (P.ablate & 0xfbf))) {   // (ablations that cut phases keep the barriers)
         // a deferred strip left the body early (its waves are not aligned on a barrier) and leaves no scores: the next
@@ -1681,12 +1695,18 @@ __host__ __device__ constexpr size_t orb_lds_bytes(int strips_per_pyr, size_t pe
 }
 
 // The gather + ORB role of a workgroup: chunk `ch` of `nch` of pyramid `pyr` (see k_gather_orb).
+struct NoWait {
+  __device__ __forceinline__ bool operator()() const { return true; }
+};
+// `wait_producers` (k_frame): called once the loads that do not depend on the strips (vrecpe table, mask-table row) are
+// under way; returns false (workgroup-uniform) when the lists never arrived — the role then does nothing.
+template <class WAIT = NoWait>
 __device__ __forceinline__ void orb_role(const FusedParams &P, const uint8_t *__restrict__ pyramids, size_t pyr_stride,
                                          const uint32_t *__restrict__ stage_kp, const uint32_t *__restrict__ strip_count,
                                          const uint32_t *__restrict__ stage_desc, uint32_t *__restrict__ kp, size_t kp_stride,
                                          uint32_t cap, uint32_t *__restrict__ counts, uint32_t *__restrict__ desc,
                                          size_t desc_stride, int words, uint32_t per_max, uint8_t *osm_all, const int pyr,
-                                         const int ch, const int nch) {
+                                         const int ch, const int nch, WAIT wait_producers = WAIT()) {
   OrbShared *sh = (OrbShared *)osm_all;
   uint8_t *osm = osm_all + sizeof(OrbShared);
   sh->rtab[threadIdx.x] = ::g_vrecpe_tab.v[threadIdx.x];
@@ -1697,6 +1717,7 @@ __device__ __forceinline__ void orb_role(const FusedParams &P, const uint8_t *__
   // (the lane's mask-table row is loaded FIRST: its memory round trip then runs under the strip-count loads of the
   //  scan instead of standing between the gather part and the first patch fetch)
   const OrbLane G = orb_lane(lane, P.vstep);
+  if (!wait_producers()) return;
   // LDS carve: patches (4 waves x 2 x 1.5 KiB) | strip offsets (S+1) | this round's keypoints still to describe |
   // their final positions
   uint8_t *patches = osm;
@@ -1839,6 +1860,75 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) void k
   }
   orb_role(P, pyramids, pyr_stride, stage_kp, strip_count, stage_desc, kp, kp_stride, cap, counts, desc, desc_stride, words,
            per_max, osm, (int)blockIdx.y, (int)blockIdx.x, (int)gridDim.x);
+}
+
+// ===========================================================================
+// k_frame — the whole path in ONE launch for small batches (the reference's own use: a frame at a time, demo.cpp:77-101,
+// README.md:17-20).  Three dependent launches cost three launch floors (~6.5 us each on MI355X, hipGraph replay
+// included): one pyramid took 31 us end to end, 15 us of it work.  Here the grid holds the strip workgroups FIRST
+// (run-major, longest runs first, like k_fused_strips) and the gather + ORB workgroups of every pyramid BEHIND them;
+// an ORB workgroup waits until its pyramid's runs have all published their lists.
+//   * No deadlock by construction: workgroups are dispatched in blockIdx order, so whenever an ORB workgroup is
+//     resident every strip workgroup has been dispatched or is about to be (it never waits for an ORB workgroup); the
+//     host only takes this path while the ORB workgroups of a few such launches in flight are a small fraction of the
+//     resident slots of an XCD.  The wait is bounded all the same (a second of polling; sync[...] then says so).
+//   * Hand-over: a strip workgroup finishes with a workgroup barrier (which also drains its stores) and ONE agent-scope
+//     RELEASE increment of its pyramid's counter (the L2 write-back of its XCD: pyramids are spread over all eight);
+//     the ORB workgroup polls with agent-scope ACQUIRE loads (cache invalidate), then a workgroup barrier.
+//   * Strips whose queues overflow are redone in place (strips_role<INLINE_OVF>): no overflow list, no second launch.
+//   * The last ORB workgroup to finish re-arms the counters for the next launch (and keeps the deferred-strip count for
+//     pislam_frontend_last_stats) — a captured launch replays without any host-side reset.
+// sync: [0 .. batch) runs done per pyramid, [batch] ORB workgroups done, [batch + 1] 1 = a wait timed out.
+// ===========================================================================
+__global__ __launch_bounds__(NT) void k_frame(const FusedParams P, const uint8_t *__restrict__ pyramids, size_t pyr_stride,
+                                              uint32_t *__restrict__ stage_kp, uint32_t *__restrict__ strip_count,
+                                              uint32_t *__restrict__ kp, size_t kp_stride, uint32_t cap,
+                                              uint32_t *__restrict__ counts, uint32_t *__restrict__ desc, size_t desc_stride,
+                                              int words, uint32_t per_max, int nch, uint32_t *__restrict__ sync,
+                                              uint32_t *__restrict__ ovf) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  __shared__ uint32_t sh_ctr[16];
+  const int n_strip = P.batch * P.runs_per_pyr;
+  if ((int)blockIdx.x < n_strip) {
+    const int pyr = (int)blockIdx.x % P.batch, run = (int)blockIdx.x / P.batch;
+    strips_role<true, false, true, false, false, true>(P, pyramids, pyr_stride, stage_kp, strip_count, nullptr, 0, nullptr, ovf,
+                                                       nullptr, smem, sh_ctr, pyr, run);
+    __syncthreads();                                // every thread's stores have been issued and acknowledged
+    if (threadIdx.x == 0) (void)__hip_atomic_fetch_add(&sync[pyr], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    return;
+  }
+  const int ob = (int)blockIdx.x - n_strip, pyr = ob / nch, ch = ob - pyr * nch;
+  __shared__ uint32_t sh_ok;
+  auto wait = [&]() -> bool {
+    if (threadIdx.x == 0) {
+      uint32_t ok = 0;
+      // (relaxed polls — an acquire load would invalidate this XCD's caches on every iteration, under the strip workgroups
+      //  still streaming their rows through them — and ONE acquire fence once the counter is there)
+      for (int it = 0; it < (1 << 20); it++) {      // (~1 s: only a lost launch ever gets there)
+        if (__hip_atomic_load(&sync[pyr], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (uint32_t)P.runs_per_pyr) {
+          ok = 1;
+          break;
+        }
+        __builtin_amdgcn_s_sleep(PISLAM_FRAME_SLEEP);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      if (!ok) __hip_atomic_store(&sync[P.batch + 1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      sh_ok = ok;
+    }
+    __syncthreads();
+    return sh_ok != 0;
+  };
+  orb_role(P, pyramids, pyr_stride, stage_kp, strip_count, nullptr, kp, kp_stride, cap, counts, desc, desc_stride, words, per_max,
+           smem, pyr, ch, nch, wait);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const uint32_t done = __hip_atomic_fetch_add(&sync[P.batch], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (done + 1 == (uint32_t)(P.batch * nch)) {    // the launch's last workgroup: every strip and every ORB workgroup is through
+      for (int i = 0; i <= P.batch; i++) __hip_atomic_store(&sync[i], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      ovf[1] = __hip_atomic_load(&ovf[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // strips redone in place (last_stats)
+      __hip_atomic_store(&ovf[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
 }
 
 }  // namespace pf

@@ -106,6 +106,7 @@ struct pislam_ctx {
   // batch pipeline workspace
   DevBuf w_score, w_stage, w_stripcnt, w_work, w_prof, w_ovf, w_stagedesc;
   DevBuf w_ustage, w_ucount;         // bucket selection pass (pf::k_bucket_select): per-unit lists and counts
+  DevBuf w_sync;                     // one-launch path (pf::k_frame): per-pyramid hand-over counters, zero between launches
   int num_cus = 0;
   int opt_pipeline = 0;      // 0 auto, 1 staged (one launch group per level), 2 fused strips
   int opt_dump_score = 0;    // fused pipeline: also materialise the score map (parity hook)
@@ -125,10 +126,12 @@ struct pislam_ctx {
   int opt_run_order = 1;     // fused pipeline: launch a pyramid's runs longest first (0: in entry order)
   int opt_tile_cols = 0;     // fused pipeline: levels with more classified columns are cut into x-tiles (0 = 704, < 0 = never)
   int opt_bucket_select = 1; // fused pipeline, buckets: 1 = strips as without buckets + pf::k_bucket_select (default), 0 = the strips select (round 1-3)
+  int opt_frame = 1;         // fused pipeline: small batches run as ONE launch (pf::k_frame): 1 = batches of 1 or 2 pyramids, n = up to n (<= 8), 0 = never
   int opt_orb_in_strip = 0;  // fused pipeline: 1 = strips describe their own keypoints (measured slower: DESIGN.md §8), 0 = k_gather_orb describes all
   int opt_match_mfma = 1;         // matcher on the matrix cores (0: the VALU popcount kernel)
   int opt_dist_rccl_single = 0;   // test hook: pislam_dist_init(world = 1) still creates a (1-rank) RCCL communicator
   int last_pipeline = 0;
+  unsigned last_path = 0;    // PISLAM_PATH_* of the last batch call
   size_t score_bytes_valid = 0;   // bytes of w_score known to be in a consistent (zero-border) state
   pislam_frontend_params last_params{};
   std::vector<pislam_level> last_levels;
@@ -154,7 +157,7 @@ struct pislam_ctx {
   unsigned long long workspace_generation() const {
     unsigned long long g = ovf_layouts;
     for (const DevBuf *b : {&w_cnt, &w_off, &w_total, &w_cellkp, &w_score, &w_stage, &w_stripcnt, &w_work, &w_prof,
-                            &w_ovf, &w_stagedesc, &w_ustage, &w_ucount})
+                            &w_ovf, &w_stagedesc, &w_ustage, &w_ucount, &w_sync})
       g += b->reallocs;
     return g;
   }
@@ -427,7 +430,7 @@ PISLAM_EXPORT int pislam_ctx_destroy(pislam_ctx *c) {
   (void)hipStreamSynchronize(c->stream);
   for (DevBuf *b : {&c->s_img, &c->s_out, &c->s_pts, &c->s_desc, &c->s_misc, &c->s_rots, &c->s_tmp, &c->w_cnt,
                     &c->w_off, &c->w_total, &c->w_cellkp, &c->w_score, &c->w_stage, &c->w_stripcnt, &c->w_work, &c->w_prof, &c->w_ovf,
-                    &c->w_stagedesc, &c->w_ustage, &c->w_ucount})
+                    &c->w_stagedesc, &c->w_ustage, &c->w_ucount, &c->w_sync})
     b->release();
   for (auto &e : c->ev)
     if (e) (void)hipEventDestroy(e);
@@ -508,6 +511,9 @@ PISLAM_EXPORT int pislam_ctx_set_option(pislam_ctx *c, const char *key, int valu
   } else if (!strcmp(key, "tile_cols")) {
     if (value > 0 && value < 64) return fail(c, PISLAM_ERR_INVALID, "tile_cols must be 0 (default), < 0 (never) or >= 64");
     c->opt_tile_cols = value;
+  } else if (!strcmp(key, "frame")) {   // 0: never one launch; 1 (default): batches of 1 or 2 pyramids; n = 2..8: batches of up to n
+    if (value < 0 || value > 8) return fail(c, PISLAM_ERR_INVALID, "frame must be 0..8");
+    c->opt_frame = value;
   } else if (!strcmp(key, "orb_in_strip")) {
     c->opt_orb_in_strip = value != 0;
   } else if (!strcmp(key, "bucket_select")) {
@@ -1389,6 +1395,22 @@ int build_select_plan(pislam_ctx *c, const pislam_frontend_params *p, const pf::
   return PISLAM_OK;
 }
 
+// The one-launch path (pf::k_frame) takes batches of up to FRAME_MAX_BATCH pyramids: three launch floors are most of such
+// a call (one VGA pyramid: 31 us in three launches, 15 us of it work), and its gather + ORB workgroups — which wait inside
+// the grid for their pyramid's strips — stay a small fraction of an XCD's resident slots even with several such launches
+// in flight (at most 128 per launch).
+constexpr int FRAME_MAX_BATCH = 8;                                  // what option "frame" can be raised to
+constexpr int FRAME_DEFAULT_BATCH = 2;                              // measured: one launch wins for 1 and 2 pyramids per call
+inline int frame_max_batch(const pislam_ctx *c) { return c->opt_frame <= 0 ? 0 : c->opt_frame == 1 ? FRAME_DEFAULT_BATCH : std::min(c->opt_frame, FRAME_MAX_BATCH); }
+inline int frame_chunks(int batch) { return std::min(64, std::max(16, 128 / std::max(1, batch))); }   // ORB workgroups per pyramid
+int ensure_frame_sync(pislam_ctx *c) {
+  bool grew = false;
+  if (c->w_sync.ensure(sizeof(uint32_t) * (FRAME_MAX_BATCH + 2), &grew) != PISLAM_OK)
+    return fail(c, PISLAM_ERR_NOMEM, "hipMalloc(frame sync)");
+  if (grew) HIPCHK(c, hipMemsetAsync(c->w_sync.p, 0, c->w_sync.cap, c->stream));   // (the kernel re-arms them itself)
+  return PISLAM_OK;
+}
+
 // `Fplan`: the strip plan, built for the largest sub-batch (sub_max pyramids).
 int run_fused(pislam_ctx *c, const pislam_frontend_params *p, const pf::FusedParams &Fplan, size_t lds, size_t lds_alias,
               const uint8_t *pyramids, size_t stride, int batch, int nsub, uint32_t *kp, uint32_t *desc, uint32_t *counts) {
@@ -1407,6 +1429,7 @@ int run_fused(pislam_ctx *c, const pislam_frontend_params *p, const pf::FusedPar
         c->w_ucount.ensure(sizeof(uint32_t) * (size_t)Q.units_per_pyr * batch) != PISLAM_OK)
       return fail(c, PISLAM_ERR_NOMEM, "hipMalloc(bucket selection staging)");
   }
+  c->last_path = PISLAM_PATH_FUSED | (sel ? PISLAM_PATH_BUCKET_SELECT : 0u) | (Fplan.lbs != 0 ? PISLAM_PATH_BUCKETS_IN_STRIPS : 0u);
   const int Sg = sel ? Q.units_per_pyr : S;            // "strips" of the plan the gather runs on
   // descriptor staging: QS_SHARED slots of `words` dwords per strip (ALIAS strips hold at most QS_SHARED survivors)
   // (only strips that describe their own keypoints write there: option "orb_in_strip")
@@ -1501,6 +1524,30 @@ int run_fused(pislam_ctx *c, const pislam_frontend_params *p, const pf::FusedPar
       HIPCHK(c, hipFuncSetAttribute((const void *)pf::k_gather_orb, hipFuncAttributeMaxDynamicSharedMemorySize, (int)olds));
   }
 
+  // ---- small batches: strips -> (overflowed strips redone in place) -> gather + ORB as ONE launch ----
+  if (alias && vec && !sel && Fplan.lbs == 0 && !hooks && !generic_orb && nsub == 1 && !Fplan.orb_in_strip &&
+      c->opt_repeat_strips <= 1 && batch <= frame_max_batch(c)) {
+    const int fch = frame_chunks(batch);
+    const size_t fper = ((size_t)p->max_keypoints + fch - 1) / fch;
+    const size_t flds = std::max(std::max(lds_alias, lds), pf::orb_lds_bytes(S, fper));
+    if (flds <= 150 * 1024) {
+      PCHK(ensure_frame_sync(c));
+      if (flds > 64 * 1024)
+        HIPCHK(c, hipFuncSetAttribute((const void *)pf::k_frame, hipFuncAttributeMaxDynamicSharedMemorySize, (int)flds));
+      pf::FusedParams F = Fplan;
+      F.batch = batch;
+      const unsigned grid = (unsigned)(batch * F.runs_per_pyr + batch * fch);
+      hipLaunchKernelGGL(pf::k_frame, dim3(grid), dim3(pf::NT), flds, c->stream, F, pyramids, stride, c->w_stage.as<uint32_t>(),
+                         c->w_stripcnt.as<uint32_t>(), kp, (size_t)p->max_keypoints, (uint32_t)p->max_keypoints, counts, desc,
+                         (size_t)p->max_keypoints * p->words, p->words, (uint32_t)fper, fch, c->w_sync.as<uint32_t>(),
+                         c->w_ovf.as<uint32_t>());
+      PCHK(launch_ok(c, "k_frame"));
+      c->last_path = PISLAM_PATH_FUSED | PISLAM_PATH_ONE_LAUNCH;
+      HIPCHK(c, hipEventRecord(c->ev[1], c->stream));   // (one launch: the stage split of last_timing is all in stage 0)
+      HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
+      return PISLAM_OK;
+    }
+  }
   const int base = batch / nsub, rem = batch % nsub;
   hipStream_t M = c->stream, X = nsub > 1 ? c->aux_stream : c->stream;
   for (int sub = 0; sub < nsub; sub++) {
@@ -1588,6 +1635,7 @@ int run_fused(pislam_ctx *c, const pislam_frontend_params *p, const pf::FusedPar
       g_cnt = u_cnt;
     }
     if (generic_orb) {
+      c->last_path |= PISLAM_PATH_GENERIC_ORB;
       hipLaunchKernelGGL(pf::k_gather, dim3(n), dim3(256), sizeof(uint32_t) * (Sg + 1), X, G, g_stage, g_cnt, s_kp,
                          (size_t)p->max_keypoints, (uint32_t)p->max_keypoints, s_counts, ovf);
       PCHK(launch_ok(c, "k_gather"));
@@ -1661,6 +1709,7 @@ PISLAM_EXPORT int pislam_frontend_reserve(pislam_ctx *c, const pislam_frontend_p
       if (c->opt_alias && submax <= 65535 && F.strips_per_pyr <= 65535)
         PCHK(prepare_ovf(c, nsub, 2 + (size_t)F.strips_per_pyr * submax));
       if (nsub > 1) PCHK(ensure_aux(c, nsub));
+      if (batch <= frame_max_batch(c)) PCHK(ensure_frame_sync(c));
       if (p->log_bucket_size != 0 && F.lbs == 0) {   // the selection pass's staging (run_fused allocates nothing after this)
         pf::SelectPlan Q;
         pf::FusedParams U;
@@ -1695,6 +1744,7 @@ PISLAM_EXPORT int pislam_orb_frontend_batch(pislam_ctx *c, const pislam_frontend
   if (c->opt_pipeline >= 2 && !fused)
     return fail(c, PISLAM_ERR_INVALID, "fused pipeline unavailable for these parameters (bucket size / LDS size)");
   c->last_pipeline = fused ? 2 : 1;
+  c->last_path = fused ? PISLAM_PATH_FUSED : PISLAM_PATH_STAGED;
   HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
   if (fused && F.strips_per_pyr == 0) {            // every level is smaller than 2 x border: nothing to extract
     HIPCHK(c, hipMemsetAsync(counts, 0, sizeof(uint32_t) * batch, c->stream));
@@ -1775,6 +1825,8 @@ PISLAM_EXPORT int pislam_frontend_last_stats(pislam_ctx *c, uint32_t stats[2]) {
   stats[1] = c->last_strips;
   return PISLAM_OK;
 }
+
+PISLAM_EXPORT unsigned pislam_frontend_last_path(const pislam_ctx *c) { return c ? c->last_path : 0u; }
 
 PISLAM_EXPORT int pislam_frontend_last_timing(pislam_ctx *c, float *total_ms, float stage_ms[3]) {
   if (!c) return PISLAM_ERR_INVALID;

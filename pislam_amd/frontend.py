@@ -319,6 +319,16 @@ class OrbFrontend:
                 "pislam_frontend_last_timing")
         return float(tot.value), [float(v) for v in st]
 
+    PATH_STAGED, PATH_FUSED, PATH_ONE_LAUNCH, PATH_BUCKET_SELECT, PATH_BUCKETS_IN_STRIPS, PATH_GENERIC_ORB = 1, 2, 4, 8, 16, 32
+
+    def last_path_of(self, ctx) -> int:
+        """last_path() of another context (a pipeline lane) that ran this front-end's parameters."""
+        return int(ctx.lib.pislam_frontend_last_path(ctx.h))
+
+    def last_path(self) -> int:
+        """Bit mask PATH_* of the path the last call on this context took — see pislam_frontend_last_path."""
+        return int(self.ctx.lib.pislam_frontend_last_path(self.ctx.h))
+
     def last_stats(self):
         """(strips redone by the overflow pass, strips) of the last call — see pislam_frontend_last_stats."""
         c = self.ctx

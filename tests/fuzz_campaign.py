@@ -40,6 +40,7 @@ def make_wide(seed):
                 orb_in_strip=int(rng.choice([0, 0, 1])), tile_cols=int(rng.choice([0, 0, -1, 192, 256, 320, 448])),
                 strip_rows_max=int(rng.choice([0, 28, 36, 44, 56, 64])), run_order=int(rng.integers(0, 2)),
                 bucket_select=int(rng.choice([1, 1, 0])))
+    opts["frame"] = int(rng.choice([8, 1, 0]))      # (drawn last: earlier campaigns' configurations keep their seeds)
     return levels, vstep, rows, pyr, par, opts
 
 

@@ -36,6 +36,7 @@ def make_case(seed):
                 strip_rows=int(rng.choice([0, 0, 10, 16, 22, 32])), sub_batches=1 + int(rng.choice([0, 0, 0, 64, 96])) // 48,
                 orb_in_strip=int(rng.integers(0, 2)), tile_cols=int(rng.choice([0, -1, 64, 96, 160])),
                 strip_rows_max=int(rng.choice([0, 0, 36, 56, 64])), bucket_select=int(rng.choice([1, 1, 0])))
+    opts["frame"] = int(rng.choice([8, 1, 0]))      # (drawn last: the configurations of earlier campaigns keep their seeds)
     return levels, vstep, rows, pyr, par, opts
 
 
@@ -67,7 +68,7 @@ def test_random_configurations_match_the_oracle(gpu_ctx, orc, chunk):
                 assert (d[b, :m].reshape(m, par["words"]) == odesc[:m]).all(), (seed, b, par, opts, levels)
     finally:
         for k, v in dict(pipeline=0, alias=1, run_len=0, strip_rows=0, sub_batches=1, orb_in_strip=0, tile_cols=0,
-                         strip_rows_max=0, bucket_select=1).items():
+                         strip_rows_max=0, bucket_select=1, frame=1).items():
             gpu_ctx.set_option(k, v)
 
 
@@ -191,7 +192,7 @@ def test_random_packed_layouts_match_the_oracle(gpu_ctx, orc):
                 assert (d_[b, :len(exp)] == orc.orb_compute(pyr[b], exp)).all(), (t, b, levels, opts)
     finally:
         for k, v in dict(pipeline=0, alias=1, run_len=0, strip_rows=0, sub_batches=1, orb_in_strip=0, tile_cols=0,
-                         strip_rows_max=0, bucket_select=1).items():
+                         strip_rows_max=0, bucket_select=1, frame=1).items():
             gpu_ctx.set_option(k, v)
 
 

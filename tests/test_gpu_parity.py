@@ -58,7 +58,76 @@ def pipeline(request, gpu_ctx):
     gpu_ctx.set_option("strip_rows", 0)
 
 
-def test_batch_path_on_reference_demo_pyramid(gpu_ctx, demo, pipeline):
+@pytest.fixture(params=[8, 0], ids=["one-launch", "three-launches"])
+def frame(request, gpu_ctx):
+    """Small batches run as ONE launch (pf::k_frame; option "frame": 1 = the default, batches of 1 or 2 pyramids; 8 = up to 8)
+    or as strips -> overflow pass -> gather+ORB."""
+    gpu_ctx.set_option("frame", request.param)
+    yield request.param
+    gpu_ctx.set_option("frame", 1)
+
+
+@pytest.mark.parametrize("batch", [1, 2, 4, 8, 9])
+def test_one_launch_path_on_reference_demo_pyramid(gpu_ctx, demo, orc, batch):
+    """The reference's own use is a frame at a time (demo.cpp:77-101): small batches take the one-launch path
+    (strip workgroups, then the gather + ORB workgroups of the same grid waiting for their pyramid) — the demo pyramid
+    against the SURVEY pins at every slot, a flipped pyramid in between against the oracle, the path reported by
+    pislam_frontend_last_path, repeated calls (the launch re-arms its own hand-over counters) and a hipGraph replay."""
+    import torch
+    from pislam_amd.frontend import OrbFrontend
+    img = demo["img"]
+    dev = torch.device("cuda:0")
+    flip = img[::-1].copy()
+    host = np.stack([flip if (b % 3) == 1 else img for b in range(batch)])
+    okp, odesc, _ = orc.pyramid(flip, demo["levels"])
+    gpu_ctx.set_option("frame", 8)                    # (the default takes batches of 1 and 2)
+    fe = OrbFrontend(demo["levels"], vstep=640, rows=2210, max_keypoints=4096, ctx=gpu_ctx)
+    kp, desc, counts = fe.alloc_outputs(batch, dev)
+    d_pyr = torch.from_numpy(host).to(dev)
+
+    def check():
+        c = counts.cpu().numpy().view(np.uint32)
+        k = kp.cpu().numpy().view(np.uint32)
+        d = desc.cpu().numpy().view(np.uint32)
+        for b in range(batch):
+            if (b % 3) == 1:
+                assert c[b] == len(okp) and (k[b, :len(okp)] == okp).all() and (d[b, :len(okp)] == odesc).all(), b
+            else:
+                assert c[b] == 1754 and sha16(k[b, :1754]) == SURVEY_PINS["kp"] and sha16(d[b, :1754]) == SURVEY_PINS["desc"], b
+
+    for rep in range(3):
+        for t in (kp, desc, counts):
+            t.zero_()
+        fe(d_pyr, kp, desc, counts)
+        torch.cuda.synchronize()
+        one = bool(fe.last_path() & fe.PATH_ONE_LAUNCH)
+        assert one == (batch <= 8), (batch, fe.last_path())
+        assert fe.last_stats()[0] == 0                     # the demo photo stays on the fast path
+        check()
+    gpu_ctx.set_option("frame", 1)
+    fe(d_pyr, kp, desc, counts)
+    torch.cuda.synchronize()
+    assert bool(fe.last_path() & fe.PATH_ONE_LAUNCH) == (batch <= 2)
+    side = torch.cuda.Stream(dev)
+    with torch.cuda.stream(side):
+        from pislam_amd.capi import Context
+        ctx = Context(device=0, stream=side.cuda_stream)
+        fe2 = OrbFrontend(demo["levels"], vstep=640, rows=2210, max_keypoints=4096, ctx=ctx)
+        fe2.reserve(batch)
+        fe2(d_pyr, kp, desc, counts)
+        side.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=side):
+            fe2(d_pyr, kp, desc, counts)
+        for rep in range(3):
+            for t in (kp, desc, counts):
+                t.zero_()
+            g.replay()
+            side.synchronize()
+            check()
+
+
+def test_batch_path_on_reference_demo_pyramid(gpu_ctx, demo, pipeline, frame):
     import torch
     from pislam_amd.frontend import OrbFrontend
     img = demo["img"]
@@ -134,7 +203,7 @@ def test_x_tiles_as_work_items_reproduce_reference_order(gpu_ctx, demo, tile_col
 
 
 @pytest.mark.parametrize("orb_in_strip,rows_max", [(0, 0), (1, 0), (0, 56), (1, 44), (0, 64)])
-def test_product_kernels_on_reference_demo_pyramid(gpu_ctx, demo, orb_in_strip, rows_max):
+def test_product_kernels_on_reference_demo_pyramid(gpu_ctx, demo, orb_in_strip, rows_max, frame):
     """The product instantiations (no debug hooks) with either ORB placement — one gather+ORB pass (default) or
     every strip describing its own keypoints (strip_body phase E, descriptors staged per strip) — and with the
     strip-height cap of small launches (28) and of large ones (56: up to 56-row strips on the narrow levels) —
@@ -289,7 +358,7 @@ def test_brief_describe_all_rotations(gpu_ctx, orc, demo):
 @pytest.mark.parametrize("strip_rows,sub_batches,run_len",
                          [(0, 1, 0), (16, 1, 1), (16, 1, 3), (32, 1, 2), (2, 1, 0), (64, 1, 64), (0, 2, 0), (0, 3, 1),
                           (16, 2, 5), (32, 3, 0), (0, 16, 0), (10, 1, 64), (12, 1, 7), (8, 1, 4)])
-def test_fused_strip_heights(gpu_ctx, orc, strip_rows, sub_batches, run_len):
+def test_fused_strip_heights(gpu_ctx, orc, strip_rows, sub_batches, run_len, frame):
     """The fused pipeline's result must not depend on how levels are cut into strips and runs of strips (halo
     rows carried over in LDS between the strips of a run), nor on the batch being cut into sub-batches."""
     import torch
@@ -336,7 +405,7 @@ def test_fused_strip_heights(gpu_ctx, orc, strip_rows, sub_batches, run_len):
         gpu_ctx.set_option("ablate", 0)
 
 
-def test_fused_odd_shapes_and_unaligned_layouts(gpu_ctx, orc):
+def test_fused_odd_shapes_and_unaligned_layouts(gpu_ctx, orc, frame):
     """Packed side-by-side layout (col0 != 0, not 16-aligned -> scalar staging path), ragged level
     sizes, odd (w-2B), levels too small to hold a keypoint, batch not a multiple of 8."""
     import torch
@@ -401,7 +470,7 @@ def test_fused_odd_shapes_and_unaligned_layouts(gpu_ctx, orc):
         assert (d[b, :len(exp)] == orc.orb_compute(pyr[b], exp)).all()
 
 
-def test_batch_parity_on_synthetic_pyramids(gpu_ctx, orc, pipeline):
+def test_batch_parity_on_synthetic_pyramids(gpu_ctx, orc, pipeline, frame):
     """bench workload (VGA 8-level x1.2, thr 20, Harris 1<<15): batch path vs oracle, bit-exact,
     incl. score maps, with and without buckets, and with a clipped keypoint capacity."""
     import torch
@@ -717,7 +786,7 @@ def test_first_bucket_mode_call_after_reserve_is_capturable(gpu_ctx, orc):
         assert c[b] == len(okp) and (kk[b, :len(okp)] == okp).all() and (dd[b, :len(okp)] == odesc).all(), b
 
 
-def test_dense_input_takes_the_overflow_pass_and_stays_exact(gpu_ctx, orc):
+def test_dense_input_takes_the_overflow_pass_and_stays_exact(gpu_ctx, orc, frame):
     """Level 0: isolated bright dots on the lattice spanned by (4, 0) and (2, 1) — no lattice point lies on another's
     FAST ring, so every dot is a corner: one pixel in four, more than the fast path's on-chip corner queue (at most 4096
     entries) holds for a 32-row strip — and levels of uniform noise: the strips whose queue overflows are redone by the
@@ -877,7 +946,7 @@ def test_bench_self_launch_two_ranks_sharing_this_gpu():
 
 
 @pytest.mark.parametrize("border", [16, 17, 19, 20, 32])
-def test_fused_borders(gpu_ctx, orc, border):
+def test_fused_borders(gpu_ctx, orc, border, frame):
     """Any border >= 16 (odd ones too: block origins and x-tile edges then fall off dword boundaries), with
     and without buckets, on both LDS layouts."""
     import torch

@@ -187,6 +187,13 @@ int run_dropin(bool buckets, const char *out_path, std::vector<uint32_t> *points
 // flight through ONE pislam_pipeline (lanes of contexts inside the library; repeated calls replayed from hipGraphs)
 // and ONE communicator per process (a context of its own; the all-gathers are ordered after / fence the lanes'
 // streams with pislam_dist_allgather_counts_on / pislam_dist_fence_on)
+struct LibOpt {
+  std::string key;
+  int value = 0;
+};
+LibOpt g_opts[8];
+int g_nopts = 0;
+
 struct OutSet {
   uint32_t *d_kp = nullptr, *d_desc = nullptr, *d_counts = nullptr, *d_all = nullptr;
 };
@@ -207,6 +214,11 @@ int run_batch(int batch, int steps, bool buckets, const char *out_path, int rank
   HIP_OK(hipSetDevice(device));
   pislam_pipeline *pipe = nullptr;
   if (pislam_pipeline_create(device, streams, &pipe) != PISLAM_OK) return 11;
+  for (int i = 0; i < g_nopts; i++)
+    if (pislam_pipeline_set_option(pipe, g_opts[i].key.c_str(), g_opts[i].value) != PISLAM_OK) {
+      fprintf(stderr, "--opt %s=%d: %s\n", g_opts[i].key.c_str(), g_opts[i].value, pislam_pipeline_last_error(pipe));
+      return 11;
+    }
   pislam_ctx *comm = nullptr;                            // holds the communicator and the collective stream
   if (pislam_ctx_create(device, &comm) != PISLAM_OK) return 11;
   // ---- one process per GPU: ONE communicator from a unique id handed over through a file ----
@@ -274,11 +286,13 @@ int run_batch(int batch, int steps, bool buckets, const char *out_path, int rank
     // the lane's stream is in order, so its previous batch is behind it; the all-gather that READ this output set
     // (`streams` exchanges ago) must be done before the batch overwrites it
     void *lane_stream = pislam_pipeline_stream(pipe, (uint64_t)s);       // (lane s % streams)
-    if (pislam_dist_fence_on(comm, streams, lane_stream) != PISLAM_OK) return 1;
+    const bool exchange = world > 1 || rccl_single || batch > 2;        // (a frame at a time on one GPU: nothing to exchange)
+    if (exchange && pislam_dist_fence_on(comm, streams, lane_stream) != PISLAM_OK) return 1;
     if (pislam_pipeline_submit(pipe, &P, lv, d_in[(size_t)(s % streams)], pyr_bytes, count, o.d_kp, o.d_desc, o.d_counts, nullptr, 0, &t) != PISLAM_OK) {
       fprintf(stderr, "pislam_pipeline_submit: %s\n", pislam_pipeline_last_error(pipe));
       return 1;
     }
+    if (!exchange) return 0;
     return pislam_dist_allgather_counts_on(comm, pislam_pipeline_stream(pipe, t), o.d_counts, (size_t)count, o.d_all) != PISLAM_OK;
   };
   for (int s = 0; s < 3 * streams; s++)                  // warm-up: eager, capture, first replay on every lane
@@ -297,13 +311,14 @@ int run_batch(int batch, int steps, bool buckets, const char *out_path, int rank
   PISLAM_OK_(comm, pislam_dist_allreduce_max(comm, &dt));           // the slowest rank
 
   std::vector<uint32_t> all((size_t)count * world);
-  HIP_OK(hipMemcpy(all.data(), sets[0].d_all, all.size() * 4, hipMemcpyDeviceToHost));
+  const bool exchanged = world > 1 || rccl_single || batch > 2;
+  HIP_OK(hipMemcpy(all.data(), exchanged ? sets[0].d_all : sets[0].d_counts, all.size() * 4, hipMemcpyDeviceToHost));
   unsigned long long total = 0;
   for (uint32_t c : all) total += c < (uint32_t)P.max_keypoints ? c : (uint32_t)P.max_keypoints;
   int bad = 0;
   for (size_t k = 1; k < sets.size(); k++) {            // every lane gathered the same counts
     std::vector<uint32_t> other(all.size());
-    HIP_OK(hipMemcpy(other.data(), sets[k].d_all, other.size() * 4, hipMemcpyDeviceToHost));
+    HIP_OK(hipMemcpy(other.data(), exchanged ? sets[k].d_all : sets[k].d_counts, other.size() * 4, hipMemcpyDeviceToHost));
     bad += other != all;
   }
   if (rank == 0) {
@@ -340,7 +355,7 @@ int run_batch(int batch, int steps, bool buckets, const char *out_path, int rank
 int main(int argc, char **argv) {
   if (argc < 2) {
     fprintf(stderr, "Usage: %s pyramid.raw|pyramid.pgm [--buckets] [--out result.bin] [--paint marked.pgm] [--threads T] [--batch N [--steps K] "
-                    "[--streams S] [--world W] [--rccl-single]]\n", argv[0]);
+                    "[--streams S] [--world W] [--rccl-single] [--opt key=value ...]]\n", argv[0]);
     return 1;
   }
   bool buckets = false, rccl_single = false;
@@ -356,6 +371,11 @@ int main(int argc, char **argv) {
     else if (!strcmp(argv[i], "--world") && i + 1 < argc) world = atoi(argv[++i]);
     else if (!strcmp(argv[i], "--threads") && i + 1 < argc) threads = atoi(argv[++i]);
     else if (!strcmp(argv[i], "--streams") && i + 1 < argc) streams = atoi(argv[++i]);
+    else if (!strcmp(argv[i], "--opt") && i + 1 < argc && g_nopts < 8 && strchr(argv[i + 1], '=')) {   // library option key=value (batch path)
+      const char *kv = argv[++i];
+      g_opts[g_nopts].key.assign(kv, strchr(kv, '=') - kv);
+      g_opts[g_nopts++].value = atoi(strchr(kv, '=') + 1);
+    }
     else {
       fprintf(stderr, "unknown argument %s\n", argv[i]);
       return 1;
