@@ -266,6 +266,15 @@ int pislam_frontend_last_stats(pislam_ctx *ctx, uint32_t stats[2]);
 #define PISLAM_PATH_GENERIC_ORB 32u    /* generic gather + per-keypoint ORB kernels (vstep % 16 != 0) */
 unsigned pislam_frontend_last_path(const pislam_ctx *ctx);
 
+/* Host only — no device, no allocation, no launch: build the strip plan (and the bucket selection plan) a batch call with
+ * these parameters would run and check the invariants the kernels rely on.  `options`: "key=value,key=value" with
+ * pislam_ctx_set_option keys (NULL / "": defaults); num_cus <= 0: 256; lanes_in_flight: 1, or the depth of the pipeline the
+ * call would be a lane of.  summary: [0] plan entries, [1] strips, [2] runs, [3] staging slots per pyramid, [4] strips per
+ * run, [5] / [6] LDS bytes of the plain / aliased layout, [7] units of the bucket selection pass.  Returns
+ * PISLAM_ERR_INVALID (message in `err`) when the parameters are refused or the staged pipeline would take the call. */
+int pislam_debug_build_plan(const pislam_frontend_params *params, const pislam_level *levels, int batch, int num_cus,
+                            int lanes_in_flight, const char *options, uint32_t summary[8], char *err, size_t err_cap);
+
 /* ---- batches in flight ---------------------------------------------------
  * A pipeline = `depth` (1..8) contexts behind one object, each with its own workspace and non-blocking stream:
  * batch k runs on lane k % depth, so that the tail of one batch (partly filled CUs, the latency-bound gather+ORB

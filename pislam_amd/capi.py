@@ -64,6 +64,8 @@ SYMBOLS = {
                                          ctypes.POINTER(ctypes.c_float * 3)]),
     "pislam_frontend_last_stats": (_i, [_vp, ctypes.POINTER(ctypes.c_uint32 * 2)]),
     "pislam_frontend_last_path": (ctypes.c_uint, [_vp]),
+    "pislam_debug_build_plan": (_i, [ctypes.POINTER(FrontendParams), ctypes.POINTER(Level), _i, _i, _i, ctypes.c_char_p,
+                                     ctypes.POINTER(ctypes.c_uint32 * 8), ctypes.c_char_p, _sz]),
     "pislam_pipeline_create": (_i, [_i, _i, ctypes.POINTER(_vp)]),
     "pislam_pipeline_destroy": (_i, [_vp]),
     "pislam_pipeline_depth": (_i, [_vp]),

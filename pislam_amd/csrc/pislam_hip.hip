@@ -1659,6 +1659,113 @@ int run_fused(pislam_ctx *c, const pislam_frontend_params *p, const pf::FusedPar
 
 }  // namespace
 
+// Host-only: build the strip plan (and the bucket selection plan) for these parameters exactly as a batch call would —
+// no device, no allocation, no launch — and check its invariants.  For the sanitizer runs of the host code (tests/
+// test_sanitizers.py runs thousands of random level tables through it in a library built with -fsanitize=address,undefined)
+// and for tools that want to know what a call will launch.  options: "key=value,key=value" (pislam_ctx_set_option keys).
+// summary: [0] plan entries, [1] strips per pyramid, [2] runs per pyramid, [3] staging slots per pyramid, [4] run length,
+// [5] LDS bytes (plain layout), [6] LDS bytes (aliased layout), [7] units of the selection pass (0: none).
+PISLAM_EXPORT int pislam_debug_build_plan(const pislam_frontend_params *p, const pislam_level *lv, int batch, int num_cus,
+                                          int lanes_in_flight, const char *options, uint32_t summary[8], char *err, size_t err_cap) {
+  pislam_ctx c;                                       // (never touches a device: plain members only)
+  auto say = [&](int rc) {
+    if (err && err_cap) snprintf(err, err_cap, "%s", c.err.c_str());
+    return rc;
+  };
+  c.num_cus = num_cus > 0 ? num_cus : 256;
+  c.lanes_in_flight = lanes_in_flight > 0 ? lanes_in_flight : 1;
+  if (!summary) return PISLAM_ERR_INVALID;
+  memset(summary, 0, sizeof(uint32_t) * 8);
+  for (const char *q = options; q && *q;) {
+    const char *e = strchr(q, ','), *eq = strchr(q, '=');
+    const size_t len = e ? (size_t)(e - q) : strlen(q);
+    if (!eq || (size_t)(eq - q) >= len) {
+      c.err = "options: key=value[,key=value...]";
+      return say(PISLAM_ERR_INVALID);
+    }
+    const std::string key(q, eq - q);
+    if (key == "own_stream") {
+      c.err = "own_stream needs a device";
+      return say(PISLAM_ERR_INVALID);
+    }
+    const int rc = pislam_ctx_set_option(&c, key.c_str(), atoi(eq + 1));
+    if (rc != PISLAM_OK) return say(rc);
+    q += len + (e ? 1 : 0);
+  }
+  int rc = check_params(&c, p, lv, batch);
+  if (rc != PISLAM_OK) return say(rc);
+  pf::FusedParams F;
+  size_t lds = 0, lds_alias = 0;
+  const int nsub = choose_sub_batches(&c, p, batch);
+  if (c.opt_pipeline == 1 || !build_fused_plan(&c, p, lv, sub_max(batch, nsub), &F, &lds, &lds_alias)) {
+    c.err = "no strip plan for these parameters (the staged pipeline takes the call)";
+    return say(PISLAM_ERR_INVALID);
+  }
+  // ---- invariants the kernels rely on ----
+  auto bad = [&](const char *what) {
+    c.err = std::string("plan invariant violated: ") + what;
+    return say(PISLAM_ERR_HIP);
+  };
+  if (F.nlevels < 1 || F.nlevels > pf::MAX_LEVELS) return bad("entries");
+  int strips = 0, slots = 0, runs = 0;
+  for (int l = 0; l < F.nlevels; l++) {
+    const pf::FusedLevel &L = F.lv[l];
+    if (L.strip0 != strips || L.slot0 != slots || L.run0 != runs) return bad("prefix sums");
+    if (L.nstrips < 0 || (L.nstrips > 0 && (L.R < 2 || (L.R & 1)))) return bad("strip height");
+    if (L.nstrips > 0) {
+      if (L.col0 < 0 || L.row0 < 0 || L.col0 + L.w > p->vstep || L.row0 + L.h > p->rows) return bad("entry outside the pyramid");
+      if (L.tpitch % 16 || L.pitch % 16 || L.tpitch <= 0) return bad("pitch");
+      if ((L.R + 10) * L.tpitch > 150 * 1024) return bad("tile larger than the LDS");
+      if (L.gfirst < 0 || L.gfirst > l || L.gn < 1 || L.gfirst + L.gn > F.nlevels) return bad("tile group");
+      if (L.ex0 < p->border || L.ex1 > L.w || L.ex0 > L.ex1) return bad("owned columns");
+      if (cdiv(L.nstrips, F.run_len) != L.nruns) return bad("runs");
+      if ((uint64_t)L.vpr_recip * (uint64_t)(L.tpitch / 16) < (1ull << 32)) return bad("vpr_recip");
+      if ((uint64_t)L.tp_recip * (uint64_t)L.tpitch < (1ull << 32)) return bad("tp_recip");
+      if (L.qh < pf::QH_SHARED) return bad("corner queue");
+    }
+    strips += L.nstrips;
+    slots += L.nstrips * (L.R / 2) * L.nbx;
+    runs += L.nruns;
+  }
+  if (strips != F.strips_per_pyr || slots != F.slots_per_pyr || runs != F.runs_per_pyr) return bad("totals");
+  if (F.order_n) {
+    if (F.order_n != runs || runs > pf::MAX_ORDER) return bad("order size");
+    std::vector<int> seen((size_t)runs, 0);
+    for (int i = 0; i < F.order_n; i++) {
+      const int e = (int)(F.order[i] >> 16), r = (int)(F.order[i] & 0xffff);
+      if (e >= F.nlevels || r >= F.lv[e].nruns) return bad("order entry");
+      seen[(size_t)(F.lv[e].run0 + r)]++;
+    }
+    for (int v : seen)
+      if (v != 1) return bad("order is not a permutation of the runs");
+  }
+  if (lds_alias > 160 * 1024) return bad("aliased LDS size");
+  summary[0] = (uint32_t)F.nlevels;
+  summary[1] = (uint32_t)F.strips_per_pyr;
+  summary[2] = (uint32_t)F.runs_per_pyr;
+  summary[3] = (uint32_t)F.slots_per_pyr;
+  summary[4] = (uint32_t)F.run_len;
+  summary[5] = (uint32_t)lds;
+  summary[6] = (uint32_t)lds_alias;
+  if (p->log_bucket_size != 0 && F.lbs == 0 && strips > 0) {
+    pf::SelectPlan Q;
+    pf::FusedParams U;
+    rc = build_select_plan(&c, p, F, &Q, &U);
+    if (rc != PISLAM_OK) return say(rc);
+    int units = 0, uslots = 0;
+    for (int l = 0; l < Q.nlevels; l++) {
+      if (Q.unit0[l] != units || Q.uslot0[l] != uslots) return bad("selection plan prefix sums");
+      if (Q.g0[l] < 0 || Q.g0[l] + Q.gn[l] > F.nlevels) return bad("selection plan entries");
+      if (Q.cap[l] / p->bucket_limit > pf::SEL_NB) return bad("more buckets than the selection pass holds");
+      units += Q.nunits[l];
+      uslots += Q.nunits[l] * Q.cap[l];
+    }
+    if (units != Q.units_per_pyr || uslots != Q.uslots_per_pyr) return bad("selection plan totals");
+    summary[7] = (uint32_t)Q.units_per_pyr;
+  }
+  return PISLAM_OK;
+}
+
 PISLAM_EXPORT int pislam_frontend_reserve(pislam_ctx *c, const pislam_frontend_params *p,
                                           const pislam_level *lv, int batch) {
   PCHK(check_params(c, p, lv, batch));

@@ -4,7 +4,10 @@ reference's demo pyramid, on adversarial levels and on buffers that end EXACTLY 
 write outside the caller's pyramid, any signed overflow / misaligned access / out-of-range shift aborts the program.
 Its printed checksum must equal the un-instrumented liborc.so's results on the same input.
 
-(The product's host side under ASan: tools/asan_round.sh, run on the GPU box; its result is kept under profiles/.)"""
+The product's host side: tools/asan_round.sh builds libpislam_hip with its HOST code under ASan + UBSan (device code
+unchanged); here (no GPU) it runs the ABI error paths and thousands of random configurations through the host-only plan
+builder (pislam_debug_build_plan: strip plan, x-tiles, launch order, bucket selection plan).  On the GPU box the suites run
+against the UBSan-trap build (ROCm's ASan runtime cannot allocate device memory there): profiles/r05_ubsan_gpu.txt."""
 import os
 import subprocess
 
@@ -99,3 +102,24 @@ def test_image_preparation_restatements_under_asan_ubsan(asan_bin, tmp_path, orc
     ref = buf.copy()
     {"gaussian": orc.gaussian5x5, "b78": orc.bilinear7_8, "b1316": orc.bilinear13_16}[kind](ref, w, h)
     assert int(r.stdout.split("=")[1], 16) == fnv(ref)
+
+
+def test_product_host_code_under_asan_ubsan_plan_builder_and_abi_error_paths():
+    """libpislam_hip.so with its host code built -fsanitize=address,undefined (hipcc, device code unchanged), the ASan runtime
+    preloaded into a child interpreter: tests/test_abi.py's error paths and 6000 random level tables / option sets through
+    pislam_debug_build_plan — the code that sizes every workspace and LDS tile and fills the fixed-size plan tables
+    (FusedParams::lv[24], order[160], SelectPlan[16])."""
+    import glob
+    rts = glob.glob("/opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.so")
+    if not rts:
+        pytest.skip("no ASan runtime in this ROCm")
+    subprocess.check_call(["bash", os.path.join(ROOT, "tools", "asan_round.sh"), "build"], stdout=subprocess.DEVNULL)
+    env = dict(os.environ, LD_PRELOAD=rts[0], PISLAM_HIP_LIB=os.path.join(ROOT, "variants", "libpislam_hip_asan.so"),
+               ASAN_OPTIONS="detect_leaks=0:abort_on_error=0:halt_on_error=1", UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1")
+    r = subprocess.run([os.sys.executable, os.path.join(ROOT, "tests", "plan_fuzz.py"), "6000", "100000"], capture_output=True,
+                       text=True, env=env, timeout=1200, cwd=ROOT)
+    assert r.returncode == 0 and "0 violations" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
+    assert "libpislam_hip_asan.so" in r.stdout
+    r = subprocess.run([os.sys.executable, "-m", "pytest", "tests/test_abi.py", "-q", "-m", "not gpu", "-p", "no:cacheprovider"],
+                       capture_output=True, text=True, env=env, timeout=1200, cwd=ROOT)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
