@@ -62,6 +62,18 @@ z = np.load("$root/tests/golden/demo_pyramid.npz")
 z["img"].astype(np.uint8).tofile("/tmp/demo_pyramid.raw")
 P
 (cd $root && make -s -C tools pislam_demo > /dev/null 2>&1; for s in 3 1; do tools/pislam_demo /tmp/demo_pyramid.raw --batch 256 --steps 100 --streams $s; done) > $out/cpp_tool_demo_photo_x256.txt 2>&1
+# ... and a frame at a time (the reference's own use): one pyramid per call, one launch (pf::k_frame) vs three, 1 and 3 calls in flight
+(cd $root && for s in 1 3; do for f in 1 0; do echo "streams $s frame=$f: $(tools/pislam_demo /tmp/demo_pyramid.raw --batch 1 --steps 3000 --streams $s --opt frame=$f 2>&1 | head -1)"; done; done) > $out/cpp_tool_one_pyramid_per_call.txt 2>&1
+# kernel durations of one pyramid per call (one launch vs three)
+for f in 1 0; do
+  rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace_one_$f -o p -- python $root/bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-one-pyramid --parity-pyramids 0 --batch 1 --streams 1 --opt frame=$f > /dev/null 2>&1
+  python - <<P >> $out/one_pyramid_kernel_trace.txt
+import csv
+for r in list(csv.DictReader(open("$out/trace_one_$f/p_kernel_stats.csv")))[:4]:
+    if int(r["Calls"]) > 100: print("frame=$f", r["Name"].split("(")[0][-44:], "calls", r["Calls"], "avg ns", r["AverageNs"], "min", r["MinNs"], "max", r["MaxNs"])
+P
+  rm -rf $out/trace_one_$f
+done
 # per-phase instruction counts of the strip kernel (cumulative ablations of the profiling build)
 (cd $root && bash tools/pmc_ablate.sh --streams 1) > $out/phase_ablation.txt 2>&1
 (cd $root && bash tools/pmc_ablate.sh --streams 1 --log-bucket-size 4 --bucket-limit 3 --opt bucket_select=0) > $out/phase_ablation_buckets43_in_strip_selection.txt 2>&1
