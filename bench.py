@@ -922,45 +922,8 @@ def worker_main(args):
                 brackets.append((e0, e1))
         torch.cuda.synchronize()
         one_ms = min(a.elapsed_time(b) for a, b in brackets) / REPS
-        # ... and ONE pyramid per call on the same object (the reference's own use: a frame at a time)
-        if not args.no_one_pyramid and b1 is None and m_out is None:
-            try:
-                o_s = fe.alloc_outputs(1, dev)
-                d_one = d_pyr[:1]
-                brackets = []
-                with torch.cuda.stream(s1):
-                    for _ in range(4):
-                        pl1.submit(fe.params, fe.levels, d_one, *o_s)
-                    for _ in range(3):
-                        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                        e0.record(s1)
-                        for _ in range(200):
-                            pl1.submit(fe.params, fe.levels, d_one, *o_s)
-                        e1.record(s1)
-                        brackets.append((e0, e1))
-                torch.cuda.synchronize()
-                one_pyr_ms = min(a.elapsed_time(b) for a, b in brackets) / 200
-                if int(o_s[2].cpu()[0]) != int(o1[2].cpu()[0]):
-                    raise RuntimeError("a pyramid alone and as the first of its batch gave different keypoint counts")
-                # ... and the latency of ONE isolated call on an idle stream (events right around the submit, a synchronise
-                # between calls): 200 back-to-back submits above are paced by the host's ~30 us per pislam_pipeline_submit
-                # from Python, not by the GPU
-                lat = []
-                with torch.cuda.stream(s1):
-                    for _ in range(60):
-                        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                        e0.record(s1)
-                        pl1.submit(fe.params, fe.levels, d_one, *o_s)
-                        e1.record(s1)
-                        e1.synchronize()
-                        lat.append(e0.elapsed_time(e1))
-                one_pyr_lat_ms = float(np.median(lat[10:]))
-                one_pyr_path = "one launch (pf::k_frame)" if (fe.last_path_of(c1) & 4) else "three launches"
-            except Exception as e:                       # noqa: BLE001
-                one_pyr_ms = None
-                print(f"[bench] one-pyramid-per-call measurement failed: {e!r}", file=sys.stderr)
-        pl1.close()
     except Exception as e:                               # noqa: BLE001
+        pl1 = None
         print(f"[bench] one-call-at-a-time measurement failed: {e!r}", file=sys.stderr)
     lib_pipe = {"api": "pislam_pipeline_create / _submit / _wait (include/pislam_hip.h): the timed steps ARE submits to this object",
                 "depth": S, **pl.stats()}
@@ -1013,6 +976,49 @@ def worker_main(args):
                       "matched_within_64_bits": int(((m_out[1] <= 64) & (torch.arange(args.max_keypoints, device=dev)[None, :]
                                                                           < cq[:, None])).sum().item())}
 
+    # (LAST of the measurements: its small, synchronised calls leave the GPU mostly idle — the strip-kernel bracket above
+    #  would otherwise be taken on clocks that have dropped; round 5's first profile showed 0.173 ms there against
+    #  0.161 ms in the kernel trace of the same kernel)
+    if pl1 is not None:
+        # ... and ONE pyramid per call on the same object (the reference's own use: a frame at a time)
+        if not args.no_one_pyramid and b1 is None and m_out is None:
+            try:
+                o_s = fe.alloc_outputs(1, dev)
+                d_one = d_pyr[:1]
+                brackets = []
+                with torch.cuda.stream(s1):
+                    for _ in range(4):
+                        pl1.submit(fe.params, fe.levels, d_one, *o_s)
+                    for _ in range(3):
+                        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                        e0.record(s1)
+                        for _ in range(200):
+                            pl1.submit(fe.params, fe.levels, d_one, *o_s)
+                        e1.record(s1)
+                        brackets.append((e0, e1))
+                torch.cuda.synchronize()
+                one_pyr_ms = min(a.elapsed_time(b) for a, b in brackets) / 200
+                if int(o_s[2].cpu()[0]) != int(o1[2].cpu()[0]):
+                    raise RuntimeError("a pyramid alone and as the first of its batch gave different keypoint counts")
+                # ... and the latency of ONE isolated call on an idle stream (events right around the submit, a synchronise
+                # between calls): 200 back-to-back submits above are paced by the host's ~30 us per pislam_pipeline_submit
+                # from Python, not by the GPU
+                lat = []
+                with torch.cuda.stream(s1):
+                    for _ in range(60):
+                        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                        e0.record(s1)
+                        pl1.submit(fe.params, fe.levels, d_one, *o_s)
+                        e1.record(s1)
+                        e1.synchronize()
+                        lat.append(e0.elapsed_time(e1))
+                one_pyr_lat_ms = float(np.median(lat[10:]))
+                one_pyr_path = "one launch (pf::k_frame)" if (fe.last_path_of(c1) & 4) else "three launches"
+            except Exception as e:                       # noqa: BLE001
+                one_pyr_ms = None
+                print(f"[bench] one-pyramid-per-call measurement failed: {e!r}", file=sys.stderr)
+
+        pl1.close()
     deferred, nstrips = fe1.last_stats()
     # counts are the reference's un-clamped totals; keypoints beyond the capacity are neither stored nor
     # described, so only min(count, max_keypoints) per pyramid is credited

@@ -1691,6 +1691,7 @@ struct OrbShared {
 };
 __host__ __device__ constexpr size_t orb_lds_bytes(int strips_per_pyr, size_t per_max) {
   return sizeof(OrbShared) + (size_t)OWAVES * 2 * ORB_PATCH_BYTES + sizeof(uint32_t) * (((size_t)strips_per_pyr + 1 + 3) & ~(size_t)3) +
+         sizeof(uint32_t) * (((size_t)strips_per_pyr + 3) & ~(size_t)3) +   // where each strip's list starts in the staging buffer
          sizeof(uint32_t) * 2 * per_max;            // keypoints to describe here and their final positions
 }
 
@@ -1722,8 +1723,17 @@ __device__ __forceinline__ void orb_role(const FusedParams &P, const uint8_t *__
   // their final positions
   uint8_t *patches = osm;
   uint32_t *soff = (uint32_t *)(osm + OWAVES * 2 * ORB_PATCH_BYTES);
-  uint32_t *kpl = soff + ((S + 1 + 3) & ~3);
+  uint32_t *sslot = soff + ((S + 1 + 3) & ~3);
+  uint32_t *kpl = sslot + ((S + 3) & ~3);
   uint32_t *kpos = kpl + per_max;
+  // Per strip, once: the staging slot its list starts at (bit 31: its level is cut into x-tiles, the final position needs
+  // final_position).  The plan lives in the kernel arguments; indexed PER KEYPOINT it was a divergent loop over the entries
+  // plus two rounds of dependent per-lane global loads from the argument segment in front of every keypoint's own load —
+  // the longest latency chain of the workgroup's prologue.  Independent of the counts: runs under their loads.
+  for (int i = tid; i < S; i += 256) {
+    const PlanStrip ps = plan_strip(P, i);
+    sslot[i] = strip_slot_of(P, ps.li, ps.s) | (P.lv[ps.li].gn > 1 ? 0x80000000u : 0u);
+  }
 
   // ---- exclusive scan of the strip counts (storage order) ----
   const uint32_t *cnt = strip_count + (size_t)pyr * S;
@@ -1778,9 +1788,13 @@ __device__ __forceinline__ void orb_role(const FusedParams &P, const uint8_t *__
         if (soff[m] <= e) a = m; else b = m;
       }
       const uint32_t k = e - soff[a];
-      const PlanStrip ps = plan_strip(P, a);
-      const uint32_t v = stage[strip_slot_of(P, ps.li, ps.s) + k];
-      const uint32_t pos = final_position(P, soff, stage, ps.li, ps.s, k, v);
+      const uint32_t ss = sslot[a];
+      const uint32_t v = stage[(ss & 0x7fffffffu) + k];
+      uint32_t pos = e;                                // (whole-level entries: storage order IS the reference's order)
+      if (ss >> 31) {
+        const PlanStrip ps = plan_strip(P, a);
+        pos = final_position(P, soff, stage, ps.li, ps.s, k, v);
+      }
       if (pos >= cap) continue;                        // beyond the caller's capacity: counted, not stored
       kp[(size_t)pyr * kp_stride + pos] = v;
       if (cnt[a] & STRIP_DESCRIBED) {
