@@ -1510,13 +1510,22 @@ struct SelectPlan {
   int nb_max;                         // most buckets of any level (the dense path's LDS counters: 2 x nb_max dwords per wave)
 };
 // (k_bucket_select takes FusedParams + SelectPlan + four pointers by value: the kernel-argument segment holds 4 KiB)
-static_assert(sizeof(FusedParams) + sizeof(SelectPlan) + 4 * sizeof(void *) <= 4096, "k_bucket_select's arguments exceed the 4 KiB kernarg segment");
+static_assert(sizeof(FusedParams) + sizeof(SelectPlan) + 5 * sizeof(void *) <= 4096, "k_bucket_select's arguments exceed the 4 KiB kernarg segment");
 constexpr int SEL_WAVES = 4;
 constexpr int SEL_NB = 1024;                         // buckets per cell row the dense path's LDS counters hold (the host checks)
+// The unit table (host-built, one record of SEL_REC dwords per unit = (level, cell row)): everything the fast path needs to
+// know about a unit arrives with ONE scalar load — until round 5 a wave found its level by a loop of dependent scalar
+// loads over the plan, and the strips overlapping its rows by two software divisions per x-tile with more plan loads
+// in between: the kernel is a single round of resident waves, its duration IS that chain.
+//   [0] lists overlapping the unit (0xffffffff: more than SEL_ML: the generic path), [1] level, [2] cell row,
+//   [3] first output slot (uslot0 + cell row * cap), [4] row0 + B, [5] col0 + B (stacked coordinates of the level's first
+//   block origin), [8 ..] staging slot of list j, [16 ..] strip-count index of list j.
+constexpr int SEL_REC = 24, SEL_ML = 6;
 __global__ __launch_bounds__(64 * SEL_WAVES) void k_bucket_select(const FusedParams F, const SelectPlan Q,
                                                                    const uint32_t *__restrict__ stage_kp,
                                                                    const uint32_t *__restrict__ strip_count,
-                                                                   uint32_t *__restrict__ ustage, uint32_t *__restrict__ ucount) {
+                                                                   uint32_t *__restrict__ ustage, uint32_t *__restrict__ ucount,
+                                                                   const uint32_t *__restrict__ utab) {
   // dynamic LDS, per wave: [64 survivors of the fast path][nb_max per-bucket counts][nb_max kept entries before the bucket]
   // (sized by the host from the level table: static arrays for the worst case cost the kernel its occupancy — it is a
   //  chain of dependent loads per wave, its duration is the number of rounds of resident waves)
@@ -1526,16 +1535,16 @@ __global__ __launch_bounds__(64 * SEL_WAVES) void k_bucket_select(const FusedPar
   uint32_t *bcnt = sbuf + 64, *bpre = bcnt + Q.nb_max;
   const int pyr = blockIdx.y, u = (int)blockIdx.x * SEL_WAVES + wv;
   if (u >= Q.units_per_pyr) return;
-  int l = 0;
-  while (l + 1 < Q.nlevels && u >= Q.unit0[l + 1]) l++;
-  const int cr = u - Q.unit0[l], lbs = Q.lbs, limit = Q.limit, B = Q.border;
+  const uint32_t *rec = utab + (size_t)u * SEL_REC;            // (wave-uniform address: scalar loads)
+  const int nl_rec = (int)rec[0], l = (int)rec[1], cr = (int)rec[2];
+  const int lbs = Q.lbs, limit = Q.limit, B = Q.border;
   const int y0 = B + (cr << lbs), y1 = min(y0 + (1 << lbs), Q.h[l] - B);        // level-relative rows of the unit
-  const int yrow0 = Q.row0[l], xcol0 = Q.col0[l] + B;
+  const int yrow0 = (int)rec[4] - B, xcol0 = (int)rec[5];
   const uint32_t *stage = stage_kp + (size_t)pyr * F.slots_per_pyr;
   const uint32_t *cnt = strip_count + (size_t)pyr * F.strips_per_pyr;
-  uint32_t *out = ustage + (size_t)pyr * Q.uslots_per_pyr + Q.uslot0[l] + (size_t)cr * Q.cap[l];
+  uint32_t *out = ustage + (size_t)pyr * Q.uslots_per_pyr + rec[3];
   // every chunk of 64 staged entries of the strips that overlap the unit's rows: f(v, in) with in = the lane holds a
-  // survivor of this unit
+  // survivor of this unit   (generic path: dense units, more than SEL_ML lists)
   auto for_each_chunk = [&](auto f) {
     for (int t = 0; t < Q.gn[l]; t++) {
       const int e = Q.g0[l] + t, R = F.lv[e].R;
@@ -1563,36 +1572,26 @@ __global__ __launch_bounds__(64 * SEL_WAVES) void k_bucket_select(const FusedPar
     }
     n_unit += __popcll(m);
   };
-  // The lists that overlap the unit (one to three strips of one to three tiles): lane j notes list j's place, the counts
-  // come in with ONE load, and the first 64 entries of every list are requested before any of them is looked at (a
-  // strip's slots exist whatever its count — the staging buffer carries 64 dwords of slack past its last strip): two
-  // memory round trips per unit instead of one or two per list.
-  constexpr int ML = 6;
-  uint32_t loff = 0, lcidx = 0;
-  int nl = 0;
-  for (int t = 0; t < Q.gn[l]; t++) {
-    const int e = Q.g0[l] + t, R = F.lv[e].R;
-    const int s_lo = (y0 - B) / R, s_hi = min((y1 - 1 - B) / R, F.lv[e].nstrips - 1);
-    for (int sidx = s_lo; sidx <= s_hi; sidx++) {
-      if (lane == nl) {
-        loff = (uint32_t)(F.lv[e].slot0 + sidx * (R >> 1) * F.lv[e].nbx);
-        lcidx = (uint32_t)(F.lv[e].strip0 + sidx);
-      }
-      nl++;
-    }
-  }
-  if (nl <= ML) {
-    const uint32_t mycnt = lane < nl ? (cnt[lcidx] & ~STRIP_DESCRIBED) : 0u;
-    uint32_t vj[ML];
-#pragma unroll
-    for (int j = 0; j < ML; j++)
-      if (j < nl) vj[j] = stage[(uint32_t)__builtin_amdgcn_readlane((int)loff, j) + (uint32_t)lane];
+  // The lists that overlap the unit (one to three strips of one to three tiles) come from the record; their counts (scalar
+  // loads) and the first 64 entries of every list are requested together, before any of them is looked at (a strip's
+  // slots exist whatever its count — the staging buffer carries 64 dwords of slack past its last strip): one memory
+  // round trip behind the record's.
+  constexpr int ML = SEL_ML;
+  if (nl_rec >= 0 && nl_rec <= ML) {
+    const int nl = nl_rec;
+    uint32_t vj[ML], nj[ML];
 #pragma unroll
     for (int j = 0; j < ML; j++)
       if (j < nl) {
-        const uint32_t n = (uint32_t)__builtin_amdgcn_readlane((int)mycnt, j);
+        nj[j] = cnt[rec[16 + j]] & ~STRIP_DESCRIBED;
+        vj[j] = stage[rec[8 + j] + (uint32_t)lane];
+      }
+#pragma unroll
+    for (int j = 0; j < ML; j++)
+      if (j < nl) {
+        const uint32_t n = nj[j];
         collect(vj[j], (uint32_t)lane < n && (int)((uint32_t)(decode_y(vj[j]) - yrow0 - B) >> lbs) == cr);
-        const uint32_t *list = stage + (uint32_t)__builtin_amdgcn_readlane((int)loff, j);
+        const uint32_t *list = stage + rec[8 + j];
         for (uint32_t q0 = 64; q0 < n; q0 += 64) {                               // (a list of more than 64 entries: dense input)
           const uint32_t q = q0 + (uint32_t)lane;
           const uint32_t v = q < n ? list[q] : 0u;

@@ -106,6 +106,8 @@ struct pislam_ctx {
   // batch pipeline workspace
   DevBuf w_score, w_stage, w_stripcnt, w_work, w_prof, w_ovf, w_stagedesc;
   DevBuf w_ustage, w_ucount;         // bucket selection pass (pf::k_bucket_select): per-unit lists and counts
+  DevBuf w_utab;                     // bucket selection pass: the unit table (pf::SEL_REC dwords per unit), rebuilt when the plan changes
+  std::vector<uint32_t> h_utab;      // its host image (kept: the upload is asynchronous)
   DevBuf w_sync;                     // one-launch path (pf::k_frame): per-pyramid hand-over counters, zero between launches
   int num_cus = 0;
   int opt_pipeline = 0;      // 0 auto, 1 staged (one launch group per level), 2 fused strips
@@ -157,7 +159,7 @@ struct pislam_ctx {
   unsigned long long workspace_generation() const {
     unsigned long long g = ovf_layouts;
     for (const DevBuf *b : {&w_cnt, &w_off, &w_total, &w_cellkp, &w_score, &w_stage, &w_stripcnt, &w_work, &w_prof,
-                            &w_ovf, &w_stagedesc, &w_ustage, &w_ucount, &w_sync})
+                            &w_ovf, &w_stagedesc, &w_ustage, &w_ucount, &w_sync, &w_utab})
       g += b->reallocs;
     return g;
   }
@@ -430,7 +432,7 @@ PISLAM_EXPORT int pislam_ctx_destroy(pislam_ctx *c) {
   (void)hipStreamSynchronize(c->stream);
   for (DevBuf *b : {&c->s_img, &c->s_out, &c->s_pts, &c->s_desc, &c->s_misc, &c->s_rots, &c->s_tmp, &c->w_cnt,
                     &c->w_off, &c->w_total, &c->w_cellkp, &c->w_score, &c->w_stage, &c->w_stripcnt, &c->w_work, &c->w_prof, &c->w_ovf,
-                    &c->w_stagedesc, &c->w_ustage, &c->w_ucount, &c->w_sync})
+                    &c->w_stagedesc, &c->w_ustage, &c->w_ucount, &c->w_sync, &c->w_utab})
     b->release();
   for (auto &e : c->ev)
     if (e) (void)hipEventDestroy(e);
@@ -1395,6 +1397,45 @@ int build_select_plan(pislam_ctx *c, const pislam_frontend_params *p, const pf::
   return PISLAM_OK;
 }
 
+// The unit table of the bucket selection pass (pf::k_bucket_select reads one record per unit instead of walking the plan):
+// built on the host from the strip plan and the selection plan, uploaded when it differs from what the context holds.
+int ensure_unit_table(pislam_ctx *c, const pislam_frontend_params *p, const pf::FusedParams &F, const pf::SelectPlan &Q) {
+  std::vector<uint32_t> t((size_t)Q.units_per_pyr * pf::SEL_REC, 0u);
+  const int B = p->border, lbs = p->log_bucket_size, bs = 1 << lbs;
+  for (int l = 0; l < Q.nlevels; l++)
+    for (int cr = 0; cr < Q.nunits[l]; cr++) {
+      uint32_t *r = &t[(size_t)(Q.unit0[l] + cr) * pf::SEL_REC];
+      const int y0 = B + (cr << lbs), y1 = std::min(y0 + bs, Q.h[l] - B);
+      int nl = 0;
+      for (int k = 0; k < Q.gn[l]; k++) {
+        const pf::FusedLevel &E = F.lv[Q.g0[l] + k];
+        const int s_lo = (y0 - B) / E.R, s_hi = std::min((y1 - 1 - B) / E.R, E.nstrips - 1);
+        for (int sidx = s_lo; sidx <= s_hi; sidx++, nl++)
+          if (nl < pf::SEL_ML) {
+            r[8 + nl] = (uint32_t)(E.slot0 + sidx * (E.R >> 1) * E.nbx);
+            r[16 + nl] = (uint32_t)(E.strip0 + sidx);
+          }
+      }
+      r[0] = nl <= pf::SEL_ML ? (uint32_t)nl : 0xffffffffu;
+      r[1] = (uint32_t)l;
+      r[2] = (uint32_t)cr;
+      r[3] = (uint32_t)(Q.uslot0[l] + cr * Q.cap[l]);
+      r[4] = (uint32_t)(Q.row0[l] + B);
+      r[5] = (uint32_t)(Q.col0[l] + B);
+    }
+  bool grew = false;
+  if (c->w_utab.ensure(sizeof(uint32_t) * std::max<size_t>(t.size(), 1), &grew) != PISLAM_OK)
+    return fail(c, PISLAM_ERR_NOMEM, "hipMalloc(unit table)");
+  if (grew || t != c->h_utab) {
+    // (in stream order before the launch that reads it; a previous launch that still reads the old table is ahead of the
+    //  copy on the same stream.  Never inside a capture: the first occurrence of a call runs eagerly, and reserve builds it)
+    c->h_utab.swap(t);
+    if (!c->h_utab.empty())
+      HIPCHK(c, hipMemcpyAsync(c->w_utab.p, c->h_utab.data(), sizeof(uint32_t) * c->h_utab.size(), hipMemcpyHostToDevice, c->stream));
+  }
+  return PISLAM_OK;
+}
+
 // The one-launch path (pf::k_frame) takes batches of up to FRAME_MAX_BATCH pyramids: three launch floors are most of such
 // a call (one VGA pyramid: 31 us in three launches, 15 us of it work), and its gather + ORB workgroups — which wait inside
 // the grid for their pyramid's strips — stay a small fraction of an XCD's resident slots even with several such launches
@@ -1428,6 +1469,7 @@ int run_fused(pislam_ctx *c, const pislam_frontend_params *p, const pf::FusedPar
     if (c->w_ustage.ensure(sizeof(uint32_t) * (size_t)Q.uslots_per_pyr * batch) != PISLAM_OK ||
         c->w_ucount.ensure(sizeof(uint32_t) * (size_t)Q.units_per_pyr * batch) != PISLAM_OK)
       return fail(c, PISLAM_ERR_NOMEM, "hipMalloc(bucket selection staging)");
+    PCHK(ensure_unit_table(c, p, Fplan, Q));
   }
   c->last_path = PISLAM_PATH_FUSED | (sel ? PISLAM_PATH_BUCKET_SELECT : 0u) | (Fplan.lbs != 0 ? PISLAM_PATH_BUCKETS_IN_STRIPS : 0u);
   const int Sg = sel ? Q.units_per_pyr : S;            // "strips" of the plan the gather runs on
@@ -1627,7 +1669,7 @@ int run_fused(pislam_ctx *c, const pislam_frontend_params *p, const pf::FusedPar
       uint32_t *u_cnt = c->w_ucount.as<uint32_t>() + (size_t)first * Q.units_per_pyr;
       const size_t sel_lds = sizeof(uint32_t) * pf::SEL_WAVES * (64 + 2 * (size_t)Q.nb_max);
       hipLaunchKernelGGL(pf::k_bucket_select, dim3(cdiv(Q.units_per_pyr, pf::SEL_WAVES), n), dim3(64 * pf::SEL_WAVES), sel_lds, X, F, Q,
-                         (const uint32_t *)s_stage, (const uint32_t *)s_cnt, u_stage, u_cnt);
+                         (const uint32_t *)s_stage, (const uint32_t *)s_cnt, u_stage, u_cnt, (const uint32_t *)c->w_utab.as<uint32_t>());
       PCHK(launch_ok(c, "k_bucket_select"));
       G = U;
       G.batch = n;
@@ -1824,6 +1866,7 @@ PISLAM_EXPORT int pislam_frontend_reserve(pislam_ctx *c, const pislam_frontend_p
         if (c->w_ustage.ensure(sizeof(uint32_t) * (size_t)Q.uslots_per_pyr * batch) != PISLAM_OK ||
             c->w_ucount.ensure(sizeof(uint32_t) * (size_t)Q.units_per_pyr * batch) != PISLAM_OK)
           return fail(c, PISLAM_ERR_NOMEM, "hipMalloc(bucket selection staging)");
+        PCHK(ensure_unit_table(c, p, F, Q));
       }
     }
   }
@@ -2086,6 +2129,9 @@ struct LaneCall {
   bool failed = false;                 // capture / instantiation failed: stay eager
   unsigned long long ws_gen = 0;       // the lane context's workspace_generation() the graph was captured against
   bool recapture = false;              // the graph was dropped because the workspace moved: next occurrence eager, then capture
+  int invalidations = 0;               // times that happened: calls that keep re-laying the lane's workspace (two repeating calls
+                                       // whose overflow-list layouts differ) stop being captured after 3 — each invalidation costs a
+                                       // stream drain, an eager run and a recapture, more than the graph ever returns
   unsigned long long last_use = 0;
   bool same(const pislam_frontend_params *q, const pislam_level *l, const uint8_t *py, size_t st, int b, uint32_t *k,
             uint32_t *d, uint32_t *c) const {
@@ -2242,6 +2288,7 @@ PISLAM_EXPORT int pislam_pipeline_submit(pislam_pipeline *q, const pislam_fronte
       destroy_exec(c, *hit);
       hit->recapture = true;
       q->n_invalidated++;
+      if (++hit->invalidations >= 3) hit->failed = true;   // (stays eager from now on)
     }
     if (hit && hit->recapture) {
       hit->recapture = false;
