@@ -201,3 +201,40 @@ def test_compiler_resources_of_the_two_measured_kernels(tmp_path):
     gather = rows["pf::k_gather_orb"]
     assert 73 <= int(gather["VGPRs"]) <= 80 and int(gather["ScratchSize [bytes/lane]"]) == 0, gather
     assert int(gather["VGPRs Spill"]) == 0 and int(gather["SGPRs Spill"]) == 0, gather
+
+
+def test_debug_build_plan_reports_the_strip_plan_without_a_device():
+    """pislam_debug_build_plan (host only: no device, no allocation): the plan of BASELINE configs[1] (59 strips per VGA pyramid
+    at batch 256, 2 strips per run for a single context and 4 for a lane of a depth-3 pipeline; 76 shorter strips and single-
+    strip runs for one pyramid), the bucket selection pass's units, and the refusals (12-bit coordinates, staged pipeline)."""
+    import ctypes
+    from pislam_amd import capi, synth
+    lib = capi.load(rebuild_if_stale=False)
+    levels = synth.level_table()
+    L = (capi.Level * 8)(*[capi.Level(w, h, r0, 0) for w, h, r0 in levels])
+
+    def plan(batch, lanes=1, opts=b"", lbs=0, rows=2210):
+        P = capi.FrontendParams(640, rows, 8, 16, 20, 1 << 15, lbs, 3, 8, 4096)
+        out = (ctypes.c_uint32 * 8)()
+        err = ctypes.create_string_buffer(200)
+        rc = lib.pislam_debug_build_plan(ctypes.byref(P), L, batch, 256, lanes, opts, ctypes.byref(out), err, 200)
+        return rc, list(out), err.value.decode()
+
+    rc, s, _ = plan(256)
+    assert rc == 0 and s[0] == 8 and s[1] == 59 and s[4] == 2 and s[6] <= 160 * 1024 // 5, s
+    rc, s3, _ = plan(256, lanes=3)
+    assert rc == 0 and s3[1] == 59 and s3[4] == 4 and s3[2] < s[2], (s, s3)        # longer runs, fewer workgroups
+    rc, s1, _ = plan(1)
+    assert rc == 0 and s1[1] == 76 and s1[4] == 1 and s1[2] == 76, s1
+    rc, sb, _ = plan(256, lbs=4)
+    assert rc == 0 and sb[1] == 59 and sb[7] == sum((h - 32 + 15) // 16 for _, h, _ in levels), sb   # one unit per 16-row cell row
+    rc, _, msg = plan(256, opts=b"pipeline=1")
+    assert rc == -1 and "staged" in msg
+    rc, _, msg = plan(256, rows=5000)
+    assert rc == 0 or "12 bits" in msg                                              # rows alone do not break the 12-bit rule
+    Lbad = (capi.Level * 8)(*[capi.Level(w, h, r0 + 3000, 0) for w, h, r0 in levels])
+    P = capi.FrontendParams(640, 6000, 8, 16, 20, 1 << 15, 0, 5, 8, 4096)
+    out = (ctypes.c_uint32 * 8)()
+    err = ctypes.create_string_buffer(200)
+    assert lib.pislam_debug_build_plan(ctypes.byref(P), Lbad, 4, 256, 1, b"", ctypes.byref(out), err, 200) == -1
+    assert b"12 bits" in err.value
