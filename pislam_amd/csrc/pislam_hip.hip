@@ -106,8 +106,16 @@ struct pislam_ctx {
   // batch pipeline workspace
   DevBuf w_score, w_stage, w_stripcnt, w_work, w_prof, w_ovf, w_stagedesc;
   DevBuf w_ustage, w_ucount;         // bucket selection pass (pf::k_bucket_select): per-unit lists and counts
-  DevBuf w_utab;                     // bucket selection pass: the unit table (pf::SEL_REC dwords per unit), rebuilt when the plan changes
-  std::vector<uint32_t> h_utab;      // its host image (kept: the upload is asynchronous)
+  // Host-built plan tables the kernels read instead of walking the plan (the bucket selection pass's unit table): one
+  // device buffer per distinct CONTENT, never rewritten in place — a captured graph keeps reading the table
+  // of the plan it was captured with whatever other shapes the context serves in between.  At most 16 are kept (the oldest
+  // is freed, and graphs of the library's pipeline are invalidated through workspace_generation()).
+  struct PlanTable {
+    std::vector<uint32_t> host;      // (kept: the upload is asynchronous)
+    DevBuf dev;
+  };
+  std::vector<PlanTable *> plan_tables;
+  const uint32_t *cur_utab = nullptr;   // the table of the call being issued
   DevBuf w_sync;                     // one-launch path (pf::k_frame): per-pyramid hand-over counters, zero between launches
   int num_cus = 0;
   int opt_pipeline = 0;      // 0 auto, 1 staged (one launch group per level), 2 fused strips
@@ -153,13 +161,14 @@ struct pislam_ctx {
   int ovf_nsub = 0;                    // layout of w_ovf the last call / reserve established: lists, dwords per list
   size_t ovf_stride = 0;
   unsigned long long ovf_layouts = 0;  // times that layout changed (a replayed graph would read another layout's headers)
+  unsigned long long table_uploads = 0;   // plan tables evicted (a graph captured with one of them holds a dangling address)
   // Everything a captured batch call bakes into its kernel arguments besides the caller's own pointers: the
   // addresses of the workspace buffers and the overflow-list layout.  pislam_pipeline_submit replays a hipGraph
   // only while this number is what it was at capture time.
   unsigned long long workspace_generation() const {
-    unsigned long long g = ovf_layouts;
+    unsigned long long g = ovf_layouts + table_uploads;
     for (const DevBuf *b : {&w_cnt, &w_off, &w_total, &w_cellkp, &w_score, &w_stage, &w_stripcnt, &w_work, &w_prof,
-                            &w_ovf, &w_stagedesc, &w_ustage, &w_ucount, &w_sync, &w_utab})
+                            &w_ovf, &w_stagedesc, &w_ustage, &w_ucount, &w_sync})
       g += b->reallocs;
     return g;
   }
@@ -432,8 +441,13 @@ PISLAM_EXPORT int pislam_ctx_destroy(pislam_ctx *c) {
   (void)hipStreamSynchronize(c->stream);
   for (DevBuf *b : {&c->s_img, &c->s_out, &c->s_pts, &c->s_desc, &c->s_misc, &c->s_rots, &c->s_tmp, &c->w_cnt,
                     &c->w_off, &c->w_total, &c->w_cellkp, &c->w_score, &c->w_stage, &c->w_stripcnt, &c->w_work, &c->w_prof, &c->w_ovf,
-                    &c->w_stagedesc, &c->w_ustage, &c->w_ucount, &c->w_sync, &c->w_utab})
+                    &c->w_stagedesc, &c->w_ustage, &c->w_ucount, &c->w_sync})
     b->release();
+  for (auto *t : c->plan_tables) {
+    t->dev.release();
+    delete t;
+  }
+  c->plan_tables.clear();
   for (auto &e : c->ev)
     if (e) (void)hipEventDestroy(e);
   if (c->aux_stream) {
@@ -1397,8 +1411,37 @@ int build_select_plan(pislam_ctx *c, const pislam_frontend_params *p, const pf::
   return PISLAM_OK;
 }
 
+// The device copy of a host-built plan table: found by content, or created (hipMalloc + upload in stream order — never
+// inside a capture: the first occurrence of a call runs eagerly, and pislam_frontend_reserve builds the tables).
+int plan_table(pislam_ctx *c, std::vector<uint32_t> &&t, const uint32_t **out) {
+  if (t.empty()) t.push_back(0u);
+  for (size_t i = 0; i < c->plan_tables.size(); i++)
+    if (c->plan_tables[i]->host == t) {
+      if (i + 1 != c->plan_tables.size()) std::swap(c->plan_tables[i], c->plan_tables.back());   // (most recently used last)
+      *out = c->plan_tables.back()->dev.as<uint32_t>();
+      return PISLAM_OK;
+    }
+  if (c->plan_tables.size() >= 16) {                  // evict the least recently used
+    HIPCHK(c, hipStreamSynchronize(c->stream));       // (a launch in flight may still read it)
+    c->plan_tables.front()->dev.release();
+    delete c->plan_tables.front();
+    c->plan_tables.erase(c->plan_tables.begin());
+    c->table_uploads++;
+  }
+  pislam_ctx::PlanTable *pt = new pislam_ctx::PlanTable();
+  pt->host = std::move(t);
+  if (pt->dev.ensure(sizeof(uint32_t) * pt->host.size()) != PISLAM_OK) {
+    delete pt;
+    return fail(c, PISLAM_ERR_NOMEM, "hipMalloc(plan table)");
+  }
+  c->plan_tables.push_back(pt);
+  HIPCHK(c, hipMemcpyAsync(pt->dev.p, pt->host.data(), sizeof(uint32_t) * pt->host.size(), hipMemcpyHostToDevice, c->stream));
+  *out = pt->dev.as<uint32_t>();
+  return PISLAM_OK;
+}
+
 // The unit table of the bucket selection pass (pf::k_bucket_select reads one record per unit instead of walking the plan):
-// built on the host from the strip plan and the selection plan, uploaded when it differs from what the context holds.
+// built on the host from the strip plan and the selection plan; its device copy comes from plan_table().
 int ensure_unit_table(pislam_ctx *c, const pislam_frontend_params *p, const pf::FusedParams &F, const pf::SelectPlan &Q) {
   std::vector<uint32_t> t((size_t)Q.units_per_pyr * pf::SEL_REC, 0u);
   const int B = p->border, lbs = p->log_bucket_size, bs = 1 << lbs;
@@ -1423,17 +1466,7 @@ int ensure_unit_table(pislam_ctx *c, const pislam_frontend_params *p, const pf::
       r[4] = (uint32_t)(Q.row0[l] + B);
       r[5] = (uint32_t)(Q.col0[l] + B);
     }
-  bool grew = false;
-  if (c->w_utab.ensure(sizeof(uint32_t) * std::max<size_t>(t.size(), 1), &grew) != PISLAM_OK)
-    return fail(c, PISLAM_ERR_NOMEM, "hipMalloc(unit table)");
-  if (grew || t != c->h_utab) {
-    // (in stream order before the launch that reads it; a previous launch that still reads the old table is ahead of the
-    //  copy on the same stream.  Never inside a capture: the first occurrence of a call runs eagerly, and reserve builds it)
-    c->h_utab.swap(t);
-    if (!c->h_utab.empty())
-      HIPCHK(c, hipMemcpyAsync(c->w_utab.p, c->h_utab.data(), sizeof(uint32_t) * c->h_utab.size(), hipMemcpyHostToDevice, c->stream));
-  }
-  return PISLAM_OK;
+  return plan_table(c, std::move(t), &c->cur_utab);
 }
 
 // The one-launch path (pf::k_frame) takes batches of up to FRAME_MAX_BATCH pyramids: three launch floors are most of such
@@ -1669,7 +1702,7 @@ int run_fused(pislam_ctx *c, const pislam_frontend_params *p, const pf::FusedPar
       uint32_t *u_cnt = c->w_ucount.as<uint32_t>() + (size_t)first * Q.units_per_pyr;
       const size_t sel_lds = sizeof(uint32_t) * pf::SEL_WAVES * (64 + 2 * (size_t)Q.nb_max);
       hipLaunchKernelGGL(pf::k_bucket_select, dim3(cdiv(Q.units_per_pyr, pf::SEL_WAVES), n), dim3(64 * pf::SEL_WAVES), sel_lds, X, F, Q,
-                         (const uint32_t *)s_stage, (const uint32_t *)s_cnt, u_stage, u_cnt, (const uint32_t *)c->w_utab.as<uint32_t>());
+                         (const uint32_t *)s_stage, (const uint32_t *)s_cnt, u_stage, u_cnt, c->cur_utab);
       PCHK(launch_ok(c, "k_bucket_select"));
       G = U;
       G.batch = n;

@@ -1184,6 +1184,47 @@ def test_pipeline_replays_repeated_calls_from_graphs_and_says_so(orc):
 
 
 
+def test_bucket_mode_graphs_of_two_shapes_on_one_lane_keep_their_own_unit_tables(orc):
+    """The bucket selection pass reads a host-built unit table (one record per unit).  Two calls of different shapes that repeat
+    alternately on ONE lane are both replayed from their graphs: each graph must keep reading the table of ITS plan — the
+    tables are device buffers per distinct content, never rewritten in place (a single rewritten table made the first
+    shape's replay read the second shape's records)."""
+    import torch
+    from pislam_amd import capi, synth
+    from pislam_amd.frontend import OrbFrontend
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    dev = torch.device("cuda:0")
+    shapes = []
+    for (w0, h0, nl, B, seed) in ((640, 480, 8, 3, 4300), (320, 240, 4, 2, 4400)):
+        levels = synth.level_table(w0, h0, nl)
+        rows = synth.pyramid_rows(levels)
+        host = synth.make_batch(seed, B, w0=w0, h0=h0, nlevels=nl, levels=levels, nshapes=40)
+        fe = OrbFrontend(levels, vstep=w0, rows=rows, max_keypoints=2048, log_bucket_size=4, bucket_limit=3)
+        want = [orc.pyramid(host[b], levels, log_bucket=4, bucket_limit=3) for b in range(B)]
+        shapes.append((fe, torch.from_numpy(host).to(dev), fe.alloc_outputs(B, dev), want, B))
+    pipe = capi.Pipeline(device=0, depth=1)
+    pipe.set_option("frame", 0)                             # (small batches: keep them on the path with the selection pass)
+    for fe, d_in, out, want, B in shapes:
+        pipe.reserve(fe.params, fe.levels, B)
+    order = [0, 0, 1, 1, 0, 1, 0, 1, 1, 0]                    # eager, captured, eager, captured, then replays in both orders
+    for k, i in enumerate(order):
+        fe, d_in, out, want, B = shapes[i]
+        for t in out:
+            t.zero_()
+        pipe.submit(fe.params, fe.levels, d_in, *out, input_stream=torch.cuda.current_stream().cuda_stream)
+        pipe.synchronize()
+        assert OrbFrontend.PATH_BUCKET_SELECT & fe.last_path_of(pipe.lane(0))
+        c = out[2].cpu().numpy().view(np.uint32)
+        kk, dd = out[0].cpu().numpy().view(np.uint32), out[1].cpu().numpy().view(np.uint32)
+        for b in range(B):
+            okp, odesc, _ = want[b]
+            assert c[b] == len(okp) and (kk[b, :len(okp)] == okp).all() and (dd[b, :len(okp)] == odesc).all(), (k, i, b)
+    st = pipe.stats()
+    assert st["captured"] == 2 and st["capture_failed"] == 0 and st["replayed_from_graphs"] == len(order) - 2, st   # (a shape's first call is eager; its second is captured AND launched from the graph)
+    pipe.close()
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("sub_batches", [1, 2])
 def test_pipeline_graph_survives_a_workspace_that_moved(orc, sub_batches):
