@@ -72,6 +72,9 @@ int pislam_ctx_set_stream(pislam_ctx *ctx, void *hip_stream);
  *                pass between strip kernel and gather keeps each bucket's bucket_limit largest keypoints (log_bucket_size 1..8);
  *                0 the selection happens inside the strips (strips cut on bucket rows; log_bucket_size 2..5, others take the
  *                staged pipeline)
+ *   "frame"      small batches run as ONE launch (strip workgroups, then the gather + ORB workgroups of the same grid behind an
+ *                agent-scope hand-over; overflowed strips redone in place): 1 (default) batches of 1 or 2 pyramids, n = 2..8
+ *                batches of up to n, 0 never (always strip kernel -> overflow pass -> gather + ORB); not with buckets
  *   "wgs_per_cu", "strip_px", "strip_rows_max", "lds_pad", "bucket_round_up", "repeat_strips", "ablate"  profiling only (ablate != 0 gives INVALID results by design)
  *   "match_mfma" 1 (default) pislam_match_hamming* run on the int8 matrix cores, 0 the VALU popcount kernel (same results)
  *   "dist_rccl_single" test hook: pislam_dist_init(world = 1) still creates a 1-rank RCCL communicator */
