@@ -33,7 +33,7 @@ HBM_PEAK_GBPS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 
 VALU_CYCLES_PER_WAVE_INST = 4.0 # what roofline.valu.issue_frac assumes (see its note)
 VALU_SUSTAINED_PER_S = 533e9    # tools/probes/valu_rate.hip on MI355X: 528-538 G wave64 integer instructions/s chip-wide
 METRIC = "ORB keypoints+descriptors/sec, 640x480 8-level pyramid"
-PROFILE_TAG = "r05"             # profiles/<tag>_counters_<workload>.json holds the PMC passes bench lines quote
+PROFILE_TAG = "r06"             # profiles/<tag>_counters_<workload>.json holds the PMC passes bench lines quote
 
 
 # ---------------------------------------------------------------------------------------------------------
@@ -158,6 +158,56 @@ def parity_in_run(snap, kept, lane_hosts, levels, max_kp, log_bucket, bucket_lim
 
 
 # ---------------------------------------------------------------------------------------------------------
+# other_workloads: every other BASELINE configuration, briefly, inside the driver's one line
+# ---------------------------------------------------------------------------------------------------------
+OTHER_WORKLOADS = [
+    # name, bench.py arguments (besides the common ones)
+    ("demo-photo", ["--workload", "demo-photo"]),                                  # natural content: the reference's own input
+    ("1280x960", ["--workload", "1280x960", "--batch", "256", "--distinct", "16"]),  # configs[3] on spec (~2000 kp)
+    ("1280x960-dense", ["--workload", "1280x960-dense", "--batch", "256", "--distinct", "16"]),   # what rounds 2-4 measured
+    ("720p-build", ["--workload", "720p-build", "--batch", "64"]),                 # configs[4]
+    ("vga-buckets43", ["--workload", "vga", "--log-bucket-size", "4", "--bucket-limit", "3", "--distinct", "32"]),   # README mode
+]
+
+
+def other_workloads(args, timeout_s: float = 90.0):
+    """Each entry of OTHER_WORKLOADS as `python bench.py ...` (N=1, the same library and pipeline depth, --other-steps timed
+    steps after a short clock ramp, parity_in_run on 8 pyramids of lane 0 + 4 of every other lane, no CPU leg): a compact
+    record per workload.  Returns (records, all_parity_ok).  A child that fails or times out is recorded as an error —
+    the headline line itself never depends on it — but a parity mismatch in a child fails the whole run (rc 6)."""
+    import subprocess
+    recs, ok = {}, True
+    for name, extra in OTHER_WORKLOADS:
+        cmd = [sys.executable, os.path.abspath(__file__), "--steps", str(args.other_steps), "--warmup", "3", "--spin-s", "0.25",
+               "--no-cpu-baseline", "--no-one-pyramid", "--no-other-workloads", "--parity-pyramids", "8",
+               "--streams", str(args.streams), "--graph", str(args.graph)] + extra
+        t0 = time.perf_counter()
+        try:
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s, cwd=ROOT)
+            line = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
+            if not line:
+                recs[name] = {"error": f"rc {r.returncode}: {r.stderr.strip()[-300:]}"}
+                continue
+            d = json.loads(line[-1])
+            pir = d.get("parity_in_run") or {}
+            recs[name] = {"ms_per_step": d["ms_per_step"], "value": d["value"], "steps": d["steps"], "batch": d["config"]["batch_per_gpu"],
+                          "keypoints_per_pyramid": d["config"]["keypoints_per_pyramid"],
+                          "strips_us": d["roofline"]["launch_ms"] * 1e3, "strips_frac_of_hbm_peak": d["roofline"]["frac"],
+                          "whole_step_frac": d["roofline"]["whole_step"]["frac"], "one_batch_ms": d.get("one_batch_ms"),
+                          "parity_ok": bool(pir.get("ok")), "parity_pyramids": pir.get("pyramids"),
+                          "parity_keypoints": pir.get("keypoints"), "baseline_config_index": d["config"]["baseline_config_index"],
+                          "wall_s": round(time.perf_counter() - t0, 1), "rc": r.returncode}
+            if r.returncode != 0 or not pir.get("ok"):
+                ok = False
+                recs[name]["first_mismatch"] = pir.get("first_mismatch")
+        except subprocess.TimeoutExpired:
+            recs[name] = {"error": f"timed out after {timeout_s:.0f} s"}
+        except Exception as e:                               # noqa: BLE001
+            recs[name] = {"error": repr(e)[:300]}
+    return recs, ok
+
+
+# ---------------------------------------------------------------------------------------------------------
 # arguments
 # ---------------------------------------------------------------------------------------------------------
 def build_parser():
@@ -190,6 +240,12 @@ def build_parser():
     ap.add_argument("--no-one-pyramid", action="store_true",
                     help="skip one_pyramid_ms (ONE pyramid per call, the reference's frame-at-a-time use): profiled runs pass this "
                          "— its small launches would enter the kernel-trace averages and PMC medians of the batch kernels")
+    ap.add_argument("--no-other-workloads", action="store_true",
+                    help="skip other_workloads: by default the N=1 run of the headline workload ends with a SHORT run of every other "
+                         "configuration (the reference's demo photo, configs[3] on spec and at the dense shape count, configs[4], the "
+                         "README bucket mode <4,3>) as child processes of this one — ms/step, strip-kernel time, keypoints per pyramid and "
+                         "parity_in_run of each — so that the driver's ONE line carries a number for every BASELINE config")
+    ap.add_argument("--other-steps", type=int, default=12, help="timed steps of each other_workloads child")
     ap.add_argument("--dist-backend", default=None,
                     help="override the torch.distributed backend (default nccl = RCCL); 'gloo' lets the N>1 code "
                          "path be exercised with several ranks sharing one GPU (testing only)")
@@ -1187,6 +1243,19 @@ def worker_main(args):
                 pins = 1754 if lb == 0 else 1315 if (lb, bl) == (4, 3) else None
             out["parity_in_run"] = parity_in_run(snap, kept_full, lane_hosts, levels, args.max_keypoints, lb, bl, pins=pins)
             parity_bad = not out["parity_in_run"]["ok"]
+        # every other BASELINE configuration, briefly (children of this process; the headline above is complete by now)
+        # (only in the full default line: development / profiling runs pass --no-cpu-baseline and get none of it)
+        if (world == 1 and not args.no_other_workloads and not args.no_cpu_baseline and args.workload == "vga" and not args.ablate
+                and not args.log_bucket_size and not args.match and args.pipeline != 1 and not args.opt and B == 256):
+            pl.synchronize()
+            torch.cuda.synchronize()
+            t_o = time.perf_counter()
+            recs, others_ok = other_workloads(args)
+            out["other_workloads"] = recs
+            out["other_workloads_wall_s"] = round(time.perf_counter() - t_o, 1)
+            if not others_ok:
+                parity_bad = True
+                print(f"[bench] other_workloads: a child failed its parity check: {recs}", file=sys.stderr, flush=True)
         print(json.dumps(out), flush=True)
         if parity_bad:
             print(f"[bench] parity_in_run FAILED: {out['parity_in_run'].get('first_mismatch')}", file=sys.stderr, flush=True)

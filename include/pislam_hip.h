@@ -267,7 +267,22 @@ int pislam_frontend_last_stats(pislam_ctx *ctx, uint32_t stats[2]);
 #define PISLAM_PATH_BUCKET_SELECT 8u   /* buckets applied by the selection pass between strips and gather (option "bucket_select" 1) */
 #define PISLAM_PATH_BUCKETS_IN_STRIPS 16u /* buckets applied inside the strips (option "bucket_select" 0, or more buckets than the pass holds) */
 #define PISLAM_PATH_GENERIC_ORB 32u    /* generic gather + per-keypoint ORB kernels (vstep % 16 != 0) */
+#define PISLAM_PATH_FRAME_TIMED_OUT 64u /* an earlier one-launch call of this context timed out (reported then, see below): the
+                                          context runs small batches as three launches now */
 unsigned pislam_frontend_last_path(const pislam_ctx *ctx);
+/* (On a pipeline lane the value is that of the lane's last call whether it ran eagerly or was replayed from its
+ * hipGraph.  On PISLAM_PATH_ONE_LAUNCH calls pislam_frontend_last_timing reports the whole call as stage 0: stages 1, 2 = 0.)
+ *
+ * The one-launch path's safety net.  Inside pf::k_frame the gather + ORB workgroups wait for the strip workgroups of the
+ * same grid; the library takes the path only while such waiting workgroups are a small fraction of the resident slots,
+ * and the wait is bounded (~1 s).  Should it ever expire (nothing observed does this: CU masks, a debugger or a future
+ * dispatcher could), the call does NOT return stale data silently:
+ *   - counts[i] of every pyramid whose keypoints were not produced is PISLAM_COUNT_INVALID (no valid count can be);
+ *   - the next call on the context (or on its pipeline lane), pislam_ctx_synchronize, pislam_pipeline_synchronize and
+ *     pislam_frontend_last_stats return PISLAM_ERR_HIP once, with a message naming the time-out, after resetting the
+ *     hand-over state; from then on the context runs small batches as three launches (PISLAM_PATH_FRAME_TIMED_OUT is set
+ *     in pislam_frontend_last_path; graphs the pipeline captured with a one-launch node are dropped). */
+#define PISLAM_COUNT_INVALID 0xffffffffu
 
 /* Host only — no device, no allocation, no launch: build the strip plan (and the bucket selection plan) a batch call with
  * these parameters would run and check the invariants the kernels rely on.  `options`: "key=value,key=value" with

@@ -34,6 +34,12 @@
 #ifndef PISLAM_OVL
 #define PISLAM_OVL 1          // strips of a run follow each other without a workgroup barrier (strip_body)
 #endif
+#ifndef PISLAM_DIAG
+#define PISLAM_DIAG 1         // pretest also requires two adjacent DIAGONAL ring points (3/7/11/15) of one polarity
+#endif
+#ifndef PISLAM_ORB_PITCH_DW
+#define PISLAM_ORB_PITCH_DW 13   // dwords per ORB patch row in LDS (12 = round 1-5: 48-byte rows skewed by a dword per 8 rows)
+#endif
 
 namespace pf {
 
@@ -167,13 +173,14 @@ __device__ __attribute__((noinline)) void harris_overflow(lds_u8 *tile, lds_u8 *
 //   table g_brief_ofs, eight tests per lane = one descriptor byte per lane.
 // ===========================================================================
 constexpr int OWAVES = 4;                           // waves per k_gather_orb workgroup
-constexpr int ORB_PITCH = 48;                       // one 48-byte (3 x 16 B) window per patch row
-// Row r of a patch starts at r * 48 + 4 * (r >> 3) bytes: a pitch of 12 dwords alone would put rows r, r+8, r+16,
-// r+24 on the same banks (12 * 8 = 96 = 3 * 32), a 4-way conflict on every one of the 9 row reads of the moments
-// (lane = row); the skew of one dword per 8 rows spreads them (PMC: 57 % of the kernel's LDS cycles were bank
-// conflicts, the LDS 68 % busy).
-__host__ __device__ constexpr int orb_row_ofs(int r) { return r * ORB_PITCH + 4 * (r >> 3); }
-constexpr int ORB_PATCH_BYTES = 32 * ORB_PITCH + 32;   // 31 rows (+1 idle) + skew + slack for the byte shift
+// One 48-byte (3 x 16 B) window per patch row, rows 13 dwords apart: an ODD dword pitch puts the 32 rows of a patch on 32
+// different banks for the 9 row reads of the moments (lane = row), and the four dword stores that park a 16-byte chunk
+// (lanes = (row, chunk), 13 row + 4 chunk + i) spread over the banks as well: 48 LDS cycles per pair instead of 68 with the
+// layout of rounds 2-5 (12-dword rows skewed by one dword per 8 rows: read-back conflict-free too, but the chunk stores
+// of 32 lanes fell on 8 banks).  (A pitch of 12 dwords alone puts rows r, r+8, r+16, r+24 on the same banks.)
+constexpr int ORB_PITCH = 4 * PISLAM_ORB_PITCH_DW;
+__host__ __device__ constexpr int orb_row_ofs(int r) { return PISLAM_ORB_PITCH_DW == 12 ? r * 48 + 4 * (r >> 3) : r * ORB_PITCH; }
+constexpr int ORB_PATCH_BYTES = 32 * ORB_PITCH + 32;   // 31 rows (+1 idle) + slack for the byte shift
 
 // Sum over each 32-lane half of the wave, result in every lane of that half.  DPP row shifts
 // (zero fill) leave each 16-lane row's sum in its last lane, row_bcast:15 folds row 0 into row 1 and
@@ -246,11 +253,20 @@ __device__ __forceinline__ OrbWin orb_fetch(const OrbLane &G, uint32_t p0, uint3
 // Park the fetched windows of a pair, then moments -> angle bin -> BRIEF.  `dst_base` (wave-uniform) + 4 * `dst_word`
 // (< 2^30): where this half's keypoint keeps its `words` descriptor words (ignored when that keypoint is absent).  `wave_patches`: 2 x
 // ORB_PATCH_BYTES of LDS private to the wave.  `rtab`: the vrecpe estimate table in LDS.
-template <class TAB>
+// `glevel` (profiling instantiation of k_gather_orb only, option "ablate" bits 20..23; 0 in every product kernel): stop the
+// describe after 2 = the fetch, 3 = + parking the windows, 4 = + read-back and moments, 5 = + angle bin, 6 = + BRIEF offset
+// table loads, 7 = + BRIEF sample reads and bit assembly (everything but the descriptor store) — cumulative, so that the
+// difference of two PMC passes is what the phase between them costs (tools/pmc_ablate_gather.sh).
+template <class TAB, bool GHOOKS = false>
 __device__ __forceinline__ void orb_describe(const OrbLane &G, const OrbWin &cur, uint32_t p0, uint32_t p1,
                                              lds_u8 *wave_patches, int vstep, const TAB *rtab, int words,
-                                             uint8_t *__restrict__ dst_base, const uint32_t dst_word) {
+                                             uint8_t *__restrict__ dst_base, const uint32_t dst_word, const int glevel = 0) {
   const int half = G.half, r = G.r;
+  if (GHOOKS && glevel == 2) {                        // the loads must stay: their registers are "used"
+#pragma unroll
+    for (int j = 0; j < 3; j++) asm volatile("" ::"v"(cur.w[j].x), "v"(cur.w[j].y), "v"(cur.w[j].z), "v"(cur.w[j].w));
+    return;
+  }
   const uint32_t pme = half ? p1 : p0;
   const bool valid = pme != 0;
   const int x = decode_x(pme), y = decode_y(pme);
@@ -267,6 +283,7 @@ __device__ __forceinline__ void orb_describe(const OrbLane &G, const OrbWin &cur
       d[2] = cur.w[j].z;
       d[3] = cur.w[j].w;
     }
+  if (GHOOKS && glevel == 3) return;
   lds_u8 *patch_l = wave_patches + half * ORB_PATCH_BYTES;
   const lds_u8 *prow = patch_l + orb_row_ofs(r);
   // read the row back aligned to the PATCH: 9 aligned dwords + v_alignbyte (byte-unaligned
@@ -291,7 +308,15 @@ __device__ __forceinline__ void orb_describe(const OrbLane &G, const OrbWin &cur
   for (int k = 4; k < 8; k++) right = __builtin_amdgcn_udot4(row[k], G.mdx[k], right, false);      // dx 1 .. 15 (16 masked)
   const int m10 = half_sum((int)right - (int)left, half);
   const int m01 = half_sum((r - 15) * (int)sv, half);
+  if (GHOOKS && glevel == 4) {
+    asm volatile("" ::"v"(m10), "v"(m01));
+    return;
+  }
   const uint32_t rot = angle_bin_fast(m10, m01, rtab);
+  if (GHOOKS && glevel == 5) {
+    asm volatile("" ::"v"(rot));
+    return;
+  }
   // BRIEF: lane r of a half runs the EIGHT tests k = 8 r .. 8 r + 7 of its keypoint — byte r of the descriptor (bit
   // k % 32 of word k / 32 = byte k / 8, bit k % 8).  The sign of a - b IS the test (Brief.h:52) and v_alignbit_b32
   // shifts it into the byte (tests taken from t = 7 down, so that test 8 r + t ends up in bit t); four adjacent lanes'
@@ -309,6 +334,11 @@ __device__ __forceinline__ void orb_describe(const OrbLane &G, const OrbWin &cur
   uint32_t ent[8];
 #pragma unroll
   for (int t = 0; t < 8; t++) ent[t] = tab[32 * t];        // all 8 table loads in flight
+  if (GHOOKS && glevel == 6) {
+#pragma unroll
+    for (int t = 0; t < 8; t++) asm volatile("" ::"v"(ent[t]));
+    return;
+  }
   uint32_t pa[8], pb[8];
 #pragma unroll
   for (int t = 0; t < 8; t++) pa[t] = bp[ent[t] & 0xffffu], pb[t] = bp[ent[t] >> 16];   // all 16 reads in flight
@@ -320,6 +350,10 @@ __device__ __forceinline__ void orb_describe(const OrbLane &G, const OrbWin &cur
   const uint32_t n2 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)hw, 0xaa, 0xf, 0xf, true);      // quad_perm [2,2,2,2]
   const uint32_t word4 = __builtin_amdgcn_perm(n2, hw, 0x05040100u);                                 // valid in lanes r % 4 == 0
   const uint32_t word = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(4u * (32u * (uint32_t)half + 4u * ((uint32_t)r & 7u))), (int)word4);
+  if (GHOOKS && glevel == 7) {
+    asm volatile("" ::"v"(word));
+    return;
+  }
   // (32-bit byte offset from a wave-uniform base: one multiply and a shift-add instead of a 64-bit multiply-add chain)
   if (valid && r < words) *(uint32_t *)(dst_base + (dst_word * 4u + 4u * (uint32_t)r)) = word;
 }
@@ -585,8 +619,30 @@ __device__ __forceinline__ void strip_body(const StripArgs A, const FusedLevel L
     const uint32_t bL = __builtin_amdgcn_lerp(hL, nkb4, 0x01010101u), bR = __builtin_amdgcn_lerp(hR, nkb4, 0x01010101u);
     const uint32_t dU = __builtin_amdgcn_lerp(hU, nkd4, 0x01010101u), dD = __builtin_amdgcn_lerp(hD, nkd4, 0x01010101u);
     const uint32_t dL = __builtin_amdgcn_lerp(hL, nkd4, 0x01010101u), dR = __builtin_amdgcn_lerp(hR, nkd4, 0x01010101u);
-    const uint32_t bright = (bU | bD) & (bL | bR);
-    const uint32_t notdark = (dU & dD) | (dL & dR);        // bit 7: no dark vertical point OR no dark horizontal point
+    uint32_t bright = (bU | bD) & (bL | bR);
+    uint32_t notdark = (dU & dD) | (dL & dR);              // bit 7: no dark vertical point OR no dark horizontal point
+#if PISLAM_DIAG
+    // A 9-arc also holds two ADJACENT DIAGONAL ring points (positions 3 / 7 / 11 / 15 = (-2,+2), (+2,+2), (+2,-2), (-2,-2):
+    // any nine consecutive ring positions contain two consecutive odd multiples-of-2 of either kind), of the arc's own
+    // polarity: one of the opposite pair (3, 11) AND one of (7, 15).  Same byte-domain form as the compass points — rows
+    // -2 / +2 as three aligned dwords each, the four neighbours of the 4 pixels by v_alignbyte — and the same polarity
+    // as the compass pair: 5.3 -> 3.1 candidates per corner on the synthetic input, 4.5 -> 2.4 on the demo photo.
+    {
+      const lds_u8 *pu2 = pb - 2 * tpitch, *pd2 = pb + 2 * tpitch;
+      const uint32_t ul = *(const lds_u32 *)pu2, uc = *(const lds_u32 *)(pu2 + 4), ur = *(const lds_u32 *)(pu2 + 8);
+      const uint32_t dl = *(const lds_u32 *)pd2, dc = *(const lds_u32 *)(pd2 + 4), dr = *(const lds_u32 *)(pd2 + 8);
+      const uint32_t h15 = __builtin_amdgcn_lerp(__builtin_amdgcn_alignbyte(uc, ul, 2), nC, 0x01010101u);   // (-2, -2)
+      const uint32_t h3 = __builtin_amdgcn_lerp(__builtin_amdgcn_alignbyte(ur, uc, 2), nC, 0x01010101u);    // (-2, +2)
+      const uint32_t h11 = __builtin_amdgcn_lerp(__builtin_amdgcn_alignbyte(dc, dl, 2), nC, 0x01010101u);   // (+2, -2)
+      const uint32_t h7 = __builtin_amdgcn_lerp(__builtin_amdgcn_alignbyte(dr, dc, 2), nC, 0x01010101u);    // (+2, +2)
+      const uint32_t b3 = __builtin_amdgcn_lerp(h3, nkb4, 0x01010101u), b11 = __builtin_amdgcn_lerp(h11, nkb4, 0x01010101u);
+      const uint32_t b7 = __builtin_amdgcn_lerp(h7, nkb4, 0x01010101u), b15 = __builtin_amdgcn_lerp(h15, nkb4, 0x01010101u);
+      const uint32_t d3 = __builtin_amdgcn_lerp(h3, nkd4, 0x01010101u), d11 = __builtin_amdgcn_lerp(h11, nkd4, 0x01010101u);
+      const uint32_t d7 = __builtin_amdgcn_lerp(h7, nkd4, 0x01010101u), d15 = __builtin_amdgcn_lerp(h15, nkd4, 0x01010101u);
+      bright &= (b3 | b11) & (b7 | b15);
+      notdark |= (d3 & d11) | (d7 & d15);
+    }
+#endif
     const uint32_t pass = bright | ~notdark;               // bit 7 of byte k: pixel x0 + k goes on to the segment test
     // The four pass flags as wave masks, ONE compare each (SDWA: the sign of byte k; groups outside the classified
     // columns cleared first), the early exit decided on the masks, and the lane predicates taken back from them
@@ -1700,7 +1756,7 @@ struct NoWait {
 };
 // `wait_producers` (k_frame): called once the loads that do not depend on the strips (vrecpe table, mask-table row) are
 // under way; returns false (workgroup-uniform) when the lists never arrived — the role then does nothing.
-template <class WAIT = NoWait>
+template <class WAIT = NoWait, bool GHOOKS = false>
 __device__ __forceinline__ void orb_role(const FusedParams &P, const uint8_t *__restrict__ pyramids, size_t pyr_stride,
                                          const uint32_t *__restrict__ stage_kp, const uint32_t *__restrict__ strip_count,
                                          const uint32_t *__restrict__ stage_desc, uint32_t *__restrict__ kp, size_t kp_stride,
@@ -1807,7 +1863,8 @@ __device__ __forceinline__ void orb_role(const FusedParams &P, const uint8_t *__
     }
     __syncthreads();
     const uint32_t nt = sh->ntodo;
-    if (nt != 0 && !(P.ablate & 64)) {
+    const int glevel = GHOOKS ? (P.ablate >> 20) & 15 : 0;
+    if (nt != 0 && !(P.ablate & 64) && glevel != 1) {
       // ---- describe the rest: two keypoints per wave iteration ----
       const uint32_t npairs = (nt + 1) >> 1;
       // the two keypoints of pair `it`: packed words (0 when absent) and their final positions
@@ -1826,11 +1883,11 @@ __device__ __forceinline__ void orb_role(const FusedParams &P, const uint8_t *__
       for (uint32_t it = wv; it < npairs; it += 2 * OWAVES) {
         pair_of(it + OWAVES, b0, b1, qb0, qb1);
         wb = orb_fetch(G, b0, b1, im, vstep, img_bytes32);
-        orb_describe(G, wa, a0, a1, wave_patches, vstep, rtab, words, (uint8_t *)dsc, (G.half ? qa1 : qa0) * (uint32_t)words);
+        orb_describe<lds_u8, GHOOKS>(G, wa, a0, a1, wave_patches, vstep, rtab, words, (uint8_t *)dsc, (G.half ? qa1 : qa0) * (uint32_t)words, glevel);
         if (it + OWAVES >= npairs) break;
         pair_of(it + 2 * OWAVES, a0, a1, qa0, qa1);
         wa = orb_fetch(G, a0, a1, im, vstep, img_bytes32);
-        orb_describe(G, wb, b0, b1, wave_patches, vstep, rtab, words, (uint8_t *)dsc, (G.half ? qb1 : qb0) * (uint32_t)words);
+        orb_describe<lds_u8, GHOOKS>(G, wb, b0, b1, wave_patches, vstep, rtab, words, (uint8_t *)dsc, (G.half ? qb1 : qb0) * (uint32_t)words, glevel);
       }
     }
     __syncthreads();                                  // kpl / kpos / todo are reused by the next round
@@ -1853,6 +1910,7 @@ __device__ __forceinline__ void orb_role(const FusedParams &P, const uint8_t *__
 // (waves_per_eu(6): asking the compiler for 7 waves caps its SGPRs and cost 13 SGPR spills — v_writelane / v_readlane in
 //  the describe loop; the resident waves are pinned to 6 per SIMD inside the kernel, see there.  A third register set
 //  (the loads of TWO pairs in flight) was measured too: 80 VGPRs, no gain.)
+template <bool GHOOKS>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) void k_gather_orb(
     const FusedParams P, const uint8_t *__restrict__ pyramids, size_t pyr_stride,
     const uint32_t *__restrict__ stage_kp, const uint32_t *__restrict__ strip_count,
@@ -1871,8 +1929,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) void k
     ovf_reset[1] = ovf_reset[0];                     // kept for pislam_frontend_last_stats
     ovf_reset[0] = 0;
   }
-  orb_role(P, pyramids, pyr_stride, stage_kp, strip_count, stage_desc, kp, kp_stride, cap, counts, desc, desc_stride, words,
-           per_max, osm, (int)blockIdx.y, (int)blockIdx.x, (int)gridDim.x);
+  orb_role<NoWait, GHOOKS>(P, pyramids, pyr_stride, stage_kp, strip_count, stage_desc, kp, kp_stride, cap, counts, desc, desc_stride,
+                           words, per_max, osm, (int)blockIdx.y, (int)blockIdx.x, (int)gridDim.x);
 }
 
 // ===========================================================================
@@ -1881,24 +1939,32 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) void k
 // included): one pyramid took 31 us end to end, 15 us of it work.  Here the grid holds the strip workgroups FIRST
 // (run-major, longest runs first, like k_fused_strips) and the gather + ORB workgroups of every pyramid BEHIND them;
 // an ORB workgroup waits until its pyramid's runs have all published their lists.
-//   * No deadlock by construction: workgroups are dispatched in blockIdx order, so whenever an ORB workgroup is
-//     resident every strip workgroup has been dispatched or is about to be (it never waits for an ORB workgroup); the
-//     host only takes this path while the ORB workgroups of a few such launches in flight are a small fraction of the
-//     resident slots of an XCD.  The wait is bounded all the same (a second of polling; sync[...] then says so).
+//   * Forward progress: workgroups are dispatched in blockIdx order, so whenever an ORB workgroup is resident every strip
+//     workgroup has been dispatched or is about to be, and a strip workgroup never waits for anything; the host takes
+//     this path only while the waiting workgroups of all such launches in flight are a small fraction of an XCD's resident
+//     slots (run_fused).  No AMD document promises that order (CU masks, debuggers, future firmware), so the wait is
+//     BOUNDED and a timeout is never silent: the workgroup that gives up raises a sticky flag in device memory and in a
+//     host-mapped word the library reads at the start of every call, publishes counts[pyr] = PISLAM_COUNT_INVALID
+//     (0xffffffff) instead of a count, and the launch does not re-arm its counters; every later launch sees the flag and
+//     publishes the same sentinel until the host has reset the counters (and stopped taking this path on that context).
 //   * Hand-over: a strip workgroup finishes with a workgroup barrier (which also drains its stores) and ONE agent-scope
 //     RELEASE increment of its pyramid's counter (the L2 write-back of its XCD: pyramids are spread over all eight);
-//     the ORB workgroup polls with agent-scope ACQUIRE loads (cache invalidate), then a workgroup barrier.
+//     the ORB workgroup polls with relaxed agent-scope loads, then ONE acquire fence and a workgroup barrier.
 //   * Strips whose queues overflow are redone in place (strips_role<INLINE_OVF>): no overflow list, no second launch.
 //   * The last ORB workgroup to finish re-arms the counters for the next launch (and keeps the deferred-strip count for
 //     pislam_frontend_last_stats) — a captured launch replays without any host-side reset.
-// sync: [0 .. batch) runs done per pyramid, [batch] ORB workgroups done, [batch + 1] 1 = a wait timed out.
+// sync: [0 .. FRAME_SYNC_PYR) runs done per pyramid, [FRAME_SYNC_DONE] ORB workgroups done, [FRAME_SYNC_POISON] sticky:
+// a wait timed out (only the host clears it).  `hflag`: the host-mapped copy of the sticky flag.
+// `test`: bit 0 = the first strip workgroup skips its release (forces the timeout: tests), bits 8.. = log2 of the poll limit.
 // ===========================================================================
+constexpr int FRAME_SYNC_PYR = 8, FRAME_SYNC_DONE = 8, FRAME_SYNC_POISON = 9, FRAME_SYNC_WORDS = 12;
+constexpr uint32_t COUNT_INVALID = 0xffffffffu;     // == PISLAM_COUNT_INVALID
 __global__ __launch_bounds__(NT) void k_frame(const FusedParams P, const uint8_t *__restrict__ pyramids, size_t pyr_stride,
                                               uint32_t *__restrict__ stage_kp, uint32_t *__restrict__ strip_count,
                                               uint32_t *__restrict__ kp, size_t kp_stride, uint32_t cap,
                                               uint32_t *__restrict__ counts, uint32_t *__restrict__ desc, size_t desc_stride,
                                               int words, uint32_t per_max, int nch, uint32_t *__restrict__ sync,
-                                              uint32_t *__restrict__ ovf) {
+                                              uint32_t *__restrict__ ovf, uint32_t *__restrict__ hflag, uint32_t test) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   __shared__ uint32_t sh_ctr[16];
   const int n_strip = P.batch * P.runs_per_pyr;
@@ -1907,7 +1973,8 @@ __global__ __launch_bounds__(NT) void k_frame(const FusedParams P, const uint8_t
     strips_role<true, false, true, false, false, true>(P, pyramids, pyr_stride, stage_kp, strip_count, nullptr, 0, nullptr, ovf,
                                                        nullptr, smem, sh_ctr, pyr, run);
     __syncthreads();                                // every thread's stores have been issued and acknowledged
-    if (threadIdx.x == 0) (void)__hip_atomic_fetch_add(&sync[pyr], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x == 0 && !((test & 1u) && blockIdx.x == 0))
+      (void)__hip_atomic_fetch_add(&sync[pyr], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     return;
   }
   const int ob = (int)blockIdx.x - n_strip, pyr = ob / nch, ch = ob - pyr * nch;
@@ -1915,9 +1982,12 @@ __global__ __launch_bounds__(NT) void k_frame(const FusedParams P, const uint8_t
   auto wait = [&]() -> bool {
     if (threadIdx.x == 0) {
       uint32_t ok = 0;
+      // an earlier launch timed out and the host has not reset the counters yet: they cannot be trusted
+      const bool poisoned = __hip_atomic_load(&sync[FRAME_SYNC_POISON], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
       // (relaxed polls — an acquire load would invalidate this XCD's caches on every iteration, under the strip workgroups
       //  still streaming their rows through them — and ONE acquire fence once the counter is there)
-      for (int it = 0; it < (1 << 20); it++) {      // (~1 s: only a lost launch ever gets there)
+      const int limit = poisoned ? 0 : 1 << (((test >> 8) & 31u) ? ((test >> 8) & 31u) : 20u);   // (2^20 polls ~ 1 s: only a lost launch ever gets there)
+      for (int it = 0; it < limit; it++) {
         if (__hip_atomic_load(&sync[pyr], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (uint32_t)P.runs_per_pyr) {
           ok = 1;
           break;
@@ -1925,7 +1995,11 @@ __global__ __launch_bounds__(NT) void k_frame(const FusedParams P, const uint8_t
         __builtin_amdgcn_s_sleep(PISLAM_FRAME_SLEEP);
       }
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      if (!ok) __hip_atomic_store(&sync[P.batch + 1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (!ok) {
+        __hip_atomic_store(&sync[FRAME_SYNC_POISON], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(hflag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (ch == 0) counts[pyr] = COUNT_INVALID;   // never a stale count: the caller's own data says the call failed
+      }
       sh_ok = ok;
     }
     __syncthreads();
@@ -1934,10 +2008,12 @@ __global__ __launch_bounds__(NT) void k_frame(const FusedParams P, const uint8_t
   orb_role(P, pyramids, pyr_stride, stage_kp, strip_count, nullptr, kp, kp_stride, cap, counts, desc, desc_stride, words, per_max,
            smem, pyr, ch, nch, wait);
   __syncthreads();
-  if (threadIdx.x == 0) {
-    const uint32_t done = __hip_atomic_fetch_add(&sync[P.batch], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  // (a workgroup that gave up does not count as done: a launch that timed out never re-arms — late strip workgroups may
+  //  still be incrementing its counters; the host resets them)
+  if (threadIdx.x == 0 && sh_ok != 0) {
+    const uint32_t done = __hip_atomic_fetch_add(&sync[FRAME_SYNC_DONE], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (done + 1 == (uint32_t)(P.batch * nch)) {    // the launch's last workgroup: every strip and every ORB workgroup is through
-      for (int i = 0; i <= P.batch; i++) __hip_atomic_store(&sync[i], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      for (int i = 0; i <= FRAME_SYNC_DONE; i++) __hip_atomic_store(&sync[i], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       ovf[1] = __hip_atomic_load(&ovf[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // strips redone in place (last_stats)
       __hip_atomic_store(&ovf[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }

@@ -22,13 +22,19 @@ __device__ const uint32_t g_brief_tab[30 * 256] = {
 static constexpr uint32_t h_brief_tab_packed[30 * 256] = {
 #include "brief_table.inc"
 };
-// The same table as byte offsets into the LDS patch of the ORB kernels (48-byte rows, skewed by one dword per 8
-// rows: pf::orb_row_ofs) whose row 15 / column 15 is the keypoint: ofs = row_ofs(dy+15) + (dx+15); low half = first
+// The same table as byte offsets into the LDS patch of the ORB kernels (rows pf::orb_row_ofs apart) whose row 15 /
+// column 15 is the keypoint: ofs = row_ofs(dy+15) + (dx+15); low half = first
 // sample point, high half = second.  Entry order: see make_brief_ofs.
 struct BriefOfsTab {
   uint32_t v[30 * 256];
 };
-static constexpr int brief_row_ofs(int r) { return r * 48 + 4 * (r >> 3); }   // == pf::orb_row_ofs (checked below)
+#include "pislam_dev.h"
+__device__ const pdev::VrecpeTab g_vrecpe_tab = pdev::make_vrecpe_tab();   // used by pf::k_gather_orb
+__device__ const pdev::OrbMaskTab g_orb_masks = pdev::make_orb_mask_tab();  // used by pf::orb_lane
+extern __device__ const BriefOfsTab g_brief_ofs;
+#include "pislam_stage_kernels.h"
+#include "pislam_fused_kernels.h"
+static constexpr int brief_row_ofs(int r) { return pf::orb_row_ofs(r); }
 static constexpr BriefOfsTab make_brief_ofs() {
   BriefOfsTab t{};
   for (int i = 0; i < 30 * 256; i++) {
@@ -44,13 +50,6 @@ static constexpr BriefOfsTab make_brief_ofs() {
 }
 __device__ const BriefOfsTab g_brief_ofs = make_brief_ofs();
 
-#include "pislam_dev.h"
-__device__ const pdev::VrecpeTab g_vrecpe_tab = pdev::make_vrecpe_tab();   // used by pf::k_gather_orb
-__device__ const pdev::OrbMaskTab g_orb_masks = pdev::make_orb_mask_tab();  // used by pf::orb_lane
-#include "pislam_stage_kernels.h"
-#include "pislam_fused_kernels.h"
-static_assert(brief_row_ofs(0) == pf::orb_row_ofs(0) && brief_row_ofs(15) == pf::orb_row_ofs(15) &&
-              brief_row_ofs(30) == pf::orb_row_ofs(30), "g_brief_ofs must use the patch layout of the ORB kernels");
 #include "pislam_prep_kernels.h"
 #include "pislam_match_kernels.h"
 
@@ -117,6 +116,13 @@ struct pislam_ctx {
   std::vector<PlanTable *> plan_tables;
   const uint32_t *cur_utab = nullptr;   // the table of the call being issued
   DevBuf w_sync;                     // one-launch path (pf::k_frame): per-pyramid hand-over counters, zero between launches
+  // The one-launch path's bounded wait (pf::k_frame): a workgroup that gives up raises a sticky flag in w_sync AND in this
+  // host-mapped word, which every call on the context reads first (a plain host load: no synchronisation, no copy).
+  uint32_t *frame_flag = nullptr;    // hipHostMalloc'ed, mapped
+  uint32_t *frame_flag_dev = nullptr;
+  bool frame_disabled = false;       // a timeout was seen: the context takes the three-launch path from then on
+  unsigned long long frame_timeouts = 0;   // (counted into workspace_generation: graphs holding a k_frame node are dropped)
+  int opt_frame_test = 0;            // test hook: bit 0 = one strip workgroup skips its release, bits 8.. = log2 poll limit
   int num_cus = 0;
   int opt_pipeline = 0;      // 0 auto, 1 staged (one launch group per level), 2 fused strips
   int opt_dump_score = 0;    // fused pipeline: also materialise the score map (parity hook)
@@ -166,7 +172,7 @@ struct pislam_ctx {
   // addresses of the workspace buffers and the overflow-list layout.  pislam_pipeline_submit replays a hipGraph
   // only while this number is what it was at capture time.
   unsigned long long workspace_generation() const {
-    unsigned long long g = ovf_layouts + table_uploads;
+    unsigned long long g = ovf_layouts + table_uploads + frame_timeouts;
     for (const DevBuf *b : {&w_cnt, &w_off, &w_total, &w_cellkp, &w_score, &w_stage, &w_stripcnt, &w_work, &w_prof,
                             &w_ovf, &w_stagedesc, &w_ustage, &w_ucount, &w_sync})
       g += b->reallocs;
@@ -458,6 +464,7 @@ PISLAM_EXPORT int pislam_ctx_destroy(pislam_ctx *c) {
     if (e) (void)hipEventDestroy(e);
   if (c->ev_join) (void)hipEventDestroy(c->ev_join);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+  if (c->frame_flag) (void)hipHostFree(c->frame_flag);
   delete c;
   return PISLAM_OK;
 }
@@ -530,6 +537,10 @@ PISLAM_EXPORT int pislam_ctx_set_option(pislam_ctx *c, const char *key, int valu
   } else if (!strcmp(key, "frame")) {   // 0: never one launch; 1 (default): batches of 1 or 2 pyramids; n = 2..8: batches of up to n
     if (value < 0 || value > 8) return fail(c, PISLAM_ERR_INVALID, "frame must be 0..8");
     c->opt_frame = value;
+  } else if (!strcmp(key, "frame_test")) {   // test hook of the one-launch path's bounded wait (see pf::k_frame `test`)
+    c->opt_frame_test = value;
+  } else if (!strcmp(key, "frame_rearm")) {  // 1: take the one-launch path again after a reported timeout (tests)
+    if (value) c->frame_disabled = false;
   } else if (!strcmp(key, "orb_in_strip")) {
     c->opt_orb_in_strip = value != 0;
   } else if (!strcmp(key, "bucket_select")) {
@@ -557,9 +568,13 @@ PISLAM_EXPORT int pislam_ctx_set_option(pislam_ctx *c, const char *key, int valu
   return PISLAM_OK;
 }
 
+namespace {
+int check_frame_poison(pislam_ctx *c);
+}
 PISLAM_EXPORT int pislam_ctx_synchronize(pislam_ctx *c) {
   if (!c) return PISLAM_ERR_INVALID;
-  return sync(c);
+  PCHK(sync(c));
+  return check_frame_poison(c);
 }
 
 PISLAM_EXPORT const char *pislam_last_error(const pislam_ctx *c) { return c ? c->err.c_str() : "null ctx"; }
@@ -1417,11 +1432,11 @@ int plan_table(pislam_ctx *c, std::vector<uint32_t> &&t, const uint32_t **out) {
   if (t.empty()) t.push_back(0u);
   for (size_t i = 0; i < c->plan_tables.size(); i++)
     if (c->plan_tables[i]->host == t) {
-      if (i + 1 != c->plan_tables.size()) std::swap(c->plan_tables[i], c->plan_tables.back());   // (most recently used last)
+      std::rotate(c->plan_tables.begin() + i, c->plan_tables.begin() + i + 1, c->plan_tables.end());   // most recently used last, the others keep their order
       *out = c->plan_tables.back()->dev.as<uint32_t>();
       return PISLAM_OK;
     }
-  if (c->plan_tables.size() >= 16) {                  // evict the least recently used
+  if (c->plan_tables.size() >= 64) {                  // evict the least recently used (a table is a few KB)
     HIPCHK(c, hipStreamSynchronize(c->stream));       // (a launch in flight may still read it)
     c->plan_tables.front()->dev.release();
     delete c->plan_tables.front();
@@ -1477,12 +1492,40 @@ constexpr int FRAME_MAX_BATCH = 8;                                  // what opti
 constexpr int FRAME_DEFAULT_BATCH = 2;                              // measured: one launch wins for 1 and 2 pyramids per call
 inline int frame_max_batch(const pislam_ctx *c) { return c->opt_frame <= 0 ? 0 : c->opt_frame == 1 ? FRAME_DEFAULT_BATCH : std::min(c->opt_frame, FRAME_MAX_BATCH); }
 inline int frame_chunks(int batch) { return std::min(64, std::max(16, 128 / std::max(1, batch))); }   // ORB workgroups per pyramid
+static_assert(FRAME_MAX_BATCH <= pf::FRAME_SYNC_PYR, "k_frame's hand-over counters");
 int ensure_frame_sync(pislam_ctx *c) {
   bool grew = false;
-  if (c->w_sync.ensure(sizeof(uint32_t) * (FRAME_MAX_BATCH + 2), &grew) != PISLAM_OK)
+  if (c->w_sync.ensure(sizeof(uint32_t) * pf::FRAME_SYNC_WORDS, &grew) != PISLAM_OK)
     return fail(c, PISLAM_ERR_NOMEM, "hipMalloc(frame sync)");
   if (grew) HIPCHK(c, hipMemsetAsync(c->w_sync.p, 0, c->w_sync.cap, c->stream));   // (the kernel re-arms them itself)
+  if (!c->frame_flag) {
+    void *h = nullptr, *d = nullptr;
+    if (hipHostMalloc(&h, 64, hipHostMallocMapped) != hipSuccess || hipHostGetDevicePointer(&d, h, 0) != hipSuccess) {
+      (void)hipGetLastError();
+      if (h) (void)hipHostFree(h);
+      return fail(c, PISLAM_ERR_NOMEM, "hipHostMalloc(frame flag)");
+    }
+    c->frame_flag = (uint32_t *)h;
+    c->frame_flag_dev = (uint32_t *)d;
+    *(volatile uint32_t *)c->frame_flag = 0;
+  }
   return PISLAM_OK;
+}
+// Has a pf::k_frame launch of this context given up waiting (see the kernel)?  Called at the start of every batch call, by
+// pislam_pipeline_submit, pislam_ctx_synchronize and pislam_frontend_last_stats.  If so: drain the stream, reset the hand-over
+// counters, stop taking the one-launch path on this context (calls run as three launches from now on; captured graphs
+// that hold a k_frame node are dropped through workspace_generation) and report the failure ONCE — the calls that were
+// affected have published counts[pyr] = PISLAM_COUNT_INVALID in the caller's own buffer.
+int check_frame_poison(pislam_ctx *c) {
+  if (!c->frame_flag || *(volatile uint32_t *)c->frame_flag == 0) return PISLAM_OK;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipMemsetAsync(c->w_sync.p, 0, c->w_sync.cap, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  *(volatile uint32_t *)c->frame_flag = 0;
+  c->frame_disabled = true;
+  c->frame_timeouts++;
+  return fail(c, PISLAM_ERR_HIP, "the one-launch path (pf::k_frame) timed out waiting for its strip workgroups: the affected calls "
+                                 "wrote counts = PISLAM_COUNT_INVALID; this context now runs small batches as three launches");
 }
 
 // `Fplan`: the strip plan, built for the largest sub-batch (sub_max pyramids).
@@ -1568,6 +1611,8 @@ int run_fused(pislam_ctx *c, const pislam_frontend_params *p, const pf::FusedPar
   // measured 0.079 ms against 0.085 ms with 16 (2.3 waves: the last one 30 % full).
   int nch = 0;
   size_t per_max = 0, olds = 0;
+  // (the profiling instantiation exists for the gather's per-phase counters: option "ablate" bits 20..23, pf::orb_describe)
+  const auto gkern = (Fplan.ablate >> 20) & 15 ? pf::k_gather_orb<true> : pf::k_gather_orb<false>;
   if (!generic_orb) {
     long px = 0;
     for (int l = 0; l < Fplan.nlevels; l++) px += (long)(Fplan.lv[l].ex1 - Fplan.lv[l].ex0) * Fplan.lv[l].nstrips * Fplan.lv[l].R;
@@ -1596,16 +1641,24 @@ int run_fused(pislam_ctx *c, const pislam_frontend_params *p, const pf::FusedPar
     olds = pf::orb_lds_bytes(Sg, per_max);
     if (olds > 150 * 1024) return fail(c, PISLAM_ERR_INVALID, "max_keypoints too large for the fused ORB kernel");
     if (olds > 64 * 1024)
-      HIPCHK(c, hipFuncSetAttribute((const void *)pf::k_gather_orb, hipFuncAttributeMaxDynamicSharedMemorySize, (int)olds));
+      HIPCHK(c, hipFuncSetAttribute((const void *)gkern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)olds));
   }
 
   // ---- small batches: strips -> (overflowed strips redone in place) -> gather + ORB as ONE launch ----
+  if (c->frame_disabled) c->last_path |= PISLAM_PATH_FRAME_TIMED_OUT;
   if (alias && vec && !sel && Fplan.lbs == 0 && !hooks && !generic_orb && nsub == 1 && !Fplan.orb_in_strip &&
-      c->opt_repeat_strips <= 1 && batch <= frame_max_batch(c)) {
+      c->opt_repeat_strips <= 1 && batch <= frame_max_batch(c) && !c->frame_disabled) {
     const int fch = frame_chunks(batch);
     const size_t fper = ((size_t)p->max_keypoints + fch - 1) / fch;
     const size_t flds = std::max(std::max(lds_alias, lds), pf::orb_lds_bytes(S, fper));
-    if (flds <= 150 * 1024) {
+    // Occupancy gate: the gather + ORB workgroups WAIT inside the grid.  With `lanes_in_flight` such launches on the device
+    // at most lanes x batch x fch of them are resident, an eighth per XCD; they must stay a small fraction (a quarter) of
+    // the workgroups an XCD holds with this launch's LDS footprint (96 VGPRs: five 4-wave workgroups per CU at most), so
+    // that strip workgroups always find a slot.
+    const long wg_per_cu = std::max<long>(1, std::min<long>(5, (long)(160 * 1024) / (long)std::max<size_t>(flds, 1)));
+    const long slots_per_xcd = wg_per_cu * std::max(1, c->num_cus / 8);
+    const long waiting_per_xcd = ((long)std::max(1, c->lanes_in_flight) * batch * fch + 7) / 8;
+    if (flds <= 150 * 1024 && 4 * waiting_per_xcd <= slots_per_xcd) {
       PCHK(ensure_frame_sync(c));
       if (flds > 64 * 1024)
         HIPCHK(c, hipFuncSetAttribute((const void *)pf::k_frame, hipFuncAttributeMaxDynamicSharedMemorySize, (int)flds));
@@ -1615,7 +1668,7 @@ int run_fused(pislam_ctx *c, const pislam_frontend_params *p, const pf::FusedPar
       hipLaunchKernelGGL(pf::k_frame, dim3(grid), dim3(pf::NT), flds, c->stream, F, pyramids, stride, c->w_stage.as<uint32_t>(),
                          c->w_stripcnt.as<uint32_t>(), kp, (size_t)p->max_keypoints, (uint32_t)p->max_keypoints, counts, desc,
                          (size_t)p->max_keypoints * p->words, p->words, (uint32_t)fper, fch, c->w_sync.as<uint32_t>(),
-                         c->w_ovf.as<uint32_t>());
+                         c->w_ovf.as<uint32_t>(), c->frame_flag_dev, (uint32_t)c->opt_frame_test);
       PCHK(launch_ok(c, "k_frame"));
       c->last_path = PISLAM_PATH_FUSED | PISLAM_PATH_ONE_LAUNCH;
       HIPCHK(c, hipEventRecord(c->ev[1], c->stream));   // (one launch: the stage split of last_timing is all in stage 0)
@@ -1719,7 +1772,7 @@ int run_fused(pislam_ctx *c, const pislam_frontend_params *p, const pf::FusedPar
                          (size_t)p->max_keypoints * p->words, (int32_t *)nullptr, (const uint8_t *)nullptr);
       PCHK(launch_ok(c, "k_orb<batch>"));
     } else {
-      hipLaunchKernelGGL(pf::k_gather_orb, dim3(nch, n), dim3(256), olds, X, G, s_pyr, stride, g_stage, g_cnt,
+      hipLaunchKernelGGL(gkern, dim3(nch, n), dim3(256), olds, X, G, s_pyr, stride, g_stage, g_cnt,
                          (const uint32_t *)s_sdesc, s_kp, (size_t)p->max_keypoints, (uint32_t)p->max_keypoints, s_counts,
                          s_desc, (size_t)p->max_keypoints * p->words, p->words, (uint32_t)per_max, ovf);
       PCHK(launch_ok(c, "k_gather_orb"));
@@ -1911,6 +1964,7 @@ PISLAM_EXPORT int pislam_orb_frontend_batch(pislam_ctx *c, const pislam_frontend
                                             size_t stride, int batch, uint32_t *kp, uint32_t *desc,
                                             uint32_t *counts) {
   PCHK(check_params(c, p, lv, batch));
+  PCHK(check_frame_poison(c));
   if (!pyramids || !kp || !desc || !counts) return fail(c, PISLAM_ERR_INVALID, "null pointer");
   if (stride < (size_t)p->rows * p->vstep) return fail(c, PISLAM_ERR_INVALID, "pyramid_stride too small");
   if (!is_device_ptr(pyramids) || !is_device_ptr(kp) || !is_device_ptr(desc) || !is_device_ptr(counts))
@@ -1999,6 +2053,8 @@ PISLAM_EXPORT int pislam_frontend_last_stats(pislam_ctx *c, uint32_t stats[2]) {
   stats[0] = stats[1] = 0;
   if (!c->w_ovf.p || !c->last_strips) return PISLAM_OK;      // staged pipeline / separate-tile layout: nothing deferred
   HIPCHK(c, hipSetDevice(c->device));
+  PCHK(sync(c));
+  PCHK(check_frame_poison(c));
   uint32_t prev[pislam_ctx::MAX_SUB] = {};
   for (int i = 0; i < c->ovf_nsub; i++)          // one list per sub-batch: [1] = strips the last step deferred
     HIPCHK(c, hipMemcpyAsync(&prev[i], c->w_ovf.as<uint32_t>() + (size_t)i * c->ovf_stride + 1, sizeof(uint32_t),
@@ -2166,6 +2222,9 @@ struct LaneCall {
                                        // whose overflow-list layouts differ) stop being captured after 3 — each invalidation costs a
                                        // stream drain, an eager run and a recapture, more than the graph ever returns
   unsigned long long last_use = 0;
+  unsigned path = 0;                   // pislam_frontend_last_path of the captured call (a replay restores it)
+  int pipeline_kind = 0;
+  uint32_t strips = 0;
   bool same(const pislam_frontend_params *q, const pislam_level *l, const uint8_t *py, size_t st, int b, uint32_t *k,
             uint32_t *d, uint32_t *c) const {
     return pyramids == py && stride == st && batch == b && kp == k && desc == d && counts == c &&
@@ -2308,7 +2367,11 @@ PISLAM_EXPORT int pislam_pipeline_submit(pislam_pipeline *q, const pislam_fronte
       return PISLAM_ERR_HIP;
     }
   }
-  int rc = PISLAM_OK;
+  int rc = check_frame_poison(c);      // (a one-launch call of this lane timed out: reported once, graphs dropped below)
+  if (rc != PISLAM_OK) {
+    q->err = c->err;
+    return rc;
+  }
   LaneCall *hit = nullptr;
   if (q->use_graphs && p && lv && p->nlevels >= 1 && p->nlevels <= 16) {
     auto &v = q->calls[li];
@@ -2362,6 +2425,9 @@ PISLAM_EXPORT int pislam_pipeline_submit(pislam_pipeline *q, const pislam_fronte
         q->n_capture_failed++;
       } else {
         hit->ws_gen = c->workspace_generation();
+        hit->path = c->last_path;
+        hit->pipeline_kind = c->last_pipeline;
+        hit->strips = c->last_strips;
         q->n_captured++;
       }
     }
@@ -2374,6 +2440,9 @@ PISLAM_EXPORT int pislam_pipeline_submit(pislam_pipeline *q, const pislam_fronte
       return PISLAM_ERR_HIP;
     }
     c->timing_valid = false;           // (the timing events were recorded inside the captured call)
+    c->last_path = hit->path;          // what pislam_frontend_last_path / last_stats report is the replayed call's
+    c->last_pipeline = hit->pipeline_kind;
+    c->last_strips = hit->strips;
     q->n_replayed++;
   } else {
     rc = pislam_orb_frontend_batch(c, p, lv, pyramids, stride, batch, kp, desc, counts);
@@ -2419,7 +2488,8 @@ PISLAM_EXPORT int pislam_pipeline_stats(const pislam_pipeline *q, uint64_t stats
 PISLAM_EXPORT int pislam_pipeline_synchronize(pislam_pipeline *q) {
   if (!q) return PISLAM_ERR_INVALID;
   for (auto *c : q->lane) {
-    const int rc = sync(c);
+    int rc = sync(c);
+    if (rc == PISLAM_OK) rc = check_frame_poison(c);
     if (rc != PISLAM_OK) {
       q->err = c->err;
       return rc;

@@ -320,6 +320,8 @@ class OrbFrontend:
         return float(tot.value), [float(v) for v in st]
 
     PATH_STAGED, PATH_FUSED, PATH_ONE_LAUNCH, PATH_BUCKET_SELECT, PATH_BUCKETS_IN_STRIPS, PATH_GENERIC_ORB = 1, 2, 4, 8, 16, 32
+    PATH_FRAME_TIMED_OUT = 64          # the one-launch path timed out earlier on this context: three launches from then on
+    COUNT_INVALID = 0xFFFFFFFF         # PISLAM_COUNT_INVALID: counts[i] of a pyramid a timed-out one-launch call did not produce
 
     def last_path_of(self, ctx) -> int:
         """last_path() of another context (a pipeline lane) that ran this front-end's parameters."""

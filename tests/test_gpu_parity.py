@@ -127,6 +127,86 @@ def test_one_launch_path_on_reference_demo_pyramid(gpu_ctx, demo, orc, batch):
             check()
 
 
+def test_one_launch_timeout_is_reported_and_the_context_recovers(demo):
+    """The one-launch path's bounded wait (pf::k_frame): a strip workgroup that never publishes its hand-over (test hook
+    "frame_test": the first strip workgroup skips its release, the poll limit is 2^12) makes the gather + ORB workgroups of
+    that pyramid give up.  Nothing stale may be returned silently: counts[0] is PISLAM_COUNT_INVALID, the NEXT call on the
+    context fails once with PISLAM_ERR_HIP naming the time-out, and from then on the context takes three launches
+    (PISLAM_PATH_FRAME_TIMED_OUT) with the reference's results — also on a pipeline lane, whose captured one-launch graph
+    is dropped."""
+    import torch
+    from pislam_amd.capi import Context, Pipeline, PislamError
+    from pislam_amd.frontend import OrbFrontend
+    dev = torch.device("cuda:0")
+    img = demo["img"]
+    d_pyr = torch.from_numpy(np.stack([img, img[::-1].copy()])).to(dev)
+    ctx = Context(device=0)
+    fe = OrbFrontend(demo["levels"], vstep=640, rows=2210, max_keypoints=4096, ctx=ctx)
+    kp, desc, counts = fe.alloc_outputs(2, dev)
+
+    def good(k, d, c, b=0):
+        c_ = c.cpu().numpy().view(np.uint32)
+        return c_[b] == 1754 and sha16(k.cpu().numpy().view(np.uint32)[b, :1754]) == SURVEY_PINS["kp"] and \
+            sha16(d.cpu().numpy().view(np.uint32)[b, :1754]) == SURVEY_PINS["desc"]
+
+    fe(d_pyr, kp, desc, counts)                         # a healthy one-launch call first
+    ctx.synchronize()
+    assert fe.last_path() & fe.PATH_ONE_LAUNCH and good(kp, desc, counts)
+    ctx.set_option("frame_test", 1 | (12 << 8))
+    counts.fill_(7)
+    fe(d_pyr, kp, desc, counts)                         # pyramid 0's hand-over never completes
+    torch.cuda.synchronize()
+    c = counts.cpu().numpy().view(np.uint32)
+    assert c[0] == fe.COUNT_INVALID, c                  # (pyramid 1 of the same launch is complete and correct)
+    ctx.set_option("frame_test", 0)
+    with pytest.raises(PislamError, match="timed out"):
+        fe(d_pyr, kp, desc, counts)                     # reported once, state reset
+    for rep in range(2):
+        for t in (kp, desc, counts):
+            t.zero_()
+        fe(d_pyr, kp, desc, counts)
+        ctx.synchronize()
+        assert not (fe.last_path() & fe.PATH_ONE_LAUNCH) and (fe.last_path() & fe.PATH_FRAME_TIMED_OUT)
+        assert good(kp, desc, counts)
+    ctx.set_option("frame_rearm", 1)                    # the path can be taken again (its counters were reset)
+    for t in (kp, desc, counts):
+        t.zero_()
+    fe(d_pyr, kp, desc, counts)
+    ctx.synchronize()
+    assert fe.last_path() & fe.PATH_ONE_LAUNCH and good(kp, desc, counts)
+    # ... and reported by pislam_ctx_synchronize when no further call follows
+    ctx.set_option("frame_test", 1 | (12 << 8))
+    fe(d_pyr, kp, desc, counts)
+    with pytest.raises(PislamError, match="timed out"):
+        ctx.synchronize()
+    ctx.set_option("frame_test", 0)
+    # a pipeline lane: eager, captured, replayed — then the time-out: the next submit fails once, the graph is dropped,
+    # later submits run as three launches
+    pipe = Pipeline(device=0, depth=1)
+    one = d_pyr[:1]
+    k1, d1, c1 = fe.alloc_outputs(1, dev)
+    for rep in range(4):
+        pipe.submit(fe.params, fe.levels, one, k1, d1, c1)
+    pipe.synchronize()
+    assert pipe.stats()["replayed_from_graphs"] >= 1 and good(k1, d1, c1)
+    assert fe.last_path_of(pipe.lane(0)) & fe.PATH_ONE_LAUNCH
+    pipe.set_option("frame_test", 1 | (12 << 8))        # (drops the captured calls: the next two run eagerly, then capture)
+    pipe.submit(fe.params, fe.levels, one, k1, d1, c1)
+    torch.cuda.synchronize()
+    assert c1.cpu().numpy().view(np.uint32)[0] == fe.COUNT_INVALID
+    pipe.set_option("frame_test", 0)
+    with pytest.raises(PislamError, match="timed out"):
+        pipe.submit(fe.params, fe.levels, one, k1, d1, c1)
+    for rep in range(4):
+        c1.zero_()
+        pipe.submit(fe.params, fe.levels, one, k1, d1, c1)
+        pipe.synchronize()
+        assert good(k1, d1, c1)
+        p_ = fe.last_path_of(pipe.lane(0))
+        assert not (p_ & fe.PATH_ONE_LAUNCH) and (p_ & fe.PATH_FRAME_TIMED_OUT), p_
+    pipe.close()
+
+
 def test_batch_path_on_reference_demo_pyramid(gpu_ctx, demo, pipeline, frame):
     import torch
     from pislam_amd.frontend import OrbFrontend
