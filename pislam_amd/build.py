@@ -14,11 +14,21 @@ LIB = os.path.join(LIBDIR, "libpislam_hip.so")
 _LIB_OVERRIDE = os.environ.get("PISLAM_HIP_LIB")
 if _LIB_OVERRIDE:
     LIB = os.path.abspath(_LIB_OVERRIDE)
+_override_announced = False
+
+
+def check_override() -> None:
+    """Called once by capi.load(): the override must exist (it is never built) and is announced on stderr — once per
+    process, not at import time (bench worker processes import this module without ever loading the library)."""
+    global _override_announced
+    if not _LIB_OVERRIDE or _override_announced:
+        return
     if not os.path.exists(LIB):
         raise RuntimeError(f"PISLAM_HIP_LIB={_LIB_OVERRIDE}: no such library (the override is never built; unset it or run "
                            "tools/ab_build.sh)")
     import sys as _sys
     print(f"[pislam_amd] PISLAM_HIP_LIB override: loading {LIB} instead of the in-tree build", file=_sys.stderr)
+    _override_announced = True
 SOURCES = ["pislam_hip.hip"]
 
 

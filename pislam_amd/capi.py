@@ -117,6 +117,7 @@ def load(rebuild_if_stale: bool = True):
         import torch  # noqa: F401
     except ImportError:
         pass
+    _build.check_override()              # PISLAM_HIP_LIB (development A/B): must exist, announced once
     path = _build.LIB
     if rebuild_if_stale:
         try:

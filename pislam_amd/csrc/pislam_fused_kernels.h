@@ -38,7 +38,7 @@
 #define PISLAM_DIAG 1         // pretest also requires two adjacent DIAGONAL ring points (3/7/11/15) of one polarity
 #endif
 #ifndef PISLAM_ORB_PITCH_DW
-#define PISLAM_ORB_PITCH_DW 13   // dwords per ORB patch row in LDS (12 = round 1-5: 48-byte rows skewed by a dword per 8 rows)
+#define PISLAM_ORB_PITCH_DW 12   // dwords per ORB patch row in LDS (12 = round 1-5: 48-byte rows skewed by a dword per 8 rows)
 #endif
 
 namespace pf {
@@ -180,7 +180,8 @@ constexpr int OWAVES = 4;                           // waves per k_gather_orb wo
 // of 32 lanes fell on 8 banks).  (A pitch of 12 dwords alone puts rows r, r+8, r+16, r+24 on the same banks.)
 constexpr int ORB_PITCH = 4 * PISLAM_ORB_PITCH_DW;
 __host__ __device__ constexpr int orb_row_ofs(int r) { return PISLAM_ORB_PITCH_DW == 12 ? r * 48 + 4 * (r >> 3) : r * ORB_PITCH; }
-constexpr int ORB_PATCH_BYTES = 32 * ORB_PITCH + 32;   // 31 rows (+1 idle) + slack for the byte shift
+// 31 rows (the idle lane's row 31 reads harmless bytes of whatever follows) + slack for the byte shift, a multiple of 16
+constexpr int ORB_PATCH_BYTES = PISLAM_ORB_PITCH_DW == 12 ? 32 * 48 + 32 : (31 * ORB_PITCH + 4 + 15) / 16 * 16;
 
 // Sum over each 32-lane half of the wave, result in every lane of that half.  DPP row shifts
 // (zero fill) leave each 16-lane row's sum in its last lane, row_bcast:15 folds row 0 into row 1 and
@@ -1315,6 +1316,7 @@ __device__ __forceinline__ void strips_role(const FusedParams &P, const uint8_t 
     t_wg = clock64();
   }
   bool carry = false, pf_have = false;
+  unsigned long long redo = 0;                      // (INLINE_OVF) strips of this run to redo with the plain layout
   u32x4 pf[PF_MAX];
 #pragma unroll
   for (int k = 0; k < PF_MAX; k++) pf[k] = (u32x4)(0u);
@@ -1345,16 +1347,8 @@ __device__ __forceinline__ void strips_role(const FusedParams &P, const uint8_t 
                                     stage_kp, strip_count, score_dump, score_stride, carry, tid_o, prof, pf, pf_have, s + 1 < s1,
                                     pf_have, ovf, INLINE_OVF ? 0xffffffffu : ((uint32_t)pyr << 16) | (uint32_t)(L.strip0 + s), stage_desc,
                                     pyramids + (size_t)pyr * pyr_stride, (uint32_t)((size_t)P.rows * P.vstep));
-    if (INLINE_OVF && ALIAS && deferred) {
-      // k_frame: a strip whose queues overflowed is redone right here with the plain layout and its scan fallbacks
-      // (what k_fused_overflow does in the three-launch path); the launch's dynamic LDS covers both layouts
-      lds_barrier();
-      const StripLds m2 = strip_lds<false>(smem, L);
-      bool d2 = false, issued = false;
-      strip_body<VEC16, HOOKS, false, false, true>(A, L, pyr, s, ys, ye, m2.tile, m2.sc, m2.queues, m2.shq, sh_ctr, sh_ctr, d2, im, lim,
-                                      stage_kp, strip_count, score_dump, score_stride, false, tid_o, nullptr, pf, false, false,
-                                      issued, nullptr, 0u, nullptr, nullptr, 0u);
-    }
+    // k_frame: a strip whose queues overflowed is redone by this workgroup with the plain layout, AFTER the run (below)
+    if (INLINE_OVF && ALIAS && deferred) redo |= 1ull << (s - s0);
     if (s + 1 < s1) {
       if (OVL && !(HOOKS && (P.ablate & 0xfbf))) {   // (ablations that cut phases keep the barriers)
         // a deferred strip left the body early (its waves are not aligned on a barrier) and leaves no scores: the next
@@ -1371,6 +1365,32 @@ __device__ __forceinline__ void strips_role(const FusedParams &P, const uint8_t 
     }
   }
   if (HOOKS && prof && threadIdx.x == 0) prof[7] += (unsigned long long)(clock64() - t_wg);
+  // k_frame: the strips of this run whose queues overflowed (dense noise, checkerboards) are redone here with the plain
+  // layout and its scan fallbacks — what k_fused_overflow does in the three-launch path; the launch's dynamic LDS covers
+  // both layouts.  A loop of its own BEHIND the run: inlined into the run's loop body (round 5) the second strip body
+  // cost k_frame 42 spilled SGPRs and a private segment on its hot path.
+  if (INLINE_OVF && ALIAS) {
+    redo = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)redo)) |
+           ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(redo >> 32)) << 32);
+    while (redo) {
+      const int s = s0 + __builtin_ctzll(redo);
+      redo &= redo - 1;
+      lds_barrier();
+      int li_o = li, tid_o = (int)threadIdx.x;
+      asm volatile("" : "+s"(li_o));
+      asm volatile("" : "+v"(tid_o));
+      const FusedLevel L = P.lv[li_o];
+      const StripLds m2 = strip_lds<false>(smem, L);
+      const uint8_t *im = pyramids + (size_t)pyr * pyr_stride + (size_t)L.row0 * P.vstep + L.col0;
+      const ptrdiff_t lim = (ptrdiff_t)P.rows * P.vstep - ((ptrdiff_t)L.row0 * P.vstep + L.col0);
+      const StripArgs A{P.border, P.thr, 0, 0, P.lbs, P.limit, P.vstep, P.slots_per_pyr, P.strips_per_pyr, P.hthr, P.words, 0};
+      const int ys = A.border + s * L.R, ye = min(ys + L.R, L.h - A.border);
+      bool d2 = false, issued = false;
+      strip_body<VEC16, false, false, false, true>(A, L, pyr, s, ys, ye, m2.tile, m2.sc, m2.queues, m2.shq, sh_ctr, sh_ctr, d2, im, lim,
+                                                   stage_kp, strip_count, nullptr, 0, false, tid_o, nullptr, pf, false, false, issued,
+                                                   nullptr, 0u, nullptr, nullptr, 0u);
+    }
+  }
 }
 
 template <bool VEC16, bool HOOKS, bool ALIAS, bool ORBK = false, bool BUCK = true>
