@@ -123,6 +123,13 @@ struct pislam_ctx {
   bool frame_disabled = false;       // a timeout was seen: the context takes the three-launch path from then on
   unsigned long long frame_timeouts = 0;   // (counted into workspace_generation: graphs holding a k_frame node are dropped)
   int opt_frame_test = 0;            // test hook: bit 0 = one strip workgroup skips its release, bits 8.. = log2 poll limit
+  // pyramid build: all reductions in one launch (pp::k_bilinear_chain) — band counters + [done, sticky fault]; the host-mapped
+  // fault word is frame_flag[1]
+  DevBuf w_chain;
+  size_t chain_words = 0;            // counters the last build laid out (a different layout starts from zeros)
+  bool chain_disabled = false;
+  int opt_build_chain = 0;           // 1: pislam_pyramid_build_batch runs levels 1.. as ONE launch (pp::k_bilinear_chain); 0 (default): one
+                                     // launch per level — measured faster: 150 against 166 us per 64 720p frames (docs/experiments.md)
   int num_cus = 0;
   int opt_pipeline = 0;      // 0 auto, 1 staged (one launch group per level), 2 fused strips
   int opt_dump_score = 0;    // fused pipeline: also materialise the score map (parity hook)
@@ -174,7 +181,7 @@ struct pislam_ctx {
   unsigned long long workspace_generation() const {
     unsigned long long g = ovf_layouts + table_uploads + frame_timeouts;
     for (const DevBuf *b : {&w_cnt, &w_off, &w_total, &w_cellkp, &w_score, &w_stage, &w_stripcnt, &w_work, &w_prof,
-                            &w_ovf, &w_stagedesc, &w_ustage, &w_ucount, &w_sync})
+                            &w_ovf, &w_stagedesc, &w_ustage, &w_ucount, &w_sync, &w_chain})
       g += b->reallocs;
     return g;
   }
@@ -256,6 +263,52 @@ int launch_ok(pislam_ctx *c, const char *what) {
 }
 
 inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+// ---- the in-grid hand-overs' safety net (pf::k_frame, pp::k_bilinear_chain) --------------------------------------------
+// Both kernels contain workgroups that WAIT for other workgroups of the same grid; the waits are bounded, and a workgroup
+// that gives up raises a sticky flag in device memory and a word of this host-mapped block (frame_flag[0]: k_frame,
+// frame_flag[1]: the build chain), which every call on the context reads first — a plain host load: no synchronisation.
+int ensure_fault_flag(pislam_ctx *c) {
+  if (c->frame_flag) return PISLAM_OK;
+  void *h = nullptr, *d = nullptr;
+  if (hipHostMalloc(&h, 64, hipHostMallocMapped) != hipSuccess || hipHostGetDevicePointer(&d, h, 0) != hipSuccess) {
+    (void)hipGetLastError();
+    if (h) (void)hipHostFree(h);
+    return fail(c, PISLAM_ERR_NOMEM, "hipHostMalloc(fault flag)");
+  }
+  c->frame_flag = (uint32_t *)h;
+  c->frame_flag_dev = (uint32_t *)d;
+  ((volatile uint32_t *)c->frame_flag)[0] = 0;
+  ((volatile uint32_t *)c->frame_flag)[1] = 0;
+  return PISLAM_OK;
+}
+// Has a launch of this context given up waiting?  Called at the start of every batch call and pyramid build, by
+// pislam_pipeline_submit, pislam_ctx_synchronize, pislam_pipeline_synchronize and pislam_frontend_last_stats.  If so: drain
+// the stream, reset the hand-over counters, stop taking that one-launch path on this context (small batches run as three
+// launches / the build as one launch per level from now on; captured graphs that hold such a node are dropped through
+// workspace_generation) and report the failure ONCE.  The front-end calls that were affected have published
+// counts[pyr] = PISLAM_COUNT_INVALID in the caller's own buffer; a build that was affected left levels of its pyramids
+// unwritten — the error of THIS call is the notice.
+int check_frame_poison(pislam_ctx *c) {
+  if (!c->frame_flag) return PISLAM_OK;
+  volatile uint32_t *f = (volatile uint32_t *)c->frame_flag;
+  const bool frame = f[0] != 0, chain = f[1] != 0;
+  if (!frame && !chain) return PISLAM_OK;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (c->w_sync.p) HIPCHK(c, hipMemsetAsync(c->w_sync.p, 0, c->w_sync.cap, c->stream));
+  if (c->w_chain.p) HIPCHK(c, hipMemsetAsync(c->w_chain.p, 0, c->w_chain.cap, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  f[0] = f[1] = 0;
+  if (frame) c->frame_disabled = true;
+  if (chain) c->chain_disabled = true;
+  c->frame_timeouts++;
+  if (chain && !frame)
+    return fail(c, PISLAM_ERR_HIP, "the one-launch pyramid build (pp::k_bilinear_chain) gave up — a wait for a level's rows timed out, "
+                                   "or a frame's workgroups did not share one XCD: the pyramids of that build are invalid; this "
+                                   "context now builds one launch per level");
+  return fail(c, PISLAM_ERR_HIP, "the one-launch path (pf::k_frame) timed out waiting for its strip workgroups: the affected calls "
+                                 "wrote counts = PISLAM_COUNT_INVALID; this context now runs small batches as three launches");
+}
 
 // ---- launch helpers shared by the 4-call API and the staged batch path ----
 
@@ -447,7 +500,7 @@ PISLAM_EXPORT int pislam_ctx_destroy(pislam_ctx *c) {
   (void)hipStreamSynchronize(c->stream);
   for (DevBuf *b : {&c->s_img, &c->s_out, &c->s_pts, &c->s_desc, &c->s_misc, &c->s_rots, &c->s_tmp, &c->w_cnt,
                     &c->w_off, &c->w_total, &c->w_cellkp, &c->w_score, &c->w_stage, &c->w_stripcnt, &c->w_work, &c->w_prof, &c->w_ovf,
-                    &c->w_stagedesc, &c->w_ustage, &c->w_ucount, &c->w_sync})
+                    &c->w_stagedesc, &c->w_ustage, &c->w_ucount, &c->w_sync, &c->w_chain})
     b->release();
   for (auto *t : c->plan_tables) {
     t->dev.release();
@@ -539,8 +592,10 @@ PISLAM_EXPORT int pislam_ctx_set_option(pislam_ctx *c, const char *key, int valu
     c->opt_frame = value;
   } else if (!strcmp(key, "frame_test")) {   // test hook of the one-launch path's bounded wait (see pf::k_frame `test`)
     c->opt_frame_test = value;
-  } else if (!strcmp(key, "frame_rearm")) {  // 1: take the one-launch path again after a reported timeout (tests)
-    if (value) c->frame_disabled = false;
+  } else if (!strcmp(key, "frame_rearm")) {  // 1: take the one-launch paths again after a reported timeout (tests)
+    if (value) c->frame_disabled = c->chain_disabled = false;
+  } else if (!strcmp(key, "build_chain")) {  // pyramid build: 1 = levels 1.. in ONE launch (pp::k_bilinear_chain), 0 (default) one launch per level
+    c->opt_build_chain = value != 0;
   } else if (!strcmp(key, "orb_in_strip")) {
     c->opt_orb_in_strip = value != 0;
   } else if (!strcmp(key, "bucket_select")) {
@@ -568,9 +623,6 @@ PISLAM_EXPORT int pislam_ctx_set_option(pislam_ctx *c, const char *key, int valu
   return PISLAM_OK;
 }
 
-namespace {
-int check_frame_poison(pislam_ctx *c);
-}
 PISLAM_EXPORT int pislam_ctx_synchronize(pislam_ctx *c) {
   if (!c) return PISLAM_ERR_INVALID;
   PCHK(sync(c));
@@ -917,6 +969,7 @@ PISLAM_EXPORT int pislam_pyramid_build_batch(pislam_ctx *c, int nlevels, const i
     return fail(c, PISLAM_ERR_INVALID, "bad argument");
   if (!is_device_ptr(frames) || !is_device_ptr(pyramids))
     return fail(c, PISLAM_ERR_INVALID, "the pyramid builder takes device pointers only");
+  PCHK(check_frame_poison(c));
   for (int l = 0; l < nlevels; l++) {
     const int pad = l + 1 < nlevels ? (steps[l] == 1 ? 8 : 16) : 1;
     const int wp = (levels[l].width + pad - 1) / pad * pad, hp = (levels[l].height + pad - 1) / pad * pad;
@@ -996,15 +1049,66 @@ PISLAM_EXPORT int pislam_pyramid_build_batch(pislam_ctx *c, int nlevels, const i
   //  work items, a device-scope fence + barrier between levels — was built in round 4, bit-exact, and measured: the step of
   //  64 720p frames 0.375 -> 0.53 ms from level 3 on, 0.59 ms from level 2 on: 64 workgroups with a handful of dependent
   //  load -> compute -> store round trips each are far slower than five launches that fill the chip, launch floors included.)
-  for (int l = 0; l + 1 < nlevels; l++) {
-    const uint8_t *src = pyramids + (size_t)levels[l].row0 * vstep;
-    uint8_t *dst = pyramids + (size_t)levels[l + 1].row0 * vstep;
-    const int w = levels[l].width, h = levels[l].height;
-    if (steps[l] == 1)
-      PCHK((launch_bilinear<8, 7>(c, src, dst, vstep, vstep, pyramid_stride, pyramid_stride, batch, w, h)));
-    else
-      PCHK((launch_bilinear<16, 13>(c, src, dst, vstep, vstep, pyramid_stride, pyramid_stride, batch, w, h)));
+  // Round 6: ALL reductions as one launch with a row-band hand-over between the levels (pp::k_bilinear_chain) — the same
+  // work items as the per-level launches, every workgroup starting as soon as the source rows it reads are complete.
+  bool chain = c->opt_build_chain && !c->chain_disabled && nlevels >= 3;
+  pp::ChainPlan C;
+  memset(&C, 0, sizeof(C));
+  if (chain) {
+    chain = (uintptr_t)pyramids % 16 == 0 && vstep % 16 == 0 && pyramid_stride % 16 == 0;   // k_bilinear4's fast path, every level
+    C.nlevels = nlevels;
+    C.vstep = vstep;
+    C.batch = batch;
+    C.groups = cdiv(batch, 8);
+    long wg = 0;
+    int bands = 0;
+    for (int l = 1; l < nlevels && chain; l++) {
+      const int N = steps[l - 1] == 1 ? 8 : 16, M = steps[l - 1] == 1 ? 7 : 13;
+      const int sw = levels[l - 1].width, sh = levels[l - 1].height;
+      const int nbx = cdiv(sw, N), nby = cdiv(sh, N);
+      if ((ptrdiff_t)cdiv(nbx, 4) * 4 * N > vstep) chain = false;      // the last group's 16-byte loads must stay in the row
+      C.kind[l] = steps[l - 1];
+      C.row0[l] = levels[l].row0;
+      C.sw[l] = sw;
+      C.sh[l] = sh;
+      C.nq[l] = cdiv(nbx, 4);
+      C.oh[l] = nby * M;
+      C.wpf[l] = cdiv(C.nq[l] * C.oh[l], 256);
+      C.wg0[l] = (int)wg;
+      wg += 8L * C.wpf[l] * C.groups;                 // (frame = 8 g + b % 8: one XCD per frame, see the kernel)
+      C.band0[l] = bands;
+      bands += cdiv(C.oh[l], pp::CH_BAND);
+    }
+    C.row0[0] = levels[0].row0;
+    C.bands_per_frame = bands;
+    C.wg0[nlevels] = (int)wg;
+    if (wg > 0x3fffffffL) chain = false;
+    if (chain) {
+      const size_t words = pp::chain_words((size_t)batch, (size_t)bands, (size_t)C.groups);
+      bool grew = false;
+      if (c->w_chain.ensure(sizeof(uint32_t) * words, &grew) != PISLAM_OK) return fail(c, PISLAM_ERR_NOMEM, "hipMalloc(build chain counters)");
+      if (grew || c->chain_words != words) {
+        // (a different layout puts [done, fault] elsewhere: start from zeros — stream order puts this behind any launch in flight)
+        HIPCHK(c, hipMemsetAsync(c->w_chain.p, 0, c->w_chain.cap, c->stream));
+        if (!grew && c->chain_words != 0) c->ovf_layouts++;   // (a captured build holds the old layout: workspace_generation)
+        c->chain_words = words;
+      }
+      PCHK(ensure_fault_flag(c));
+      hipLaunchKernelGGL(pp::k_bilinear_chain, dim3((unsigned)wg), dim3(256), 0, c->stream, C, pyramids, pyramid_stride,
+                         c->w_chain.as<uint32_t>(), c->frame_flag_dev + 1, (uint32_t)c->opt_frame_test);
+      PCHK(launch_ok(c, "k_bilinear_chain"));
+    }
   }
+  if (!chain)
+    for (int l = 0; l + 1 < nlevels; l++) {
+      const uint8_t *src = pyramids + (size_t)levels[l].row0 * vstep;
+      uint8_t *dst = pyramids + (size_t)levels[l + 1].row0 * vstep;
+      const int w = levels[l].width, h = levels[l].height;
+      if (steps[l] == 1)
+        PCHK((launch_bilinear<8, 7>(c, src, dst, vstep, vstep, pyramid_stride, pyramid_stride, batch, w, h)));
+      else
+        PCHK((launch_bilinear<16, 13>(c, src, dst, vstep, vstep, pyramid_stride, pyramid_stride, batch, w, h)));
+    }
   return PISLAM_OK;
 }
 
@@ -1498,36 +1602,8 @@ int ensure_frame_sync(pislam_ctx *c) {
   if (c->w_sync.ensure(sizeof(uint32_t) * pf::FRAME_SYNC_WORDS, &grew) != PISLAM_OK)
     return fail(c, PISLAM_ERR_NOMEM, "hipMalloc(frame sync)");
   if (grew) HIPCHK(c, hipMemsetAsync(c->w_sync.p, 0, c->w_sync.cap, c->stream));   // (the kernel re-arms them itself)
-  if (!c->frame_flag) {
-    void *h = nullptr, *d = nullptr;
-    if (hipHostMalloc(&h, 64, hipHostMallocMapped) != hipSuccess || hipHostGetDevicePointer(&d, h, 0) != hipSuccess) {
-      (void)hipGetLastError();
-      if (h) (void)hipHostFree(h);
-      return fail(c, PISLAM_ERR_NOMEM, "hipHostMalloc(frame flag)");
-    }
-    c->frame_flag = (uint32_t *)h;
-    c->frame_flag_dev = (uint32_t *)d;
-    *(volatile uint32_t *)c->frame_flag = 0;
-  }
-  return PISLAM_OK;
+  return ensure_fault_flag(c);
 }
-// Has a pf::k_frame launch of this context given up waiting (see the kernel)?  Called at the start of every batch call, by
-// pislam_pipeline_submit, pislam_ctx_synchronize and pislam_frontend_last_stats.  If so: drain the stream, reset the hand-over
-// counters, stop taking the one-launch path on this context (calls run as three launches from now on; captured graphs
-// that hold a k_frame node are dropped through workspace_generation) and report the failure ONCE — the calls that were
-// affected have published counts[pyr] = PISLAM_COUNT_INVALID in the caller's own buffer.
-int check_frame_poison(pislam_ctx *c) {
-  if (!c->frame_flag || *(volatile uint32_t *)c->frame_flag == 0) return PISLAM_OK;
-  HIPCHK(c, hipStreamSynchronize(c->stream));
-  HIPCHK(c, hipMemsetAsync(c->w_sync.p, 0, c->w_sync.cap, c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
-  *(volatile uint32_t *)c->frame_flag = 0;
-  c->frame_disabled = true;
-  c->frame_timeouts++;
-  return fail(c, PISLAM_ERR_HIP, "the one-launch path (pf::k_frame) timed out waiting for its strip workgroups: the affected calls "
-                                 "wrote counts = PISLAM_COUNT_INVALID; this context now runs small batches as three launches");
-}
-
 // `Fplan`: the strip plan, built for the largest sub-batch (sub_max pyramids).
 int run_fused(pislam_ctx *c, const pislam_frontend_params *p, const pf::FusedParams &Fplan, size_t lds, size_t lds_alias,
               const uint8_t *pyramids, size_t stride, int batch, int nsub, uint32_t *kp, uint32_t *desc, uint32_t *counts) {
@@ -1648,7 +1724,7 @@ int run_fused(pislam_ctx *c, const pislam_frontend_params *p, const pf::FusedPar
   if (c->frame_disabled) c->last_path |= PISLAM_PATH_FRAME_TIMED_OUT;
   if (alias && vec && !sel && Fplan.lbs == 0 && !hooks && !generic_orb && nsub == 1 && !Fplan.orb_in_strip &&
       c->opt_repeat_strips <= 1 && batch <= frame_max_batch(c) && !c->frame_disabled) {
-    const int fch = frame_chunks(batch);
+    const int fch = c->opt_orb_chunks > 0 ? std::min(c->opt_orb_chunks, 128) : frame_chunks(batch);
     const size_t fper = ((size_t)p->max_keypoints + fch - 1) / fch;
     const size_t flds = std::max(std::max(lds_alias, lds), pf::orb_lds_bytes(S, fper));
     // Occupancy gate: the gather + ORB workgroups WAIT inside the grid.  With `lanes_in_flight` such launches on the device

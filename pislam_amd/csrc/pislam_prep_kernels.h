@@ -168,15 +168,28 @@ __device__ __forceinline__ uint32_t bilinear_px(const uint8_t *__restrict__ s, i
 // bytes come in as 16-byte loads, the 4M outputs leave as M aligned dwords (4M = 28 or 52 bytes,
 // and 4 blocks start on a 4-byte boundary); the x loop is unrolled so every filter weight and
 // source column is an immediate.  Needs vstep % 16 == 0 and 16-byte aligned bases.
-template <int N, int M>
-__global__ __launch_bounds__(256) void k_bilinear4(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst,
-                                                   int vstep_src, int vstep_dst, size_t stride_src,
-                                                   size_t stride_dst, int width, int height) {
+// (the work of ONE lane: item t = (output row oy, group q of four source blocks) of one image — shared by k_bilinear4,
+//  one launch per level, and k_bilinear_chain, all levels of a pyramid build in one launch)
+// COH (k_bilinear_chain): the source rows were written by OTHER workgroups of the same grid, on the same XCD (the chain
+// keeps a frame on one XCD and checks it: see there).  Their plain stores sit in that XCD's L2, which is the coherence point
+// of its CUs; what a consumer must not do is hit its own CU's vector L1, which no other CU's store ever refreshes — so the
+// source comes in through 16-byte `sc1` loads (they bypass the L1 and are served by the L2 at the plain rate;
+// /opt/skills/guides/MI355X_MICROARCH.md, inter-workgroup visibility).  Measured alternatives, 64 720p frames, seven launches
+// = 108 us: ordinary accesses between an agent-scope release per band and an acquire per workgroup 1218 us (12 000 L2
+// write-backs and L1 invalidates); agent-scope relaxed atomics on both sides (8-byte loads, 4-byte write-through stores:
+// every dword its own fabric write) 1031 us.
+__device__ __forceinline__ g_u32x4 load16_sc1(const uint8_t *p) {
+  g_u32x4 v;
+  asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
+  return v;
+}
+template <int N, int M, bool COH = false>
+__device__ __forceinline__ void bilinear4_item(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, int vstep_src,
+                                               int vstep_dst, int width, int height, int t) {
   constexpr int F7[7] = {238, 201, 165, 128, 91, 55, 18};
   constexpr int F13[13] = {226, 167, 108, 49, 246, 187, 128, 69, 10, 207, 138, 89, 30};
   const int nbx = (width + N - 1) / N, nby = (height + N - 1) / N;
   const int nq = (nbx + 3) / 4, oh = nby * M;
-  const int t = blockIdx.x * 256 + threadIdx.x;       // flattened (output row, block group): no idle lanes
   const int oy = t / nq, q = t - oy * nq;
   if (oy >= oh) return;
   const int by = oy / M, y = oy - by * M;
@@ -188,20 +201,46 @@ __global__ __launch_bounds__(256) void k_bilinear4(const uint8_t *__restrict__ s
       fy0 = (M == 7) ? F7[k] : F13[k];
       fy1 = (M == 7) ? F7[M - 1 - k] : F13[M - 1 - k];
     }
-  const uint8_t *s0 = src + (size_t)blockIdx.z * stride_src + (ptrdiff_t)(by * N + sy) * vstep_src + q * 4 * N;
-  uint8_t *d = dst + (size_t)blockIdx.z * stride_dst + (ptrdiff_t)oy * vstep_dst + q * 4 * M;
+  const uint8_t *s0 = src + (ptrdiff_t)(by * N + sy) * vstep_src + q * 4 * N;
+  uint8_t *d = dst + (ptrdiff_t)oy * vstep_dst + q * 4 * M;
   constexpr int NV = 4 * N / 16;                     // 16-byte vectors per source row segment
   uint32_t r0[NV * 4], r1[NV * 4];
+  g_u32x4 ca[NV], cb[NV];
   const int vmax = ((nbx - 4 * q) * N + 15) / 16;    // vectors that exist (whole blocks only; padding is the caller's)
 #pragma unroll
   for (int v = 0; v < NV; v++) {
-    uint4 a = make_uint4(0, 0, 0, 0), b = a;
-    if (v < vmax) {
-      a = *(const uint4 *)(s0 + 16 * v);
-      b = *(const uint4 *)(s0 + vstep_src + 16 * v);
+    if (COH) {
+      // (asm loads: the compiler does not know their latency — all of them are issued first, ONE wait below covers them)
+      g_u32x4 a = (g_u32x4)(0u), b = (g_u32x4)(0u);
+      if (v < vmax) {
+        a = load16_sc1(s0 + 16 * v);
+        b = load16_sc1(s0 + vstep_src + 16 * v);
+      }
+      ca[v] = a;
+      cb[v] = b;
+    } else {
+      uint4 a = make_uint4(0, 0, 0, 0), b = a;
+      if (v < vmax) {
+        a = *(const uint4 *)(s0 + 16 * v);
+        b = *(const uint4 *)(s0 + vstep_src + 16 * v);
+      }
+      r0[4 * v] = a.x; r0[4 * v + 1] = a.y; r0[4 * v + 2] = a.z; r0[4 * v + 3] = a.w;
+      r1[4 * v] = b.x; r1[4 * v + 1] = b.y; r1[4 * v + 2] = b.z; r1[4 * v + 3] = b.w;
     }
-    r0[4 * v] = a.x; r0[4 * v + 1] = a.y; r0[4 * v + 2] = a.z; r0[4 * v + 3] = a.w;
-    r1[4 * v] = b.x; r1[4 * v + 1] = b.y; r1[4 * v + 2] = b.z; r1[4 * v + 3] = b.w;
+  }
+  if (COH) {
+    // the wait takes the loaded registers as operands: nothing that uses them can be scheduled in front of it
+    if constexpr (NV == 2) {
+      asm volatile("s_waitcnt vmcnt(0)" : "+v"(ca[0]), "+v"(ca[1]), "+v"(cb[0]), "+v"(cb[1])::"memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)"
+                   : "+v"(ca[0]), "+v"(ca[1]), "+v"(ca[2]), "+v"(ca[3]), "+v"(cb[0]), "+v"(cb[1]), "+v"(cb[2]), "+v"(cb[3])::"memory");
+    }
+#pragma unroll
+    for (int v = 0; v < NV; v++) {
+      r0[4 * v] = ca[v].x; r0[4 * v + 1] = ca[v].y; r0[4 * v + 2] = ca[v].z; r0[4 * v + 3] = ca[v].w;
+      r1[4 * v] = cb[v].x; r1[4 * v + 1] = cb[v].y; r1[4 * v + 2] = cb[v].z; r1[4 * v + 3] = cb[v].w;
+    }
   }
   // Horizontal filter: the two taps of an output are adjacent source bytes, so p0*f0 + p1*f1 + 128 is ONE
   // v_dot4_u32_u8 of the source dword with a constant weight word (f0, f1 at the taps' byte positions, zero
@@ -241,6 +280,183 @@ __global__ __launch_bounds__(256) void k_bilinear4(const uint8_t *__restrict__ s
     for (int k = 0; k < M; k++) *(uint32_t *)(d + 4 * k) = outw[k];
   } else {
     for (int i = 0; i < nb_here * M; i++) d[i] = (uint8_t)((outw[i >> 2] >> (8 * (i & 3))) & 0xffu);
+  }
+}
+
+template <int N, int M>
+__global__ __launch_bounds__(256) void k_bilinear4(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst,
+                                                   int vstep_src, int vstep_dst, size_t stride_src,
+                                                   size_t stride_dst, int width, int height) {
+  // flattened (output row, block group): no idle lanes
+  bilinear4_item<N, M>(src + (size_t)blockIdx.z * stride_src, dst + (size_t)blockIdx.z * stride_dst, vstep_src, vstep_dst, width,
+                       height, (int)(blockIdx.x * 256 + threadIdx.x));
+}
+
+// ---------------------------------------------------------------------------
+// k_bilinear_chain — EVERY reduction of a pyramid build (levels 1 .. n-1 of every frame of the batch) in ONE launch.
+// Level by level the build was seven dependent launches; the small levels move a few MB each and took ~15 us apiece
+// where ~3 us of work was in them: launch floor, ramp-up and tail, seven times.  Here the grid holds the work items of
+// all levels, level-major (all of level 1, then all of level 2, ...), and a workgroup of level l + 1 starts as soon as the
+// rows of level l it reads are complete — not when the whole level is:
+//   * level l's output rows are counted in BANDS of CH_BAND rows per frame: a workgroup that has stored its items adds,
+//     per band it touched, the number of items it finished there (all stores acknowledged by the L2, workgroup barrier,
+//     then ONE agent-scope add per band by thread 0); a band is complete when its counter holds rows x items-per-row;
+//   * a workgroup of level l + 1 computes the source rows its items read, polls those bands' counters (relaxed agent-scope
+//     loads, one lane per band), then — behind a workgroup barrier — runs its items (pp::bilinear4_item: the arithmetic of
+//     the one-launch-per-level kernel, bit for bit);
+//   * ONE XCD PER FRAME.  Per-XCD L2s are not coherent with each other, and the per-workgroup agent-scope release
+//     (L2 write-back) / acquire (L1 invalidate) that would make a cross-XCD hand-over visible cost more than the launches
+//     they replace (see bilinear4_item<COH>).  So all workgroups of a frame are placed on the same XCD — workgroup b of a
+//     level works on frame 8 g + b % 8, and blocks are dealt to XCDs round-robin — where the L2 is the common coherence point:
+//     plain stores + `sc1` loads, no cache maintenance at all.  That placement is an observation, not a contract, so it
+//     is VERIFIED: the first workgroup of a frame records its HW_REG_XCC_ID, every later one compares; a mismatch raises
+//     the fault flag (the library reports it at the next call and builds one launch per level from then on);
+//   * forward progress: workgroups are dispatched in blockIdx order and a workgroup only ever waits for workgroups with
+//     SMALLER indices, so the earliest unfinished workgroup is always resident with all its inputs complete.  Nothing
+//     documents that order either: the wait is bounded, a workgroup that gives up raises the same sticky flag (counter
+//     block + host-mapped fault word), and such a launch does not re-arm;
+//   * the launch's last workgroup re-arms the counters: a captured launch replays with no host-side reset.
+// Level 0 (the blurred frame) comes from the launch before this one (stream order): level 1 waits for nothing.
+// ---------------------------------------------------------------------------
+constexpr int CH_BAND = 16;
+struct ChainPlan {
+  int nlevels, vstep, batch, bands_per_frame;
+  int groups;                  // ceil(batch / 8) groups of eight frames (frame = 8 g + b % 8)
+  int wg0[17];                 // first workgroup of level l (1 .. nlevels-1), multiples of 8; wg0[nlevels] = grid size
+  // (Launch order: level-major.  Ordering by diagonals d = g + l - 1 — group g's level l + 1 one step behind its level l, so
+  //  that the small levels of the early groups run beside the big levels of the late ones instead of all at the end — was
+  //  measured: 202 us per 64-frame build against 166: consumers then sit right behind their producers in the dispatch order,
+  //  and a waiting workgroup holds a slot.)
+  int wpf[16];                 // workgroups per frame of level l
+  int kind[16];                // the reduction INTO level l: 1 = 7/8, 2 = 13/16
+  int row0[16];                // pyramid row of level l
+  int sw[16], sh[16];          // width / height of level l - 1 (the source of the reduction into level l)
+  int nq[16], oh[16];          // level l: items per output row, output rows written
+  int band0[16];               // index (within a frame's block) of level l's first band counter
+};
+// ctr: [batch][bands_per_frame] band counters (rounded up to a 128-byte line), then — every word on a 128-byte line of its
+// own (CH_LINE dwords apart) — [0] sticky fault (a wait timed out / a frame met two XCDs), [1] shards complete,
+// [2 .. 2 + CH_SHARDS) workgroups done per shard, [2 + CH_SHARDS ..) the XCD of each frame + 1 (0 = not yet known).  All
+// zero between launches (the fault word: until the host has seen it).
+// (Measured, 64 720p frames: ONE done counter next to the fault word every poller reads and the per-frame XCD words every
+//  workgroup reads made the kernel 837 us; without the done counter 134 us — 12 500 returning atomics on a line that 12 500
+//  other accesses want.  Hence the shards and the lines.)
+constexpr int CH_LINE = 32, CH_SHARDS = 64;
+__host__ __device__ constexpr size_t chain_tail_ofs(size_t batch, size_t bands_per_frame) {
+  return (batch * bands_per_frame + CH_LINE - 1) / CH_LINE * CH_LINE;
+}
+__host__ __device__ constexpr size_t chain_words(size_t batch, size_t bands_per_frame, size_t groups) {
+  return chain_tail_ofs(batch, bands_per_frame) + (2 + CH_SHARDS + 8 * groups) * CH_LINE;
+}
+__global__ __launch_bounds__(256) void k_bilinear_chain(const ChainPlan C, uint8_t *__restrict__ pyramids, size_t stride,
+                                                        uint32_t *__restrict__ ctr, uint32_t *__restrict__ hflag,
+                                                        uint32_t test) {
+  __shared__ uint32_t sh_ok;
+  int l = 1;
+  while (l + 1 < C.nlevels && (int)blockIdx.x >= C.wg0[l + 1]) l++;
+  const int b = (int)blockIdx.x - C.wg0[l];
+  const int rest = b >> 3, g = rest / C.wpf[l], chunk = rest - g * C.wpf[l];
+  const int frame = 8 * g + (b & 7);
+  const int tid = threadIdx.x;
+  const int nq = C.nq[l], oh = C.oh[l], nitems = nq * oh;
+  const int t0 = chunk * 256, t1 = min(t0 + 256, nitems) - 1;       // this workgroup's items [t0, t1]
+  uint32_t *tail = ctr + chain_tail_ofs(C.batch, C.bands_per_frame);
+  uint32_t *fault = tail, *top = tail + CH_LINE, *shard = tail + (2 + ((int)blockIdx.x & (CH_SHARDS - 1))) * CH_LINE;
+  uint32_t *home = tail + (2 + CH_SHARDS) * CH_LINE;
+  const int N = C.kind[l] == 1 ? 8 : 16, M = C.kind[l] == 1 ? 7 : 13;
+  const bool idle = frame >= C.batch;               // (the batch is padded to whole groups of eight frames)
+  uint32_t *fctr = ctr + (size_t)(idle ? 0 : frame) * C.bands_per_frame;
+  if (tid == 0) sh_ok = 1;
+  __syncthreads();
+  if (!idle) {
+    if (tid == 32 && !(test & 32u)) {
+      // one XCD per frame (see above): HW_REG_XCC_ID (id 20), bits 3:0
+      const uint32_t me = (__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 15u) + 1u + ((test & 2u) && blockIdx.x == 9 ? 1u : 0u);
+      uint32_t seen = __hip_atomic_load(&home[frame * CH_LINE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (seen == 0) {
+        uint32_t expect = 0;
+        if (!__hip_atomic_compare_exchange_strong(&home[frame * CH_LINE], &expect, me, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+          seen = expect;
+        else
+          seen = me;
+      }
+      if (seen != me) {
+        __hip_atomic_store(fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(hflag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        sh_ok = 0;
+      }
+    }
+    if (l > 1) {
+      // source rows of the items' output rows oy0 .. oy1 (level l - 1): block row * N + sy .. + 1; rows the producer never
+      // writes (block padding / zero margins below its last written row) are nobody's output
+      const int oy0 = t0 / nq, oy1 = t1 / nq;
+      const int y0 = oy0 % M, y1 = oy1 % M;
+      const int r_lo = (oy0 / M) * N + (M == 7 ? y0 : y0 + (y0 > 3) + (y0 > 8));
+      const int r_hi = min((oy1 / M) * N + (M == 7 ? y1 : y1 + (y1 > 3) + (y1 > 8)) + 1, C.oh[l - 1] - 1);
+      const int b_lo = r_lo / CH_BAND, b_hi = r_hi / CH_BAND;
+      if (tid <= b_hi - b_lo && r_lo <= r_hi && !(test & 4u)) {
+        const int band = b_lo + tid;
+        const uint32_t want = (uint32_t)(min(CH_BAND, C.oh[l - 1] - band * CH_BAND) * C.nq[l - 1]);
+        const uint32_t *p = fctr + C.band0[l - 1] + band;
+        bool ok = false;
+        const bool poisoned = __hip_atomic_load(fault, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+        const int limit = poisoned ? 0 : 1 << (((test >> 8) & 31u) ? ((test >> 8) & 31u) : 20u);   // (2^20 polls ~ 1 s)
+        for (int it = 0; it < limit; it++) {
+          if (__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= want) {
+            ok = true;
+            break;
+          }
+          __builtin_amdgcn_s_sleep(8);
+        }
+        // (no acquire fence: the items' loads bypass this CU's L1 themselves — bilinear4_item<COH> — and are issued
+        //  behind this poll's result in program order, behind the barrier below)
+        if (!ok) {
+          __hip_atomic_store(fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(hflag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          sh_ok = 0;
+        }
+      }
+    }
+    __syncthreads();
+    if (sh_ok == 0) return;                           // (workgroup-uniform; not counted as done: the launch never re-arms)
+    uint8_t *img = pyramids + (size_t)frame * stride;
+    const uint8_t *src = img + (size_t)C.row0[l - 1] * C.vstep;
+    uint8_t *dst = img + (size_t)C.row0[l] * C.vstep;
+    if (C.kind[l] == 1) bilinear4_item<8, 7, true>(src, dst, C.vstep, C.vstep, C.sw[l], C.sh[l], t0 + tid);
+    else bilinear4_item<16, 13, true>(src, dst, C.vstep, C.vstep, C.sw[l], C.sh[l], t0 + tid);
+    // every thread's stores have been acknowledged by the L2 before the barrier; the counter add behind it needs no
+    // release fence (which would write back this XCD's whole L2): the consumers read this L2
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+  if (tid == 0) {
+    if (!idle && l + 1 < C.nlevels && !((test & 1u) && blockIdx.x == 0) && !(test & 8u)) {
+      for (int band = (t0 / nq) / CH_BAND; band <= (t1 / nq) / CH_BAND; band++) {
+        const int lo = max(t0, band * CH_BAND * nq), hi = min(t1, (band + 1) * CH_BAND * nq - 1);
+        (void)__hip_atomic_fetch_add(&fctr[C.band0[l] + band], (uint32_t)(hi - lo + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    // done: CH_SHARDS counters (workgroup b -> shard b % CH_SHARDS); the arrival that completes a shard reports it to the
+    // top counter, the one that completes the top is the launch's last workgroup
+    uint32_t last = 0;
+    if (!(test & 16u)) {
+      const uint32_t sh_i = blockIdx.x & (CH_SHARDS - 1);
+      const uint32_t expect = (gridDim.x - sh_i + CH_SHARDS - 1) / CH_SHARDS;      // workgroups b < gridDim.x with b % CH_SHARDS == sh_i
+      const uint32_t done = __hip_atomic_fetch_add(shard, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (done + 1 == expect) {
+        const uint32_t nsh = min((uint32_t)CH_SHARDS, gridDim.x);
+        last = __hip_atomic_fetch_add(top, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1 == nsh;
+      }
+    }
+    sh_ok = last ? 2u : 1u;                           // 2: the launch's last workgroup — nobody polls any more
+  }
+  __syncthreads();
+  if (sh_ok == 2u) {
+    // re-arm, all 256 threads (ONE thread storing the 6 400 counters of a 64-frame build word by word took ~0.2 ms)
+    const int nb = (int)chain_tail_ofs(C.batch, C.bands_per_frame);
+    for (int i = tid; i < nb; i += 256) __hip_atomic_store(&ctr[i], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int i = 1 + tid; i < 2 + CH_SHARDS + 8 * C.groups; i += 256)               // (every line but the sticky fault word's)
+      __hip_atomic_store(&tail[i * CH_LINE], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 

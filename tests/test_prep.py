@@ -183,6 +183,77 @@ def test_pyramid_build_equals_reference_functions_in_sequence(gpu_ctx, orc):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(1280, 720, (2, 1, 2, 2, 1, 2, 2), 64), (640, 480, (2, 1, 2, 2, 1, 2, 2), 5), (333, 251, (1, 2, 1), 3),
+                                   (1920, 1080, (2, 2, 1, 2), 2)])
+def test_one_launch_build_equals_one_launch_per_level(gpu_ctx, shape):
+    """pp::k_bilinear_chain (every reduction of a build in ONE launch, row bands of level l handed to the workgroups of
+    level l + 1 through counters) writes the bytes of the one-launch-per-level build (option "build_chain" 0) — at the bench's
+    batch of 64 720p frames too — on frames that CHANGE between builds into the same buffer (a workgroup that started
+    before its source rows were complete, or read them from a stale cache line, would show the previous frames' pixels), and a
+    launch re-arms its own counters (five builds in a row, no host-side reset)."""
+    import torch
+    from pislam_amd.frontend import PyramidBuilder
+    w0, h0, steps, B = shape
+    rng = np.random.default_rng(w0 * 7 + B)
+    pb = PyramidBuilder(w0, h0, steps, ctx=gpu_ctx)
+    d_a = torch.zeros((B, pb.rows, pb.vstep), dtype=torch.uint8, device="cuda")
+    d_b = torch.zeros_like(d_a)
+    for rep in range(5):
+        base = rng.integers(0, 256, (min(B, 4), h0, w0), dtype=np.uint8)
+        frames = torch.from_numpy(base).cuda()[torch.arange(B, device="cuda") % base.shape[0]].contiguous()
+        if B > 4:
+            frames[B // 2:] = 255 - frames[B // 2:]          # (the second half of a large batch differs from the first)
+        gpu_ctx.set_option("build_chain", 1)
+        pb(frames, d_a, margins_clean=rep > 0)
+        gpu_ctx.set_option("build_chain", 0)
+        pb(frames, d_b, margins_clean=rep > 0)
+        torch.cuda.synchronize()
+        assert torch.equal(d_a, d_b), (shape, rep, torch.nonzero(d_a != d_b)[:4])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("hook", [1 | (12 << 8), 2], ids=["a-band-never-completes", "a-frame-meets-two-XCDs"])
+def test_one_launch_build_faults_are_reported_and_the_context_recovers(hook):
+    """The build chain's two safety nets (test hook "frame_test"): bit 0 — the first workgroup of level 1 never publishes its
+    rows, the poll limit is 2^12: a bounded wait expires; bit 1 — one workgroup pretends to run on another XCD than the
+    frame's first workgroup: the one-XCD-per-frame placement the hand-over through the L2 rests on is violated.  Either way
+    the next call on the context fails once naming the fault, after that the context builds one launch per level and the
+    result is the reference's again."""
+    import torch
+    from pislam_amd.capi import Context, PislamError
+    from pislam_amd.frontend import PyramidBuilder
+    ctx = Context(device=0)
+    pb = PyramidBuilder(640, 480, (2, 1, 2, 2), ctx=ctx)
+    rng = np.random.default_rng(3)
+    frames = torch.from_numpy(rng.integers(0, 256, (4, 480, 640), dtype=np.uint8)).cuda()
+    good = torch.zeros((4, pb.rows, pb.vstep), dtype=torch.uint8, device="cuda")
+    pyr = torch.zeros_like(good)
+    ctx.set_option("build_chain", 0)
+    pb(frames, good)
+    ctx.set_option("build_chain", 1)
+    pb(frames, pyr)
+    ctx.synchronize()
+    assert torch.equal(pyr, good)
+    ctx.set_option("frame_test", hook)
+    pb(frames, pyr)
+    ctx.set_option("frame_test", 0)
+    with pytest.raises(PislamError, match="one-launch pyramid build"):
+        ctx.synchronize()
+    for rep in range(2):
+        pyr.zero_()
+        pb(frames, pyr)
+        ctx.synchronize()
+        assert torch.equal(pyr, good)
+    ctx.set_option("frame_rearm", 1)                    # the one-launch build again (its counters were reset)
+    for rep in range(2):
+        pyr.zero_()
+        pb(frames, pyr)
+        ctx.synchronize()
+        assert torch.equal(pyr, good)
+    ctx.close()
+
+
+@pytest.mark.gpu
 def test_pyramid_build_flags_are_checked(gpu_ctx):
     """ABI 2: the last argument of pislam_pyramid_build_batch is a PISLAM_BUILD_* bitmask (ABI 1: `blur`, any non-zero
     value): unknown bits are refused instead of being read as flags, and PISLAM_BUILD_CHECK_MARGINS verifies a
