@@ -1355,6 +1355,29 @@ bool build_fused_plan_rows(const pislam_ctx *c, const pislam_frontend_params *p,
     const double per_slot = (double)strips * batch / (5.0 * std::max(1, c->num_cus));
     const double per_wg = c->lanes_in_flight > 1 ? 3.25 : 6.5;
     F->run_len = c->opt_run_len > 0 ? c->opt_run_len : std::max(1, std::min(8, (int)(per_slot / per_wg + 0.5)));
+    // Round 6, lanes only: the LONGEST runs that still leave the launch 0.6 workgroups per resident slot (5 per CU) — whole
+    // levels per workgroup where the batch is large enough.  Re-swept after the pretest change, pipelined step in ms for
+    // run_len default (the rule above) / 12 / 16 / 24 / 32 / 64: VGA batch 256 0.2117 / 0.2087 / 0.2062 / 0.2072 / 0.2063 / 0.2068
+    // (8 whole-level runs per pyramid = 1.6 per slot); demo photo 0.3169 / 0.3153 / 0.3153 / 0.3144 / 0.3143 / 0.3140; 1280x960
+    // 0.6692 / 0.6674 / 0.6628 / 0.6637 / 0.6517 / 0.6531; 720p build batch 64 0.2865 / 0.2759 / 0.2671 / 0.2581 / 0.2589 / 0.2590
+    // (15 runs per pyramid = 0.75 per slot); bucket mode 0.2334 / 0.2293 / 0.2285 / 0.2281 / 0.2287 / 0.2277 — and where the
+    // launch gets too few workgroups it turns: VGA batch 64 0.0646 / 0.0631 (0.6 per slot) / 0.0681 (0.5) / 0.0720; batch 16
+    // 0.0208 / 0.0425.  The strip kernel ALONE is slower with long runs (0.156 -> 0.159-0.162 ms: a longer tail); on a lane
+    // another batch's kernels run in that tail, and a long run stages its halo once and prefetches every strip but the first.
+    if (c->opt_run_len <= 0 && c->lanes_in_flight > 1) {
+      const long want = (long)(0.6 * 5.0 * std::max(1, c->num_cus));
+      int longest = 1;
+      for (int l = 0; l < F->nlevels; l++) longest = std::max(longest, F->lv[l].nstrips);
+      longest = std::min(longest, 64);                 // (option range; k_frame keeps a 64-bit mask of a run's strips)
+      for (int rl = longest; rl > F->run_len; rl--) {
+        long r = 0;
+        for (int l = 0; l < F->nlevels; l++) r += cdiv(F->lv[l].nstrips, rl);
+        if (r * batch >= want && r <= pf::MAX_ORDER) {
+          F->run_len = rl;
+          break;
+        }
+      }
+    }
   }
   for (int l = 0; l < F->nlevels; l++) {
     F->lv[l].run0 = runs;

@@ -205,7 +205,7 @@ def test_compiler_resources_of_the_two_measured_kernels(tmp_path):
 
 def test_debug_build_plan_reports_the_strip_plan_without_a_device():
     """pislam_debug_build_plan (host only: no device, no allocation): the plan of BASELINE configs[1] (59 strips per VGA pyramid
-    at batch 256, 2 strips per run for a single context and 4 for a lane of a depth-3 pipeline; 76 shorter strips and single-
+    at batch 256, 2 strips per run for a single context and whole levels for a lane of a depth-3 pipeline; 76 shorter strips and single-
     strip runs for one pyramid), the bucket selection pass's units, and the refusals (12-bit coordinates, staged pipeline)."""
     import ctypes
     from pislam_amd import capi, synth
@@ -223,7 +223,9 @@ def test_debug_build_plan_reports_the_strip_plan_without_a_device():
     rc, s, _ = plan(256)
     assert rc == 0 and s[0] == 8 and s[1] == 59 and s[4] == 2 and s[6] <= 160 * 1024 // 5, s
     rc, s3, _ = plan(256, lanes=3)
-    assert rc == 0 and s3[1] == 59 and s3[4] == 4 and s3[2] < s[2], (s, s3)        # longer runs, fewer workgroups
+    assert rc == 0 and s3[1] == 59 and s3[4] == 19 and s3[2] == 8, (s, s3)          # a lane: whole levels per workgroup (1.6 per slot)
+    rc, s3b, _ = plan(64, lanes=3)
+    assert rc == 0 and s3b[1] == 76 and s3b[4] == 9 and s3b[2] == 12, s3b                     # batch 64: the longest runs that leave 0.6 per slot
     rc, s1, _ = plan(1)
     assert rc == 0 and s1[1] == 76 and s1[4] == 1 and s1[2] == 76, s1
     rc, sb, _ = plan(256, lbs=4)
