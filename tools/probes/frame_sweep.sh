@@ -18,7 +18,7 @@ print("$*", "| call ms", ms, "kp", kp, "parity", ok, "|", [(r["Name"].split("(")
 P
   rm -rf $d $d.json
 }
-for w in "" "--workload demo-photo"; do
+for w in ""; do
 run $w "$@"
 run $w --opt strip_rows_max=16 "$@"
 run $w --opt strip_rows_max=20 "$@"

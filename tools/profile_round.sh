@@ -4,7 +4,7 @@
 # (separate --pmc passes: FETCH_SIZE | WRITE_SIZE | TCC | SQ instructions | SQ LDS / activity), the bench lines (which quote those counters when the
 # kernel sources match), rocprofv3 --kernel-trace --stats of the same commands — and copies the counter JSONs to
 # profiles/ so that the bench lines of THIS run can already quote them.
-tag=${1:-r05}
+tag=${1:-r06}
 root=${GRAFT_REPO_ROOT:-$(pwd)}
 out=$root/gpurun_out/$tag
 mkdir -p $out
@@ -78,6 +78,11 @@ done
 (cd $root && bash tools/pmc_ablate.sh --streams 1) > $out/phase_ablation.txt 2>&1
 (cd $root && bash tools/pmc_ablate.sh --streams 1 --log-bucket-size 4 --bucket-limit 3 --opt bucket_select=0) > $out/phase_ablation_buckets43_in_strip_selection.txt 2>&1
 rm -rf $root/gpurun_out/abl_*
+# per-phase counters of pf::k_gather_orb (cumulative ablations of its profiling instantiation)
+(cd $root && bash tools/pmc_ablate_gather.sh) > $out/phase_ablation_gather.txt 2>&1
+# round 6 probes: the one-launch frame path under other strip plans; the one-launch pyramid build with parts of its protocol off
+(cd $root && bash tools/probes/frame_sweep.sh) > $out/frame_plan_sweep.txt 2>&1
+(cd $root && python tools/probes/chain_probe.py 2>&1 | grep "us per build\|fault") > $out/build_chain_probe.txt
 # workgroup wall-clock share of the strip kernel's phases (clock64 around the phases of every strip, profiling build):
 # cycles per strip of one eager launch (the first lines: the later ones come from bench.py's 16-launch bracket)
 python $root/bench.py --steps 3 --warmup 1 --streams 1 --graph 0 --no-cpu-baseline --ablate 8192 2>&1 | grep "cycles/strip" | head -3 > $out/phase_cycles.txt

@@ -1,7 +1,7 @@
 #!/bin/bash
 # usage (GPU box): bash tools/round_final.sh <tag> — the round's closing run: GPU suite, fuzz campaign on the final sources
 # (hash recorded), then tools/profile_round.sh
-tag=${1:-r05}
+tag=${1:-r06}
 root=${GRAFT_REPO_ROOT:-$(pwd)}
 out=$root/gpurun_out/$tag; mkdir -p $out
 cd $root
