@@ -178,7 +178,7 @@ def other_workloads(args, timeout_s: float = 90.0):
     import subprocess
     recs, ok = {}, True
     for name, extra in OTHER_WORKLOADS:
-        cmd = [sys.executable, os.path.abspath(__file__), "--steps", str(args.other_steps), "--warmup", "3", "--spin-s", "0.25",
+        cmd = [sys.executable, os.path.abspath(__file__), "--steps", str(args.other_steps), "--warmup", "5", "--spin-s", "0.4",
                "--no-cpu-baseline", "--no-one-pyramid", "--no-other-workloads", "--parity-pyramids", "8",
                "--streams", str(args.streams), "--graph", str(args.graph)] + extra
         t0 = time.perf_counter()
@@ -245,7 +245,7 @@ def build_parser():
                          "configuration (the reference's demo photo, configs[3] on spec and at the dense shape count, configs[4], the "
                          "README bucket mode <4,3>) as child processes of this one — ms/step, strip-kernel time, keypoints per pyramid and "
                          "parity_in_run of each — so that the driver's ONE line carries a number for every BASELINE config")
-    ap.add_argument("--other-steps", type=int, default=12, help="timed steps of each other_workloads child")
+    ap.add_argument("--other-steps", type=int, default=30, help="timed steps of each other_workloads child")
     ap.add_argument("--dist-backend", default=None,
                     help="override the torch.distributed backend (default nccl = RCCL); 'gloo' lets the N>1 code "
                          "path be exercised with several ranks sharing one GPU (testing only)")
