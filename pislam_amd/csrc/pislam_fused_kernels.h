@@ -196,16 +196,34 @@ __device__ __forceinline__ int half_sum(int v, int half) {
   return half ? s1 : s0;
 }
 
+#ifndef PISLAM_FETCH_X3
+#define PISLAM_FETCH_X3 1
+#endif
+#if PISLAM_FETCH_X3
+// One patch row per lane QUAD: the row's 48-byte window as four 12-byte pieces in four ADJACENT lanes (global_load_dwordx3), so
+// that the four lanes the texture path takes up together fall into one cache line (two when the window straddles a line)
+// instead of the 2.6 lines of "three 16-byte chunks per row" — and the three dword stores that park a piece (lanes 12 bytes
+// apart, rows 48 apart) spread over the banks where the four stores of a 16-byte chunk fell on 8.
+constexpr int ORB_NLD = 4;                          // loads per lane and pair: 62 quads = 248 of 256 slots
+struct OrbPiece {
+  uint32_t x, y, z;
+};
+struct OrbWin {
+  OrbPiece w[ORB_NLD];
+};
+#else
+constexpr int ORB_NLD = 3;
 struct OrbWin {
   uint4 w[3];
 };
+#endif
 // Per-lane geometry of the pair scheme: slot j = lane + 64 j -> (keypoint half, patch row, 16-byte chunk) with
 // the three chunks of a row in ADJACENT lanes (the L1 processes a divergent load at about one distinct cache
 // line per cycle: one or two lines per row instead of three requests).
 struct OrbLane {
   int half, r;                                      // r = patch row index, dy = r - 15 (r = 31 idle)
-  int sl_h[3], sl_park[3], sl_rel[3];
-  bool sl_on[3];
+  int sl_h[ORB_NLD], sl_park[ORB_NLD], sl_rel[ORB_NLD];
+  bool sl_on[ORB_NLD];
   // circle mask of this lane's row (Orb.h:118-121,163-286), folded into dot-product weights — byte j of the 32
   // covers dx = j - 15: m01 = 1 where the pixel belongs to the patch, mdx = |dx| there (0 elsewhere)
   uint32_t m01[8], mdx[8];
@@ -221,6 +239,18 @@ __device__ __forceinline__ OrbLane orb_lane(int lane, int vstep) {
     G.m01[k] = row[k];
     G.mdx[k] = row[8 + k];
   }
+#if PISLAM_FETCH_X3
+#pragma unroll
+  for (int j = 0; j < ORB_NLD; j++) {
+    const int slot = lane + 64 * j;                 // 0..255, 248 used: quad q = slot / 4 -> (keypoint half, patch row)
+    const int q = slot >> 2, k = slot & 3;
+    const int h = q >= 31 ? 1 : 0, row = q - 31 * h;
+    G.sl_h[j] = h;
+    G.sl_on[j] = q < 62;
+    G.sl_rel[j] = row * vstep + 12 * k;             // byte offset of the piece relative to the (16-byte aligned) window origin
+    G.sl_park[j] = h * ORB_PATCH_BYTES + orb_row_ofs(row) + 12 * k;
+  }
+#else
 #pragma unroll
   for (int j = 0; j < 3; j++) {
     const int slot = lane + 64 * j;                 // 0..191, 186 used
@@ -231,6 +261,7 @@ __device__ __forceinline__ OrbLane orb_lane(int lane, int vstep) {
     G.sl_rel[j] = row * vstep + 16 * chunk;         // byte offset of the chunk relative to the patch origin (y-15, x-15)
     G.sl_park[j] = h * ORB_PATCH_BYTES + orb_row_ofs(row) + 16 * chunk;
   }
+#endif
   return G;
 }
 // Issue the loads of one pair (p0 / p1: packed keypoints in stacked coordinates, 0 = absent).  vstep % 16 == 0
@@ -244,59 +275,42 @@ __device__ __forceinline__ OrbWin orb_fetch(const OrbLane &G, uint32_t p0, uint3
   const int org0 = (decode_y(p0) - 15) * vstep + (decode_x(p0) - 15);
   const int org1 = (decode_y(p1) - 15) * vstep + (decode_x(p1) - 15);
   const int d01 = org1 - org0;                      // (wave-uniform: the slot's keypoint is picked by one v_and, not by a select)
+#if PISLAM_FETCH_X3
+#pragma unroll
+  for (int j = 0; j < ORB_NLD; j++) {
+    // (vstep % 16 == 0: aligning the patch origin aligns every row's window; a piece is 4-byte aligned)
+    const uint32_t a = min(((uint32_t)(org0 + (d01 & -G.sl_h[j])) & ~15u) + (uint32_t)G.sl_rel[j], img_bytes32 - 12u);
+    f.w[j] = *(const OrbPiece *)(im + a);           // three adjacent dwords at 4-byte alignment: ONE global_load_dwordx3
+  }
+#else
 #pragma unroll
   for (int j = 0; j < 3; j++) {
     const uint32_t a = min((uint32_t)(org0 + G.sl_rel[j] + (d01 & -G.sl_h[j])) & ~15u, img_bytes32 - 16u);
     f.w[j] = *(const uint4 *)(im + a);
   }
+#endif
   return f;
 }
-// Park the fetched windows of a pair, then moments -> angle bin -> BRIEF.  `dst_base` (wave-uniform) + 4 * `dst_word`
-// (< 2^30): where this half's keypoint keeps its `words` descriptor words (ignored when that keypoint is absent).  `wave_patches`: 2 x
-// ORB_PATCH_BYTES of LDS private to the wave.  `rtab`: the vrecpe estimate table in LDS.
-// `glevel` (profiling instantiation of k_gather_orb only, option "ablate" bits 20..23; 0 in every product kernel): stop the
-// describe after 2 = the fetch, 3 = + parking the windows, 4 = + read-back and moments, 5 = + angle bin, 6 = + BRIEF offset
-// table loads, 7 = + BRIEF sample reads and bit assembly (everything but the descriptor store) — cumulative, so that the
-// difference of two PMC passes is what the phase between them costs (tools/pmc_ablate_gather.sh).
+// Moments -> angle bin -> BRIEF -> descriptor store of a pair whose patches lie in LDS: `prow4` = this lane's patch row, rounded
+// down to a dword (the row's first byte is prow4 + sh3), `bp` = the half's patch origin (byte (dy, dx) at bp + tab offset of
+// (dy + 15, dx + 15)), `tab` = the BRIEF offset table of that LDS layout ([rot][t][r], see make_brief_ofs).  (The tail of orb_describe, kept apart
+// from the parking so that other LDS layouts can share it: round 6 measured one — row bands staged once per strip,
+// tools/probes/band_orb_experiment.patch, docs/experiments.md R6.)
 template <class TAB, bool GHOOKS = false>
-__device__ __forceinline__ void orb_describe(const OrbLane &G, const OrbWin &cur, uint32_t p0, uint32_t p1,
-                                             lds_u8 *wave_patches, int vstep, const TAB *rtab, int words,
-                                             uint8_t *__restrict__ dst_base, const uint32_t dst_word, const int glevel = 0) {
+__device__ __forceinline__ void orb_describe_rows(const OrbLane &G, const lds_u8 *prow4, const uint32_t sh3, const lds_u8 *bp,
+                                                  const uint32_t *__restrict__ tab_base, const bool valid, const TAB *rtab,
+                                                  int words, uint8_t *__restrict__ dst_base, const uint32_t dst_word,
+                                                  const int glevel = 0) {
   const int half = G.half, r = G.r;
-  if (GHOOKS && glevel == 2) {                        // the loads must stay: their registers are "used"
-#pragma unroll
-    for (int j = 0; j < 3; j++) asm volatile("" ::"v"(cur.w[j].x), "v"(cur.w[j].y), "v"(cur.w[j].z), "v"(cur.w[j].w));
-    return;
-  }
-  const uint32_t pme = half ? p1 : p0;
-  const bool valid = pme != 0;
-  const int x = decode_x(pme), y = decode_y(pme);
-  // byte shift of the patch inside its 16-byte chunks: ((y - 15) * vstep + (x - 15)) & 15 with vstep % 16 == 0
-  // (the precondition of this scheme) — the same for every row, and independent of y
-  const uint32_t sh = (uint32_t)(x + 1) & 15u;
-  // (the skewed row starts are only 4-byte aligned: four dword stores per chunk instead of one 16-byte store)
-#pragma unroll
-  for (int j = 0; j < 3; j++)
-    if (G.sl_on[j]) {
-      lds_u32 *d = (lds_u32 *)(wave_patches + G.sl_park[j]);
-      d[0] = cur.w[j].x;
-      d[1] = cur.w[j].y;
-      d[2] = cur.w[j].z;
-      d[3] = cur.w[j].w;
-    }
-  if (GHOOKS && glevel == 3) return;
-  lds_u8 *patch_l = wave_patches + half * ORB_PATCH_BYTES;
-  const lds_u8 *prow = patch_l + orb_row_ofs(r);
   // read the row back aligned to the PATCH: 9 aligned dwords + v_alignbyte (byte-unaligned
   // ds_read_b32 works on gfx950 but costs ~47 stall cycles each — SQ_LDS_UNALIGNED_STALL)
   uint32_t row[8];
   {
-    const lds_u8 *pa = prow + (sh & ~3u);
     uint32_t in[9];
 #pragma unroll
-    for (int k = 0; k < 9; k++) in[k] = *(const lds_u32 *)(pa + 4 * k);
+    for (int k = 0; k < 9; k++) in[k] = *(const lds_u32 *)(prow4 + 4 * k);
 #pragma unroll
-    for (int k = 0; k < 8; k++) row[k] = __builtin_amdgcn_alignbyte(in[k + 1], in[k], sh & 3u);
+    for (int k = 0; k < 8; k++) row[k] = __builtin_amdgcn_alignbyte(in[k + 1], in[k], sh3);
   }
   // moments of this row: sum v and sum |dx| v, left (dx<0) and right (dx>0) separately (Orb.h:123-126).  The
   // circle mask lives in the dot-product weights (a zero weight ignores the pixel), so the row is never ANDed.
@@ -328,10 +342,9 @@ __device__ __forceinline__ void orb_describe(const OrbLane &G, const OrbWin &cur
   //  took 8 + 16 VALU and a 5-cycle hazard pad for the same bits: 24.05 -> 22.9 M VALU per launch together with the
   //  32-bit destination offsets below.  The first measurements of this form were 1.3 % SLOWER per pipelined step: it
   //  needs fewer SGPRs, which let a seventh wave per SIMD in — see the occupancy pin in k_gather_orb.)
-  const uint32_t *tab = ::g_brief_ofs.v + rot * 256 + r;   // defined by the including TU
+  const uint32_t *tab = tab_base + rot * 256 + r;
   // the patch's byte (dy,dx) sits at orb_row_ofs(dy+15) + sh + dx+15 (the table holds the first and last term); sh is
   // the same for every row
-  const lds_u8 *bp = patch_l + sh;
   uint32_t ent[8];
 #pragma unroll
   for (int t = 0; t < 8; t++) ent[t] = tab[32 * t];        // all 8 table loads in flight
@@ -357,6 +370,47 @@ __device__ __forceinline__ void orb_describe(const OrbLane &G, const OrbWin &cur
   }
   // (32-bit byte offset from a wave-uniform base: one multiply and a shift-add instead of a 64-bit multiply-add chain)
   if (valid && r < words) *(uint32_t *)(dst_base + (dst_word * 4u + 4u * (uint32_t)r)) = word;
+}
+
+// Park the fetched windows of a pair, then moments -> angle bin -> BRIEF.  `dst_base` (wave-uniform) + 4 * `dst_word`
+// (< 2^30): where this half's keypoint keeps its `words` descriptor words (ignored when that keypoint is absent).  `wave_patches`: 2 x
+// ORB_PATCH_BYTES of LDS private to the wave.  `rtab`: the vrecpe estimate table in LDS.
+// `glevel` (profiling instantiation of k_gather_orb only, option "ablate" bits 20..23; 0 in every product kernel): stop the
+// describe after 2 = the fetch, 3 = + parking the windows, 4 = + read-back and moments, 5 = + angle bin, 6 = + BRIEF offset
+// table loads, 7 = + BRIEF sample reads and bit assembly (everything but the descriptor store) — cumulative, so that the
+// difference of two PMC passes is what the phase between them costs (tools/pmc_ablate_gather.sh).
+template <class TAB, bool GHOOKS = false>
+__device__ __forceinline__ void orb_describe(const OrbLane &G, const OrbWin &cur, uint32_t p0, uint32_t p1,
+                                             lds_u8 *wave_patches, int vstep, const TAB *rtab, int words,
+                                             uint8_t *__restrict__ dst_base, const uint32_t dst_word, const int glevel = 0) {
+  const int half = G.half, r = G.r;
+  if (GHOOKS && glevel == 2) {                        // the loads must stay: their registers are "used"
+#pragma unroll
+    for (int j = 0; j < ORB_NLD; j++) asm volatile("" ::"v"(cur.w[j].x), "v"(cur.w[j].y), "v"(cur.w[j].z));
+    return;
+  }
+  const uint32_t pme = half ? p1 : p0;
+  const bool valid = pme != 0;
+  const int x = decode_x(pme), y = decode_y(pme);
+  // byte shift of the patch inside its 16-byte chunks: ((y - 15) * vstep + (x - 15)) & 15 with vstep % 16 == 0
+  // (the precondition of this scheme) — the same for every row, and independent of y
+  const uint32_t sh = (uint32_t)(x + 1) & 15u;
+  // (the skewed row starts are only 4-byte aligned: four dword stores per chunk instead of one 16-byte store)
+#pragma unroll
+  for (int j = 0; j < ORB_NLD; j++)
+    if (G.sl_on[j]) {
+      lds_u32 *d = (lds_u32 *)(wave_patches + G.sl_park[j]);
+      d[0] = cur.w[j].x;
+      d[1] = cur.w[j].y;
+      d[2] = cur.w[j].z;
+#if !PISLAM_FETCH_X3
+      d[3] = cur.w[j].w;
+#endif
+    }
+  if (GHOOKS && glevel == 3) return;
+  lds_u8 *patch_l = wave_patches + half * ORB_PATCH_BYTES;
+  orb_describe_rows<TAB, GHOOKS>(G, patch_l + orb_row_ofs(r) + (sh & ~3u), sh & 3u, patch_l + sh, ::g_brief_ofs.v, valid, rtab, words,
+                                 dst_base, dst_word, glevel);
 }
 
 // Scalar copies of the kernel arguments the strip body needs (the by-value FusedParams must not be
