@@ -164,20 +164,22 @@ __device__ __attribute__((noinline)) void harris_overflow(lds_u8 *tile, lds_u8 *
 // ORB for two keypoints per wave (one per 32-lane half) — orbCompute, Orb.h:396-441 — shared by the strip
 // kernel (keypoints described right after their strip's NMS, while the rows they need are still in the L2
 // that just served the strip) and by k_gather_orb (keypoints of strips that took a fallback path).
-//   lane r of a half owns patch row dy = r-15.  Each row's 48-byte window covering x-15..x+16 is fetched as
-//   three 16-byte chunks by ADJACENT lanes (one or two cache lines per row), parked in an LDS patch (pitch
-//   48) and read back patch-aligned with 9 aligned dwords + v_alignbyte; the circle mask (Orb.h:118-121,
+//   lane r of a half owns patch row dy = r-15.  Each row's 48-byte window covering x-15..x+16 is fetched by ONE
+//   LANE QUAD as four 12-byte pieces (global_load_dwordx3; round 6 — until then three 16-byte chunks by adjacent
+//   lanes: PISLAM_FETCH_X3 0), parked in an LDS patch (pitch 48) and read back patch-aligned with 9 aligned dwords +
+//   v_alignbyte; the circle mask (Orb.h:118-121,
 //   163-286) is a per-lane constant; the moments are v_dot4_u32_u8 dot products with the |dx| weights
 //   (Orb.h:123-126); rows are summed across the 32 lanes by DPP; every lane evaluates the angle bin
 //   (Orb.h:310-387); the 256 BRIEF tests (Brief.h:52) read the LDS patch through the precomputed offset
 //   table g_brief_ofs, eight tests per lane = one descriptor byte per lane.
 // ===========================================================================
 constexpr int OWAVES = 4;                           // waves per k_gather_orb workgroup
-// One 48-byte (3 x 16 B) window per patch row, rows 13 dwords apart: an ODD dword pitch puts the 32 rows of a patch on 32
-// different banks for the 9 row reads of the moments (lane = row), and the four dword stores that park a 16-byte chunk
-// (lanes = (row, chunk), 13 row + 4 chunk + i) spread over the banks as well: 48 LDS cycles per pair instead of 68 with the
-// layout of rounds 2-5 (12-dword rows skewed by one dword per 8 rows: read-back conflict-free too, but the chunk stores
-// of 32 lanes fell on 8 banks).  (A pitch of 12 dwords alone puts rows r, r+8, r+16, r+24 on the same banks.)
+// One 48-byte window per patch row.  Default layout (PISLAM_ORB_PITCH_DW 12): rows 12 dwords apart, skewed by one dword per
+// 8 rows — the 9 row reads of the moments (lane = row) are conflict-free (a pitch of 12 dwords alone puts rows r, r+8, r+16,
+// r+24 on the same banks), and so are the three dword stores that park a 12-byte piece (lanes = (row, piece): 12 row + 3
+// piece + i hits 32 different banks for the 8 rows x 4 pieces of a half-wave).  With the 16-byte chunks of rounds 2-5 the
+// four stores of a chunk fell on 8 banks (4-way: 5.6 M of the kernel's 13.8 M conflict cycles per launch, 1.5 M now); rows 13
+// dwords apart (PISLAM_ORB_PITCH_DW 13, round 6) cured that at the price of 1 KB more LDS per workgroup and were not kept.
 constexpr int ORB_PITCH = 4 * PISLAM_ORB_PITCH_DW;
 __host__ __device__ constexpr int orb_row_ofs(int r) { return PISLAM_ORB_PITCH_DW == 12 ? r * 48 + 4 * (r >> 3) : r * ORB_PITCH; }
 // 31 rows (the idle lane's row 31 reads harmless bytes of whatever follows) + slack for the byte shift, a multiple of 16
