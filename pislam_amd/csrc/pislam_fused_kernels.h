@@ -197,7 +197,27 @@ __device__ __forceinline__ int half_sum(int v, int half) {
   const int s0 = __builtin_amdgcn_readlane(v, 31), s1 = __builtin_amdgcn_readlane(v, 63);
   return half ? s1 : s0;
 }
+// ... of two values at once, the two chains' steps alternating
+__device__ __forceinline__ void half_sum2(int &a, int &b, int half) {
+  a += __builtin_amdgcn_update_dpp(0, a, 0x111, 0xf, 0xf, true);
+  b += __builtin_amdgcn_update_dpp(0, b, 0x111, 0xf, 0xf, true);
+  a += __builtin_amdgcn_update_dpp(0, a, 0x112, 0xf, 0xf, true);
+  b += __builtin_amdgcn_update_dpp(0, b, 0x112, 0xf, 0xf, true);
+  a += __builtin_amdgcn_update_dpp(0, a, 0x114, 0xf, 0xf, true);
+  b += __builtin_amdgcn_update_dpp(0, b, 0x114, 0xf, 0xf, true);
+  a += __builtin_amdgcn_update_dpp(0, a, 0x118, 0xf, 0xf, true);
+  b += __builtin_amdgcn_update_dpp(0, b, 0x118, 0xf, 0xf, true);
+  a += __builtin_amdgcn_update_dpp(0, a, 0x142, 0xa, 0xf, false);
+  b += __builtin_amdgcn_update_dpp(0, b, 0x142, 0xa, 0xf, false);
+  const int a0 = __builtin_amdgcn_readlane(a, 31), a1 = __builtin_amdgcn_readlane(a, 63);
+  const int b0 = __builtin_amdgcn_readlane(b, 31), b1 = __builtin_amdgcn_readlane(b, 63);
+  a = half ? a1 : a0;
+  b = half ? b1 : b0;
+}
 
+#ifndef PISLAM_MERGE_FAST
+#define PISLAM_MERGE_FAST 1
+#endif
 #ifndef PISLAM_FETCH_X3
 #define PISLAM_FETCH_X3 1
 #endif
@@ -280,7 +300,11 @@ __device__ __forceinline__ OrbWin orb_fetch(const OrbLane &G, uint32_t p0, uint3
 #if PISLAM_FETCH_X3
 #pragma unroll
   for (int j = 0; j < ORB_NLD; j++) {
-    // (vstep % 16 == 0: aligning the patch origin aligns every row's window; a piece is 4-byte aligned)
+    // (vstep % 16 == 0: aligning the patch origin aligns every row's window; a piece is 4-byte aligned.  A piece that starts
+    //  within 12 bytes of the end of the buffer is moved back as a whole — its bytes are then NOT where the patch expects
+    //  them: harmless, because such a piece holds no patch byte.  The batch entry points require border >= 16, so the last row
+    //  a patch uses is at most the buffer's last row but one, a piece reaches at most 17 bytes past a patch byte, and a
+    //  pyramid row is at least that long: every piece that holds a patch byte ends inside the buffer.)
     const uint32_t a = min(((uint32_t)(org0 + (d01 & -G.sl_h[j])) & ~15u) + (uint32_t)G.sl_rel[j], img_bytes32 - 12u);
     f.w[j] = *(const OrbPiece *)(im + a);           // three adjacent dwords at 4-byte alignment: ONE global_load_dwordx3
   }
@@ -323,8 +347,10 @@ __device__ __forceinline__ void orb_describe_rows(const OrbLane &G, const lds_u8
   for (int k = 0; k < 4; k++) left = __builtin_amdgcn_udot4(row[k], G.mdx[k], left, false);        // dx -15 .. 0
 #pragma unroll
   for (int k = 4; k < 8; k++) right = __builtin_amdgcn_udot4(row[k], G.mdx[k], right, false);      // dx 1 .. 15 (16 masked)
-  const int m10 = half_sum((int)right - (int)left, half);
-  const int m01 = half_sum((r - 15) * (int)sv, half);
+  // (the two reductions interleaved: each DPP step must wait two cycles for its own previous result — the other chain's step
+  //  fills one of them; |dy| <= 16, sv < 2^13: the full-rate 24-bit multiply)
+  int m10 = (int)right - (int)left, m01 = __mul24(r - 15, (int)sv);
+  half_sum2(m10, m01, half);
   if (GHOOKS && glevel == 4) {
     asm volatile("" ::"v"(m10), "v"(m01));
     return;
@@ -907,9 +933,35 @@ __device__ __forceinline__ void strip_body(const StripArgs A, const FusedLevel L
     }
     if (ng > 0 && !(ablate & 16)) pretest_batch(lane < ng, lane < ng ? qg[lane] : grp_base + (uint32_t)lin_lo);
     ng = 0;
-    // left-over candidates (< 64): one partial batch per wave — cheaper than a barrier to merge them
+#if PISLAM_MERGE_FAST
+    // Left-over candidates (< 64 per wave): the four waves' left-overs as ONE list.  A wave queues ~156 candidates per strip —
+    // two full batches and a partial one, so that three of ten FAST batches ran half empty; every wave now leaves its
+    // count in the first word of its (dead) group queue, and behind a barrier wave b runs batch b of the concatenation of
+    // the four candidate queues (~2 batches instead of 4: one FAST batch in seven saved).
+    if (lane == 0) qg[0] = (uint32_t)nf;
+    lds_barrier();
+    {
+      static_assert(WAVES == 4, "left-over merge: four candidate queues");
+      const int n0 = __builtin_amdgcn_readfirstlane((int)queues[0 * QCAP]), n1 = __builtin_amdgcn_readfirstlane((int)queues[1 * QCAP]);
+      const int n2 = __builtin_amdgcn_readfirstlane((int)queues[2 * QCAP]), n3 = __builtin_amdgcn_readfirstlane((int)queues[3 * QCAP]);
+      const int p1 = n0, p2 = n0 + n1, p3 = p2 + n2, total = p3 + n3;
+      if (!(ablate & 2))
+        for (int b0 = 64 * wave; b0 < total; b0 += 64 * WAVES) {
+          const int idx = min(b0 + lane, total - 1);
+          // queue of entry idx: w = number of prefix boundaries at or below it; its word: queues[w * QCAP + QCAP_G + idx - p_w]
+          int off = QCAP_G + idx;
+          off = idx >= p1 ? QCAP + QCAP_G + idx - p1 : off;
+          off = idx >= p2 ? 2 * QCAP + QCAP_G + idx - p2 : off;
+          off = idx >= p3 ? 3 * QCAP + QCAP_G + idx - p3 : off;
+          fast_batch(b0 + lane < total, queues[off]);
+        }
+    }
+    nf = 0;
+#else
+    // left-over candidates (< 64): one partial batch per wave
     if (nf > 0 && !(ablate & 2)) fast_batch(lane < nf, qf[min(lane, nf - 1)]);
     nf = 0;
+#endif
     lds_barrier();
     mark(1);
     {
