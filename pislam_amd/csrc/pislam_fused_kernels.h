@@ -215,9 +215,6 @@ __device__ __forceinline__ void half_sum2(int &a, int &b, int half) {
   b = half ? b1 : b0;
 }
 
-#ifndef PISLAM_MERGE_FAST
-#define PISLAM_MERGE_FAST 1
-#endif
 #ifndef PISLAM_FETCH_X3
 #define PISLAM_FETCH_X3 1
 #endif
@@ -933,35 +930,9 @@ __device__ __forceinline__ void strip_body(const StripArgs A, const FusedLevel L
     }
     if (ng > 0 && !(ablate & 16)) pretest_batch(lane < ng, lane < ng ? qg[lane] : grp_base + (uint32_t)lin_lo);
     ng = 0;
-#if PISLAM_MERGE_FAST
-    // Left-over candidates (< 64 per wave): the four waves' left-overs as ONE list.  A wave queues ~156 candidates per strip —
-    // two full batches and a partial one, so that three of ten FAST batches ran half empty; every wave now leaves its
-    // count in the first word of its (dead) group queue, and behind a barrier wave b runs batch b of the concatenation of
-    // the four candidate queues (~2 batches instead of 4: one FAST batch in seven saved).
-    if (lane == 0) qg[0] = (uint32_t)nf;
-    lds_barrier();
-    {
-      static_assert(WAVES == 4, "left-over merge: four candidate queues");
-      const int n0 = __builtin_amdgcn_readfirstlane((int)queues[0 * QCAP]), n1 = __builtin_amdgcn_readfirstlane((int)queues[1 * QCAP]);
-      const int n2 = __builtin_amdgcn_readfirstlane((int)queues[2 * QCAP]), n3 = __builtin_amdgcn_readfirstlane((int)queues[3 * QCAP]);
-      const int p1 = n0, p2 = n0 + n1, p3 = p2 + n2, total = p3 + n3;
-      if (!(ablate & 2))
-        for (int b0 = 64 * wave; b0 < total; b0 += 64 * WAVES) {
-          const int idx = min(b0 + lane, total - 1);
-          // queue of entry idx: w = number of prefix boundaries at or below it; its word: queues[w * QCAP + QCAP_G + idx - p_w]
-          int off = QCAP_G + idx;
-          off = idx >= p1 ? QCAP + QCAP_G + idx - p1 : off;
-          off = idx >= p2 ? 2 * QCAP + QCAP_G + idx - p2 : off;
-          off = idx >= p3 ? 3 * QCAP + QCAP_G + idx - p3 : off;
-          fast_batch(b0 + lane < total, queues[off]);
-        }
-    }
-    nf = 0;
-#else
-    // left-over candidates (< 64): one partial batch per wave
+    // left-over candidates (< 64): one partial batch per wave — cheaper than a barrier to merge them
     if (nf > 0 && !(ablate & 2)) fast_batch(lane < nf, qf[min(lane, nf - 1)]);
     nf = 0;
-#endif
     lds_barrier();
     mark(1);
     {
