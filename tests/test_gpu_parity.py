@@ -1039,6 +1039,35 @@ def test_bench_self_launch_two_ranks_sharing_this_gpu():
     assert d["n_gpus"] == 2 and d["value"] > 0 and d["config"]["global_batch"] == 16
 
 
+@pytest.mark.parametrize("w,h,seed", [(128, 96, 1007), (192, 80, 1007), (64, 128, 1008)])
+def test_keypoints_at_the_last_pixel_of_the_buffer(gpu_ctx, orc, w, h, seed, frame):
+    """ONE level that IS the buffer (w = vstep, h = rows), uniform noise: keypoints on the last classifiable row (h - 17) and
+    column (w - 17), one of them on both — the patch rows of the gather's 48-byte windows then end one row above the end of
+    the allocation, and the 12-byte pieces of a window (pf::orb_fetch) that reach past it are moved back as a whole: no
+    piece that holds a patch byte may be among them.  The LAST pyramid of the batch ends the tensor."""
+    import torch
+    from pislam_amd.frontend import OrbFrontend
+    levels = [(w, h, 0)]
+    rng = np.random.default_rng(seed)
+    img = rng.integers(0, 256, (h, w), dtype=np.uint8)
+    okp, odesc, _ = orc.pyramid(img, levels)
+    x, y = (okp >> 12) & 0xfff, okp & 0xfff
+    assert ((x == w - 17) & (y == h - 17)).any() and (y == h - 17).sum() > 3 and (x == w - 17).sum() > 3
+    dev = torch.device("cuda:0")
+    for batch in (1, 3):
+        pyr = np.repeat(img[None], batch, axis=0)
+        fe = OrbFrontend(levels, vstep=w, rows=h, max_keypoints=2048, ctx=gpu_ctx)
+        kp, desc, counts = fe.alloc_outputs(batch, dev)
+        fe(torch.from_numpy(pyr).to(dev), kp, desc, counts)
+        torch.cuda.synchronize()
+        c = counts.cpu().numpy().view(np.uint32)
+        k = kp.cpu().numpy().view(np.uint32)
+        d = desc.cpu().numpy().view(np.uint32)
+        for b in range(batch):
+            assert c[b] == len(okp)
+            assert (k[b, :c[b]] == okp).all() and (d[b, :c[b]] == odesc).all(), (batch, b)
+
+
 @pytest.mark.parametrize("border", [16, 17, 19, 20, 32])
 def test_fused_borders(gpu_ctx, orc, border, frame):
     """Any border >= 16 (odd ones too: block origins and x-tile edges then fall off dword boundaries), with
