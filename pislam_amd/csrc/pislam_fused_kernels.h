@@ -185,19 +185,10 @@ __host__ __device__ constexpr int orb_row_ofs(int r) { return PISLAM_ORB_PITCH_D
 // 31 rows (the idle lane's row 31 reads harmless bytes of whatever follows) + slack for the byte shift, a multiple of 16
 constexpr int ORB_PATCH_BYTES = PISLAM_ORB_PITCH_DW == 12 ? 32 * 48 + 32 : (31 * ORB_PITCH + 4 + 15) / 16 * 16;
 
-// Sum over each 32-lane half of the wave, result in every lane of that half.  DPP row shifts
+// Sums over each 32-lane half of the wave, results in every lane of that half: two values at once.  DPP row shifts
 // (zero fill) leave each 16-lane row's sum in its last lane, row_bcast:15 folds row 0 into row 1 and
-// row 2 into row 3, two v_readlane pick the totals up.
-__device__ __forceinline__ int half_sum(int v, int half) {
-  v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);   // row_shr:1
-  v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);   // row_shr:2
-  v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);   // row_shr:4
-  v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);   // row_shr:8
-  v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);  // row_bcast:15 into rows 1 and 3
-  const int s0 = __builtin_amdgcn_readlane(v, 31), s1 = __builtin_amdgcn_readlane(v, 63);
-  return half ? s1 : s0;
-}
-// ... of two values at once, the two chains' steps alternating
+// row 2 into row 3, two v_readlane per value pick the totals up.  The two chains' steps alternate: a DPP step must
+// wait two cycles for its own previous result, the other chain's step fills one of them.
 __device__ __forceinline__ void half_sum2(int &a, int &b, int half) {
   a += __builtin_amdgcn_update_dpp(0, a, 0x111, 0xf, 0xf, true);
   b += __builtin_amdgcn_update_dpp(0, b, 0x111, 0xf, 0xf, true);
@@ -222,7 +213,9 @@ __device__ __forceinline__ void half_sum2(int &a, int &b, int half) {
 // One patch row per lane QUAD: the row's 48-byte window as four 12-byte pieces in four ADJACENT lanes (global_load_dwordx3), so
 // that the four lanes the texture path takes up together fall into one cache line (two when the window straddles a line)
 // instead of the 2.6 lines of "three 16-byte chunks per row" — and the three dword stores that park a piece (lanes 12 bytes
-// apart, rows 48 apart) spread over the banks where the four stores of a 16-byte chunk fell on 8.
+// apart, rows 48 apart) spread over the banks where the four stores of a 16-byte chunk fell on 8.  Measured per launch (256 VGA
+// pyramids): vector-L1 tag look-ups 22.4 -> 18.8 M, line requests to the L2 unchanged (6.1 M: lines are shared between the two
+// keypoints of one load instruction only), LDS bank-conflict cycles 13.8 -> 9.8 M, the kernel 1.4 us shorter.
 constexpr int ORB_NLD = 4;                          // loads per lane and pair: 62 quads = 248 of 256 slots
 struct OrbPiece {
   uint32_t x, y, z;
@@ -930,7 +923,9 @@ __device__ __forceinline__ void strip_body(const StripArgs A, const FusedLevel L
     }
     if (ng > 0 && !(ablate & 16)) pretest_batch(lane < ng, lane < ng ? qg[lane] : grp_base + (uint32_t)lin_lo);
     ng = 0;
-    // left-over candidates (< 64): one partial batch per wave — cheaper than a barrier to merge them
+    // left-over candidates (< 64): one partial batch per wave.  (Round 6 measured the alternative — the four waves' left-overs
+    // as one list behind a barrier, wave b running batch b of it: 0.12 M of 62.75 M VALU saved per launch, the kernel 1.6 %
+    // slower: docs/experiments.md R6.)
     if (nf > 0 && !(ablate & 2)) fast_batch(lane < nf, qf[min(lane, nf - 1)]);
     nf = 0;
     lds_barrier();
